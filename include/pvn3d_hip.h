@@ -1,0 +1,166 @@
+/*
+ * pvn3d_hip.h -- C ABI of libpvn3d_hip.so: MI355X (gfx950) kernels for PVN3D's per-point
+ * voting hot path.  This is the drop-in boundary: plain pointers and sizes, no torch types.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - the library never allocates or frees device memory: outputs and scratch are passed in;
+ *   - `stream` is a hipStream_t (passed as void*; NULL = the default stream).  Work is enqueued
+ *     on it and the call returns without synchronising unless documented otherwise;
+ *   - return value: 0 on success, otherwise a hipError_t code (launch / argument error).
+ *     Nothing prints or exits (the reference's CUDA_CHECK_ERRORS, cuda_utils.h:30-39, calls
+ *     exit(-1); the Python shim turns a non-zero return into RuntimeError instead);
+ *   - re-entrant: no global mutable state; the device is the one current on the calling thread.
+ *   - fp32 data, int32 indices, contiguous row-major tensors exactly as the reference lays
+ *     them out (shapes are given per function).
+ *
+ * Section 1 mirrors, one to one, the `*_kernel_wrapper` functions that the reference's
+ * pybind glue calls (pvn3d/_ext-src/src/{sampling,ball_query,group_points,interpolate}.cpp);
+ * argument order is the reference's with `stream` appended.  Sections 2-3 are fused entry
+ * points for the callers one level up (QueryAndGroup.forward, cal_frame_poses*).
+ */
+#ifndef PVN3D_HIP_H_
+#define PVN3D_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVN3D_ABI_VERSION 1
+int pvn3d_abi_version(void);
+
+/* =============================== 1. pointnet2 _ext ops ================================== */
+
+/* opt_n_threads: pvn3d/_ext-src/include/cuda_utils.h:15-19.  Host helper; it fixes the FPS
+ * tie-break order (see pvn3d_furthest_point_sampling). */
+int pvn3d_opt_n_threads(int work_size);
+
+/* replaces furthest_point_sampling_kernel_wrapper, pvn3d/_ext-src/src/sampling_gpu.cu:175-229
+ * (declared sampling.cpp:12-14).  dataset (b,n,3) -> idxs (b,m).  `temp` (b,n) is the
+ * reference's scratch; it may be NULL (distances live in registers here) -- if given it is
+ * left untouched.  Index-exact with the reference block of opt_n_threads(n) threads,
+ * including its tie-break order and the `x^2+y^2+z^2 <= 1e-3` skip rule. */
+int pvn3d_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                  int* idxs, void* stream);
+
+/* replaces gather_points_kernel_wrapper, sampling_gpu.cu:22-29.
+ * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
+int pvn3d_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,
+                        float* out, void* stream);
+
+/* replaces gather_points_grad_kernel_wrapper, sampling_gpu.cu:49-57.
+ * grad_out (b,c,npoints), idx (b,npoints) -> grad_points (b,c,n); zero-fills grad_points
+ * itself (the reference relies on torch::zeros, sampling.cpp:54-56). */
+int pvn3d_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out,
+                             const int* idx, float* grad_points, void* stream);
+
+/* replaces query_ball_point_kernel_wrapper, ball_query_gpu.cu:46-53.
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample); writes every slot (rows without a hit
+ * are zero, as with the reference's torch::zeros, ball_query.cpp:19-21). */
+int pvn3d_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz,
+                     const float* xyz, int* idx, void* stream);
+
+/* replaces group_points_kernel_wrapper, group_points_gpu.cu:30-38.
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+int pvn3d_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                       const int* idx, float* out, void* stream);
+
+/* replaces group_points_grad_kernel_wrapper, group_points_gpu.cu:66-75.
+ * grad_out (b,c,npoints,nsample) -> grad_points (b,c,n); zero-fills grad_points itself. */
+int pvn3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                            const float* grad_out, const int* idx, float* grad_points,
+                            void* stream);
+
+/* replaces three_nn_kernel_wrapper, interpolate_gpu.cu:61-68.
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3) */
+int pvn3d_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                   int* idx, void* stream);
+
+/* replaces three_interpolate_kernel_wrapper, interpolate_gpu.cu:103-111.
+ * points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) */
+int pvn3d_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                            const float* weight, float* out, void* stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper, interpolate_gpu.cu:145-154.
+ * grad_out (b,c,n), idx/weight (b,n,3) -> grad_points (b,c,m); zero-fills grad_points.
+ * refbug_compat != 0 reproduces what the reference binary actually returns: its
+ * interpolate.cpp:89-93 calls the FORWARD wrapper with m and n swapped. */
+int pvn3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                 const int* idx, const float* weight, float* grad_points,
+                                 int refbug_compat, void* stream);
+
+/* ============================ 2. fused set-abstraction ops ============================== */
+
+/* Two ball queries sharing centres and points in one scan (the two scales of a
+ * PointnetSAModuleMSG level, pvn3d/lib/pointnet2_utils/pointnet2_modules.py:57-60).
+ * idx0 (b,m,nsample0) for radius0, idx1 (b,m,nsample1) for radius1; each identical to a
+ * separate pvn3d_ball_query. */
+int pvn3d_ball_query_pair(int b, int n, int m, float radius0, int nsample0, float radius1,
+                          int nsample1, const float* new_xyz, const float* xyz, int* idx0,
+                          int* idx1, void* stream);
+
+/* QueryAndGroup.forward (pvn3d/lib/pointnet2_utils/pointnet2_utils.py:293-330) minus the
+ * ball query: writes the concatenated tensor directly.
+ *   out (b, 3*use_xyz + c, m, nsample):
+ *     channels [0,3)   = xyz[idx] - new_xyz        (grouping_operation(xyz^T) ; -= ; :313-314)
+ *     channels [3,3+c) = features[idx]             (:317, torch.cat :319-321)
+ * xyz (b,n,3), new_xyz (b,m,3), features (b,c,n) or NULL (c = 0), idx (b,m,nsample). */
+int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xyz,
+                             const float* xyz, const float* new_xyz, const float* features,
+                             const int* idx, float* out, void* stream);
+
+/* ========================= 3. vote -> MeanShift -> pose (post-proc) ===================== */
+
+/* Batched MeanShiftTorch.fit (pvn3d/lib/utils/meanshift_pytorch.py:18-51).
+ * n_seg independent fits.  pts is a (total,4) float array (x,y,z,unused) holding the
+ * segments back to back; segment s occupies rows [seg_off[s], seg_off[s]+seg_cnt[s]).
+ * seg_off / seg_cnt are DEVICE int arrays (counts may come from an on-device compaction);
+ * max_cnt_host >= every seg_cnt is the host-known bound that sizes the grid.
+ * Outputs per segment: ctr (n_seg,3); labels (total) uint8 aligned with pts rows;
+ * iters (n_seg) number of mean-shift iterations run (== the reference's `it`).
+ * A segment with cnt == 0 yields ctr = 0, iters = 0.
+ * workspace: >= pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter) bytes of device
+ * scratch.  poll_host: optional PINNED host int[2] used to stop enqueuing once every fit
+ * has converged (the call then blocks on events every `poll_every` iterations, like the
+ * reference's per-iteration host test, meanshift_pytorch.py:42); with poll_host == NULL the
+ * call is fully asynchronous and enqueues all max_iter+1 iterations (finished fits exit at
+ * block start). */
+size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
+int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,
+                              int n_seg, int total, int max_cnt_host, float bandwidth,
+                              int max_iter, float* ctr, uint8_t* labels, int* iters,
+                              void* workspace, size_t workspace_bytes, int* poll_host,
+                              int poll_every, void* stream);
+
+/* Vote assembly + order-preserving mask compaction
+ * (cal_frame_poses_lm, pvn3d/lib/utils/pvn3d_eval_utils.py:160-175; cal_frame_poses :41-42,83,91-92).
+ * For instance i = (frame inst_frame[i], class inst_cls[i]) the rows p with
+ * mask[frame, p] == cls are taken in ascending p ("row r" = r-th such point).  If sel != NULL,
+ * row r is kept only when sel[i*sel_inst_stride + r] != 0 -- sel is typically the `labels`
+ * output of an earlier centre fit on the same instance (in_pred_kp = cls_voted_kps[:, ctr_labels, :],
+ * :91-92); when no row is selected row 0 is kept (`ctr_labels[0] = 1`, :86-87, 178-179).
+ * For v in [v_first, v_first+v_count): vote v of row p = pcld[p] - off_v[p] with
+ * off_v = pred_kp_of[frame, v] for v < n_kps and ctr_of[frame, 0] for v == n_kps.
+ * pcld (F,n_pts,3); mask (F,n_pts) int32; ctr_of (F,1,n_pts,3); pred_kp_of (F,n_kps,n_pts,3).
+ * Output: votes ((n_inst*(n_kps+1))*n_pts, 4) float -- segment s = i*(n_kps+1)+v starts at row
+ * s*n_pts; seg_off[s] / seg_cnt[s] are filled for the produced segments only.
+ * inst_frame / inst_cls: device int arrays (n_inst). */
+int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst, int v_first, int v_count,
+                       const float* pcld, const int* mask, const float* ctr_of,
+                       const float* pred_kp_of, const int* inst_frame, const int* inst_cls,
+                       const uint8_t* sel, long long sel_inst_stride, float* votes,
+                       int* seg_off, int* seg_cnt, void* stream);
+
+/* Batched best_fit_transform (pvn3d/lib/utils/basic_utils.py:47-80): for each of n_sets,
+ * A (npts,3) -> B (npts,3), T (3,4) float64 row-major [R|t].  valid (n_sets) int or NULL:
+ * sets with valid == 0 get the identity pose (pvn3d_eval_utils.py:172-173). */
+int pvn3d_best_fit_transform(int n_sets, int npts, const float* A, const float* B,
+                             const int* valid, double* T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVN3D_HIP_H_ */

@@ -1,0 +1,56 @@
+"""ctypes loader for libpvn3d_hip.so -- the C-ABI boundary (include/pvn3d_hip.h).
+
+Fails loudly: if the shared library is missing or does not export a declared symbol, importing
+this module raises.  There is deliberately no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvn3d_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); one entry per declaration in include/pvn3d_hip.h
+SIGNATURES = {
+    "pvn3d_abi_version": (_i, []),
+    "pvn3d_opt_n_threads": (_i, [_i]),
+    "pvn3d_furthest_point_sampling": (_i, [_i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_gather_points": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_gather_points_grad": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_ball_query": (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _p]),
+    "pvn3d_group_points": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_three_nn": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_three_interpolate": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "pvn3d_ball_query_pair": (_i, [_i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_group_xyz_features": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_meanshift_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pvn3d_meanshift_fit_batch": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p, _i, _p]),
+    "pvn3d_vote_compact": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p]),
+    "pvn3d_best_fit_transform": (_i, [_i, _i, _p, _p, _p, _p, _p]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "pvn3d_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+        " or `make -C pvn3d_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == ABI mismatch, by design
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.pvn3d_abi_version() != 1:
+    raise ImportError("pvn3d_amd: libpvn3d_hip.so ABI version mismatch")
+
+
+def check(rc, what):
+    """Non-zero return (a hipError_t) -> RuntimeError, like AT_CHECK in the reference glue."""
+    if rc != 0:
+        raise RuntimeError("%s failed: hipError %d" % (what, rc))

@@ -1,0 +1,195 @@
+// interpolate.hip -- three_nn / three_interpolate (feature propagation) for gfx950.
+//
+// Replaces pvn3d/_ext-src/src/interpolate_gpu.cu (reference): three_nn_kernel (:9-59),
+// three_interpolate_kernel (:72-101), three_interpolate_grad_kernel (:116-143).
+//
+// three_nn: one lane per unknown point, the known cloud is staged through LDS in 1024-point
+// chunks and every lane reads the same LDS address (broadcast, conflict-free); insertion with
+// strict '<' so the earlier k wins ties exactly as the reference.  The reference keeps its
+// running bests in double (init 1e40); fp32 with +inf init is equivalent because every
+// candidate is an fp32 value (a d of +inf or NaN is never inserted in either form, and the
+// unfilled slots convert to +inf in both).
+// three_interpolate: same shape as group_points -- a thread owns 4 consecutive unknown
+// points, keeps their 12 indices/weights in registers and loops over channels with one
+// 16-byte store per channel.
+// Arithmetic: -ffp-contract=off; d = ((dx*dx + dy*dy) + dz*dz), out = ((p1*w1 + p2*w2) + p3*w3).
+#include "common.h"
+
+namespace {
+
+constexpr int NN_CHUNK = 1024;
+
+// grid: (ceil(n/256), b)
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
+                                                       const float* __restrict__ unknown,
+                                                       const float* __restrict__ known,
+                                                       float* __restrict__ dist2,
+                                                       int* __restrict__ idx) {
+  __shared__ float s_k[NN_CHUNK * 3];
+  const int bi = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  unknown += (size_t)bi * n * 3;
+  known += (size_t)bi * m * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (j < n) {
+    ux = unknown[j * 3 + 0];
+    uy = unknown[j * 3 + 1];
+    uz = unknown[j * 3 + 2];
+  }
+  float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int k0 = 0; k0 < m; k0 += NN_CHUNK) {
+    const int cnt = min(NN_CHUNK, m - k0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += 256) s_k[t] = known[(size_t)k0 * 3 + t];
+    __syncthreads();
+    for (int kk = 0; kk < cnt; ++kk) {
+      const float dx = ux - s_k[kk * 3 + 0], dy = uy - s_k[kk * 3 + 1],
+                  dz = uz - s_k[kk * 3 + 2];
+      const float d = dx * dx + dy * dy + dz * dz;
+      const int k = k0 + kk;
+      // branch-free form of the if / else-if / else-if chain (interpolate_gpu.cu:38-56)
+      const bool lt1 = d < b1, lt2 = d < b2, lt3 = d < b3;
+      const float nb3 = lt2 ? b2 : (lt3 ? d : b3);
+      const int ni3 = lt2 ? i2 : (lt3 ? k : i3);
+      const float nb2 = lt1 ? b1 : (lt2 ? d : b2);
+      const int ni2 = lt1 ? i1 : (lt2 ? k : i2);
+      b1 = lt1 ? d : b1;
+      i1 = lt1 ? k : i1;
+      b2 = nb2; i2 = ni2;
+      b3 = nb3; i3 = ni3;
+    }
+  }
+  if (j < n) {
+    float* od = dist2 + ((size_t)bi * n + j) * 3;
+    int* oi = idx + ((size_t)bi * n + j) * 3;
+    od[0] = b1; od[1] = b2; od[2] = b3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+  }
+}
+
+// grid: (ceil(n/1024), n_chunks, b), n % 4 == 0
+__global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(
+    int c, int m, int n, int cch, const float* __restrict__ points,
+    const int* __restrict__ idx, const float* __restrict__ weight, float* __restrict__ out) {
+  const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j0 >= n) return;
+  const int bi = blockIdx.z;
+  const int c0 = blockIdx.y * cch;
+  const int c1 = min(c0 + cch, c);
+  int id[12];
+  float w[12];
+  {
+    const int4* ip = reinterpret_cast<const int4*>(idx + ((size_t)bi * n + j0) * 3);
+    const float4* wp = reinterpret_cast<const float4*>(weight + ((size_t)bi * n + j0) * 3);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int4 a = ip[u];
+      const float4 f = wp[u];
+      id[u * 4 + 0] = a.x; id[u * 4 + 1] = a.y; id[u * 4 + 2] = a.z; id[u * 4 + 3] = a.w;
+      w[u * 4 + 0] = f.x; w[u * 4 + 1] = f.y; w[u * 4 + 2] = f.z; w[u * 4 + 3] = f.w;
+    }
+  }
+  const float* row = points + ((size_t)bi * c + c0) * m;
+  float* o = out + ((size_t)bi * c + c0) * n + j0;
+  for (int l = c0; l < c1; ++l) {
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      r[u] = row[id[u * 3 + 0]] * w[u * 3 + 0] + row[id[u * 3 + 1]] * w[u * 3 + 1] +
+             row[id[u * 3 + 2]] * w[u * 3 + 2];
+    *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+    row += m;
+    o += n;
+  }
+}
+
+// any-n fallback / reference-bug-compat path.  out[(bi*c+l)*n_out + j] for j < n_out, with
+// idx/weight batch stride given explicitly.  grid: (ceil(n_out/256), c, b)
+__global__ __launch_bounds__(256) void three_interpolate_scalar_kernel(
+    int c, int m, int n_out, size_t iw_batch_stride, const float* __restrict__ points,
+    const int* __restrict__ idx, const float* __restrict__ weight, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_out) return;
+  const int l = blockIdx.y, bi = blockIdx.z;
+  const int* id = idx + (size_t)bi * iw_batch_stride + (size_t)j * 3;
+  const float* w = weight + (size_t)bi * iw_batch_stride + (size_t)j * 3;
+  const float* row = points + ((size_t)bi * c + l) * m;
+  out[((size_t)bi * c + l) * n_out + j] = row[id[0]] * w[0] + row[id[1]] * w[1] + row[id[2]] * w[2];
+}
+
+// grid: (ceil(n/256), c, b)
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float* __restrict__ grad_out, const int* __restrict__ idx,
+    const float* __restrict__ weight, float* __restrict__ grad_points) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int l = blockIdx.y, bi = blockIdx.z;
+  const int* id = idx + ((size_t)bi * n + j) * 3;
+  const float* w = weight + ((size_t)bi * n + j) * 3;
+  const float g = grad_out[((size_t)bi * c + l) * n + j];
+  float* gp = grad_points + ((size_t)bi * c + l) * m;
+  atomicAdd(gp + id[0], g * w[0]);
+  atomicAdd(gp + id[1], g * w[1]);
+  atomicAdd(gp + id[2], g * w[2]);
+}
+
+}  // namespace
+
+extern "C" int pvn3d_three_nn(int b, int n, int m, const float* unknown, const float* known,
+                              float* dist2, int* idx, void* stream) {
+  if (b <= 0 || n <= 0) return 0;
+  if (m < 0 || !unknown || !known || !dist2 || !idx) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(pvn3d_ceil_div(n, 256), b), dim3(256), 0,
+                     (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* points,
+                                       const int* idx, const float* weight, float* out,
+                                       void* stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = (n % 4 == 0) && (((uintptr_t)out & 15) == 0) &&
+                       (((uintptr_t)idx & 15) == 0) && (((uintptr_t)weight & 15) == 0);
+  if (aligned) {
+    const int gx = pvn3d_ceil_div(n, 1024);
+    int chunks = pvn3d_ceil_div(2048, gx * b);
+    if (chunks < 1) chunks = 1;
+    if (chunks > c) chunks = c;
+    const int cch = pvn3d_ceil_div(c, chunks);
+    chunks = pvn3d_ceil_div(c, cch);
+    hipLaunchKernelGGL(three_interpolate_vec4_kernel, dim3(gx, chunks, b), dim3(256), 0, st, c,
+                       m, n, cch, points, idx, weight, out);
+  } else {
+    hipLaunchKernelGGL(three_interpolate_scalar_kernel, dim3(pvn3d_ceil_div(n, 256), c, b),
+                       dim3(256), 0, st, c, m, n, (size_t)n * 3, points, idx, weight, out);
+  }
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                            const int* idx, const float* weight,
+                                            float* grad_points, int refbug_compat,
+                                            void* stream) {
+  if (b <= 0 || c <= 0 || m <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (refbug_compat) {
+    // interpolate.cpp:89-93: forward kernel with (m_arg = n, n_arg = m); idx/weight batch
+    // stride becomes n_arg*3 = m*3.  Reads stay in bounds only if m <= n (FP modules: m < n).
+    if (n <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(three_interpolate_scalar_kernel, dim3(pvn3d_ceil_div(m, 256), c, b),
+                       dim3(256), 0, st, c, n, m, (size_t)m * 3, grad_out, idx, weight,
+                       grad_points);
+    PVN3D_LAUNCH_CHECK();
+    return 0;
+  }
+  PVN3D_RETURN_IF_ERR(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, st));
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(pvn3d_ceil_div(n, 256), c, b),
+                     dim3(256), 0, st, c, n, m, grad_out, idx, weight, grad_points);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

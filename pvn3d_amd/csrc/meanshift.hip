@@ -1,0 +1,463 @@
+// meanshift.hip -- vote assembly + batched Gaussian mean-shift clustering for gfx950.
+//
+// Replaces, for a whole batch of fits at once, MeanShiftTorch.fit
+// (pvn3d/lib/utils/meanshift_pytorch.py:24-51) and the vote assembly / mask compaction of
+// cal_frame_poses(_lm) (pvn3d/lib/utils/pvn3d_eval_utils.py:41-42, 83, 160-175).
+//
+// The reference materialises (n,n,3) tensors (~150*n^2 bytes of HBM traffic and ~12 launches
+// plus a host sync per iteration).  Here one launch per iteration serves EVERY fit of the
+// batch: a workgroup owns a tile of seeds of one fit (seed state in VGPRs), streams that fit's
+// points through LDS (broadcast reads), and publishes its largest seed shift with one
+// atomicMax.  Compulsory HBM traffic is 32*n bytes per iteration, so the kernel is bound by
+// fp32 VALU + v_exp_f32 issue, not by HBM.
+// Convergence is decided on the device: iteration t of fit s runs iff t == 1 or
+// (max_shift[s][t-1] >= thresh and t-1 <= max_iter) -- the reference's
+// `if max(Adis) < stop_thresh or it > max_iter: break` (:42) -- so finished fits cost one
+// early-exit per workgroup and no host round trip.
+//
+// Numerics (tolerance 1e-4 on centres): seeds and points are kept relative to
+// the fit's first point and pre-scaled by kappa = sqrt(0.5*log2(e))/bw so that the Gaussian
+// weight is exp2(-|c'-a'|^2) (one v_exp_f32, constant factor dropped: it cancels in
+// sum(w*a)/sum(w)).  Centring removes the ~1 m offset of camera-frame coordinates from the fp32
+// accumulators.  The neighbour count / labels pass uses the ORIGINAL coordinates and the
+// oracle's exact unfused fp32 distance so labels are bit-identical to it.
+// This TU is compiled with -ffp-contract=off; FMAs in the hot loop are explicit fmaf().
+#include "common.h"
+
+namespace {
+
+constexpr int MS_THREADS = 256;
+constexpr int MS_CHUNK = 1024;  // points staged in LDS per step (16 KiB)
+
+struct MsState {        // device-side layout inside the caller's workspace
+  float4* cbuf[2];      // seed positions, scaled+centred frame, double-buffered
+  unsigned* maxshift;   // [n_seg][max_iter+2]  float bits (>= 0 so uint order == float order)
+  int* iters;           // [n_seg]
+  unsigned long long* best;  // [n_seg]  (count << 32) | ~index
+  int* active;          // [2]
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState* st) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  const size_t o_c0 = take(sizeof(float4) * (size_t)total);
+  const size_t o_c1 = take(sizeof(float4) * (size_t)total);
+  const size_t o_small = off;  // everything from here is zero-filled per call
+  const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
+  const size_t o_it = take(sizeof(int) * (size_t)n_seg);
+  const size_t o_best = take(sizeof(unsigned long long) * (size_t)n_seg);
+  const size_t o_act = take(sizeof(int) * 2);
+  if (st) {
+    st->cbuf[0] = (float4*)(base + o_c0);
+    st->cbuf[1] = (float4*)(base + o_c1);
+    st->maxshift = (unsigned*)(base + o_ms);
+    st->iters = (int*)(base + o_it);
+    st->best = (unsigned long long*)(base + o_best);
+    st->active = (int*)(base + o_act);
+  }
+  (void)o_small;
+  return off;
+}
+
+// ---------------------------------------------------------------------------------------
+// vote assembly + order-preserving compaction.  grid: (n_inst, n_kps+1), block 1024.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void vote_compact_kernel(
+    int n_pts, int n_kps, int v_first, const float* __restrict__ pcld,
+    const int* __restrict__ mask, const float* __restrict__ ctr_of,
+    const float* __restrict__ pred_kp_of, const int* __restrict__ inst_frame,
+    const int* __restrict__ inst_cls, const uint8_t* __restrict__ sel, long long sel_inst_stride,
+    float4* __restrict__ votes, int* __restrict__ seg_off, int* __restrict__ seg_cnt) {
+  __shared__ int s_w1[16], s_w2[16];
+  __shared__ int s_run1, s_run2, s_nsel;
+  const int inst = blockIdx.x, v = v_first + blockIdx.y;
+  const int f = inst_frame[inst], cls = inst_cls[inst];
+  const int seg = inst * (n_kps + 1) + v;
+  const float* P = pcld + (size_t)f * n_pts * 3;
+  const int* M = mask + (size_t)f * n_pts;
+  const float* O = (v < n_kps) ? pred_kp_of + ((size_t)f * n_kps + v) * n_pts * 3
+                               : ctr_of + (size_t)f * n_pts * 3;
+  const uint8_t* S = sel ? sel + (size_t)inst * sel_inst_stride : nullptr;
+  float4* out = votes + (size_t)seg * n_pts;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) { s_run1 = 0; s_run2 = 0; s_nsel = 0; }
+  __syncthreads();
+  // row filter: S[r] refers to the r-th row of the mask-compacted sequence (the labels of an
+  // earlier fit on the same instance).  "if ctr_labels.sum() < 1: ctr_labels[0] = 1"
+  // (pvn3d_eval_utils.py:86-87,178-179): with no selected row, row 0 is kept.
+  bool force_row0 = false;
+  if (S) {
+    int mine = 0;
+    int total_rows = 0;
+    for (int p = tid; p < n_pts; p += 1024) total_rows += (M[p] == cls) ? 1 : 0;
+    // rows are [0, total); count selected among them
+    // (a block-wide sum of total_rows first, then of the selected flags)
+    for (int o = 32; o >= 1; o >>= 1) total_rows += __shfl_xor(total_rows, o, 64);
+    if (lane == 0) s_w1[w] = total_rows;
+    __syncthreads();
+    int total = 0;
+    for (int i = 0; i < 16; ++i) total += s_w1[i];
+    for (int r = tid; r < total; r += 1024) mine += S[r] ? 1 : 0;
+    if (mine) atomicAdd(&s_nsel, mine);
+    __syncthreads();
+    force_row0 = (s_nsel == 0);
+    __syncthreads();
+  }
+  for (int p0 = 0; p0 < n_pts; p0 += 1024) {
+    const int p = p0 + tid;
+    const bool m1 = (p < n_pts) && (M[p] == cls);
+    const unsigned long long bal1 = __ballot(m1);
+    if (lane == 0) s_w1[w] = __builtin_popcountll(bal1);
+    __syncthreads();
+    int row = s_run1 + pvn3d_mbcnt(bal1);
+    for (int i = 0; i < w; ++i) row += s_w1[i];
+    bool keep = m1;
+    if (S && m1) keep = S[row] != 0 || (force_row0 && row == 0);
+    const unsigned long long bal2 = __ballot(keep);
+    if (lane == 0) s_w2[w] = __builtin_popcountll(bal2);
+    __syncthreads();
+    if (keep) {
+      int pos = s_run2 + pvn3d_mbcnt(bal2);
+      for (int i = 0; i < w; ++i) pos += s_w2[i];
+      out[pos] = make_float4(P[p * 3 + 0] - O[p * 3 + 0], P[p * 3 + 1] - O[p * 3 + 1],
+                             P[p * 3 + 2] - O[p * 3 + 2], 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t1 = 0, t2 = 0;
+      for (int i = 0; i < 16; ++i) { t1 += s_w1[i]; t2 += s_w2[i]; }
+      s_run1 += t1;
+      s_run2 += t2;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    seg_off[seg] = seg * n_pts;
+    seg_cnt[seg] = s_run2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// one mean-shift iteration for every still-running fit.  grid: (tiles, n_seg), block 256.
+// S seeds per thread (tile = 256*S seeds).
+// ---------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off,
+    const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
+    unsigned* __restrict__ maxshift, int* __restrict__ iters, int t, int max_iter,
+    float thresh, float kappa, float inv_kappa) {
+  __shared__ float4 s_pts[MS_CHUNK];
+  __shared__ float s_red[MS_THREADS / 64];
+  const int seg = blockIdx.y;
+  const int n = seg_cnt[seg];
+  const int tile0 = blockIdx.x * (MS_THREADS * S);
+  if (tile0 >= n) return;
+  unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
+  if (t > 1) {
+    const float prev = __uint_as_float(ms[t - 1]);
+    if (!(prev >= thresh) || (t - 1) > max_iter) return;  // converged / capped (:42)
+  }
+  const int base = seg_off[seg];
+  const float4 org = pts[base];  // frame origin: the fit's first point
+  const int tid = threadIdx.x;
+
+  float cx[S], cy[S], cz[S], sw[S], sx[S], sy[S], sz[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int i = tile0 + s * MS_THREADS + tid;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+      if (t == 1) {
+        const float4 a = pts[base + i];
+        c = make_float4((a.x - org.x) * kappa, (a.y - org.y) * kappa, (a.z - org.z) * kappa, 0.f);
+      } else {
+        c = cin[base + i];
+      }
+    }
+    cx[s] = c.x; cy[s] = c.y; cz[s] = c.z;
+    sw[s] = sx[s] = sy[s] = sz[s] = 0.f;
+  }
+
+  for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
+    const int cnt = min(MS_CHUNK, n - j0);
+    __syncthreads();
+    for (int q = tid; q < MS_CHUNK; q += MS_THREADS) {
+      float4 a;
+      if (q < cnt) {
+        const float4 r = pts[base + j0 + q];
+        a = make_float4((r.x - org.x) * kappa, (r.y - org.y) * kappa, (r.z - org.z) * kappa, 0.f);
+      } else {
+        a = make_float4(1e18f, 1e18f, 1e18f, 0.f);  // exp2(-huge) == 0: padded rows weigh 0
+      }
+      s_pts[q] = a;
+    }
+    __syncthreads();
+    const int cnt4 = (cnt + 3) & ~3;
+#pragma unroll 4
+    for (int q = 0; q < cnt4; ++q) {
+      const float4 a = s_pts[q];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float dx = cx[s] - a.x, dy = cy[s] - a.y, dz = cz[s] - a.z;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float w = __builtin_amdgcn_exp2f(-d2);
+        sw[s] += w;
+        sx[s] = fmaf(w, a.x, sx[s]);
+        sy[s] = fmaf(w, a.y, sy[s]);
+        sz[s] = fmaf(w, a.z, sz[s]);
+      }
+    }
+  }
+
+  float mshift = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int i = tile0 + s * MS_THREADS + tid;
+    if (i < n) {
+      const float inv = 1.0f / sw[s];
+      const float nx = sx[s] * inv, ny = sy[s] * inv, nz = sz[s] * inv;
+      const float ex = nx - cx[s], ey = ny - cy[s], ez = nz - cz[s];
+      const float sh = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_kappa;
+      mshift = fmaxf(mshift, sh);
+      cout[base + i] = make_float4(nx, ny, nz, 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
+  if ((tid & 63) == 0) s_red[tid >> 6] = mshift;
+  __syncthreads();
+  if (tid == 0) {
+    float m = s_red[0];
+    for (int i = 1; i < MS_THREADS / 64; ++i) m = fmaxf(m, s_red[i]);
+    atomicMax(ms + t, __float_as_uint(m));
+    atomicMax(iters + seg, t);
+  }
+}
+
+// number of fits that would still run iteration t+1.  grid 1, block 256.
+__global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
+                               const int* __restrict__ seg_cnt, int n_seg, int t, int max_iter,
+                               float thresh, int* __restrict__ active_slot) {
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int s = threadIdx.x; s < n_seg; s += blockDim.x) {
+    if (seg_cnt[s] <= 0) continue;
+    const float prev = __uint_as_float(maxshift[(size_t)s * (max_iter + 2) + t]);
+    if (prev >= thresh && t <= max_iter) mine++;
+  }
+  if (mine) atomicAdd(&s_any, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) *active_slot = s_any;
+}
+
+// neighbour count of every ORIGINAL point (meanshift_pytorch.py:46-49) + first-max argmax.
+// `dis < bw` is evaluated as d2 <= d2_max where d2_max is the largest fp32 whose correctly
+// rounded sqrt is < bw (host-computed) -- identical to the oracle's sqrtf(d2) < bw.
+// grid: (tiles, n_seg), block 256, one seed per thread.
+__global__ __launch_bounds__(MS_THREADS) void ms_count_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off,
+    const int* __restrict__ seg_cnt, float d2_max, unsigned long long* __restrict__ best) {
+  __shared__ float4 s_pts[MS_CHUNK];
+  __shared__ unsigned long long s_red[MS_THREADS / 64];
+  const int seg = blockIdx.y;
+  const int n = seg_cnt[seg];
+  const int tile0 = blockIdx.x * MS_THREADS;
+  if (tile0 >= n) return;
+  const int base = seg_off[seg];
+  const int tid = threadIdx.x;
+  const int i = tile0 + tid;
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) c = pts[base + i];
+  int count = 0;
+  for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
+    const int cnt = min(MS_CHUNK, n - j0);
+    __syncthreads();
+    for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + j0 + q];
+    __syncthreads();
+    for (int q = 0; q < cnt; ++q) {
+      const float4 a = s_pts[q];
+      const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      count += (d2 <= d2_max) ? 1 : 0;
+    }
+  }
+  unsigned long long key = 0ULL;
+  if (i < n) key = ((unsigned long long)(unsigned)count << 32) | (unsigned long long)(~(unsigned)i);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)key, o, 64);
+    const unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    key = other > key ? other : key;
+  }
+  if ((tid & 63) == 0) s_red[tid >> 6] = key;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long m = s_red[0];
+    for (int w = 1; w < MS_THREADS / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
+    atomicMax(best + seg, m);
+  }
+}
+
+// labels = |A_j - A_maxidx| < bw ; ctr = C[maxidx] back in the camera frame.
+// grid: (tiles, n_seg), block 256.  Tile 0 also writes ctr / iters.
+__global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off,
+    const int* __restrict__ seg_cnt, const float4* __restrict__ c0,
+    const float4* __restrict__ c1, const unsigned long long* __restrict__ best,
+    const int* __restrict__ iters_ws, float d2_max, float inv_kappa, float* __restrict__ ctr,
+    uint8_t* __restrict__ labels, int* __restrict__ iters) {
+  const int seg = blockIdx.y;
+  const int n = seg_cnt[seg];
+  const int tid = threadIdx.x;
+  if (n <= 0) {
+    if (blockIdx.x == 0 && tid == 0) {
+      ctr[seg * 3 + 0] = ctr[seg * 3 + 1] = ctr[seg * 3 + 2] = 0.f;
+      if (iters) iters[seg] = 0;
+    }
+    return;
+  }
+  const int j = blockIdx.x * MS_THREADS + tid;
+  if (blockIdx.x * MS_THREADS >= n) return;
+  const int base = seg_off[seg];
+  const int max_idx = (int)(~(unsigned)(best[seg] & 0xffffffffULL));
+  const float4 c = pts[base + max_idx];
+  if (j < n && labels) {
+    const float4 a = pts[base + j];
+    const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    labels[base + j] = (d2 <= d2_max) ? 1 : 0;
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const int it = iters_ws[seg];
+    const float4 org = pts[base];
+    const float4 m = (it & 1) ? c1[base + max_idx] : c0[base + max_idx];
+    ctr[seg * 3 + 0] = m.x * inv_kappa + org.x;
+    ctr[seg * 3 + 1] = m.y * inv_kappa + org.y;
+    ctr[seg * 3 + 2] = m.z * inv_kappa + org.z;
+    if (iters) iters[seg] = it;
+  }
+}
+
+// largest fp32 t with sqrtf(t) < bw (sqrtf correctly rounded on the host)
+float d2_threshold(float bw) {
+  float t = bw * bw;
+  while (sqrtf(t) < bw) t = nextafterf(t, INFINITY);
+  while (!(sqrtf(t) < bw)) t = nextafterf(t, -INFINITY);
+  return t;
+}
+
+}  // namespace
+
+extern "C" size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter) {
+  if (n_seg < 0 || total < 0 || max_iter < 0) return 0;
+  return ms_layout(n_seg, total, max_iter, nullptr, nullptr);
+}
+
+extern "C" int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst, int v_first,
+                                  int v_count, const float* pcld, const int* mask,
+                                  const float* ctr_of, const float* pred_kp_of,
+                                  const int* inst_frame, const int* inst_cls,
+                                  const uint8_t* sel, long long sel_inst_stride, float* votes,
+                                  int* seg_off, int* seg_cnt, void* stream) {
+  (void)n_frames;
+  if (n_inst <= 0 || v_count <= 0) return 0;
+  if (n_pts <= 0 || n_kps < 0 || v_first < 0 || v_first + v_count > n_kps + 1 || !pcld ||
+      !mask || !ctr_of || !votes || !seg_off || !seg_cnt || (v_first < n_kps && !pred_kp_of))
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(vote_compact_kernel, dim3(n_inst, v_count), dim3(1024), 0,
+                     (hipStream_t)stream, n_pts, n_kps, v_first, pcld, mask, ctr_of, pred_kp_of,
+                     inst_frame, inst_cls, sel, sel_inst_stride, (float4*)votes, seg_off,
+                     seg_cnt);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
+                                         const int* seg_cnt, int n_seg, int total,
+                                         int max_cnt_host, float bandwidth, int max_iter,
+                                         float* ctr, uint8_t* labels, int* iters,
+                                         void* workspace, size_t workspace_bytes,
+                                         int* poll_host, int poll_every, void* stream) {
+  if (n_seg <= 0) return 0;
+  if (!pts || !seg_off || !seg_cnt || !ctr || !workspace || total <= 0 || max_cnt_host <= 0 ||
+      max_iter < 0 || !(bandwidth > 0.f))
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  MsState S;
+  ms_layout(n_seg, total, max_iter, (char*)workspace, &S);
+  const size_t small_bytes =
+      ((char*)workspace + pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter)) -
+      (char*)S.maxshift;
+  PVN3D_RETURN_IF_ERR(hipMemsetAsync(S.maxshift, 0, small_bytes, st));
+
+  const float thresh = (float)((double)bandwidth * 1e-3);  // meanshift_pytorch.py:21
+  const float kappa = sqrtf(0.5f * 1.44269504088896341f) / bandwidth;
+  const float inv_kappa = 1.0f / kappa;
+  const float d2_max = d2_threshold(bandwidth);
+  const float4* P = (const float4*)pts;
+
+  // seeds per thread: 2 once a fit has enough seeds to keep the chip busy anyway
+  const long long seeds = (long long)n_seg * max_cnt_host;
+  const int S2 = seeds >= 256LL * 256 * 2 * 4;
+  const int tile = MS_THREADS * (S2 ? 2 : 1);
+  const dim3 grid_it(pvn3d_ceil_div(max_cnt_host, tile), n_seg);
+  const dim3 grid_1(pvn3d_ceil_div(max_cnt_host, MS_THREADS), n_seg);
+
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int pending[2] = {0, 0};
+  int slot = 0;
+  const bool poll = poll_host != nullptr && poll_every > 0;
+  if (poll) {
+    PVN3D_RETURN_IF_ERR(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    PVN3D_RETURN_IF_ERR(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  }
+  int rc = 0;
+  for (int t = 1; t <= max_iter + 1; ++t) {
+    const float4* cin = S.cbuf[(t - 1) & 1];
+    float4* cout = S.cbuf[t & 1];
+    if (S2)
+      hipLaunchKernelGGL(ms_iter_kernel<2>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
+                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, kappa,
+                         inv_kappa);
+    else
+      hipLaunchKernelGGL(ms_iter_kernel<1>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
+                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, kappa,
+                         inv_kappa);
+    if ((rc = (int)hipGetLastError()) != 0) break;
+    if (poll && (t % poll_every) == 0 && t <= max_iter) {
+      hipLaunchKernelGGL(ms_poll_kernel, dim3(1), dim3(256), 0, st, S.maxshift, seg_cnt, n_seg,
+                         t, max_iter, thresh, S.active + slot);
+      if ((rc = (int)hipMemcpyAsync(poll_host + slot, S.active + slot, sizeof(int),
+                                    hipMemcpyDeviceToHost, st)) != 0) break;
+      if ((rc = (int)hipEventRecord(ev[slot], st)) != 0) break;
+      pending[slot] = 1;
+      const int other = slot ^ 1;  // the GPU stays one chunk ahead of the host test
+      if (pending[other]) {
+        if ((rc = (int)hipEventSynchronize(ev[other])) != 0) break;
+        pending[other] = 0;
+        if (poll_host[other] == 0) break;
+      }
+      slot = other;
+    }
+  }
+  if (poll) {
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(ms_count_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                     d2_max, S.best);
+  PVN3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ms_final_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                     S.cbuf[0], S.cbuf[1], S.best, S.iters, d2_max, inv_kappa, ctr, labels, iters);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,221 @@
+"""Drop-in for the reference's compiled module ``pointnet2_utils._ext``.
+
+Exports exactly the nine functions of pvn3d/_ext-src/src/bindings.cpp:6-19 with the same
+argument order, tensor contract and error behaviour as the reference's ATen glue
+(pvn3d/_ext-src/src/{sampling,ball_query,group_points,interpolate}.cpp):
+  * inputs must be contiguous, fp32 / int32 (CHECK_CONTIGUOUS / CHECK_IS_FLOAT / CHECK_IS_INT,
+    pvn3d/_ext-src/include/utils.h:10-25) and live on the GPU ("CPU not supported");
+  * outputs are freshly allocated on the inputs' device by torch (caching allocator owns them);
+  * kernels are enqueued on torch's current stream, no synchronisation.
+All compute is in libpvn3d_hip.so (include/pvn3d_hip.h); this file only validates, allocates
+and passes raw pointers.  Extra (non-reference) entry points used by the fused callers are
+grouped at the bottom.
+"""
+import torch
+
+from ..._lib import lib, check
+
+# Reproduce what the reference BINARY returns from three_interpolate_grad (it calls the forward
+# kernel with swapped sizes, pvn3d/_ext-src/src/interpolate.cpp:89-93).  Default: the
+# mathematically correct gradient.  See DESIGN.md "Reference bug: three_interpolate_grad".
+REFERENCE_BUG_COMPAT = False
+
+
+def _chk(t, name, dtype):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be a%s tensor" % (name, " float" if dtype == torch.float32 else "n int"))
+
+
+def _same_dev(a, b, name):
+    """After the dtype/contiguity checks of every argument, as in the reference glue: the first
+    tensor decides CPU ("CPU not supported") vs GPU, the others must live on the same device."""
+    if not a.is_cuda:
+        raise RuntimeError("CPU not supported")
+    if b.device != a.device:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def furthest_point_sampling(points, nsamples):
+    """points (B,N,3) -> (B,nsamples) int32.  sampling.cpp:65-86"""
+    _chk(points, "points", torch.float32)
+    _same_dev(points, points, "points")
+    B, N = points.size(0), points.size(1)
+    out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
+    # the reference's (B,N) 1e10 scratch is only needed beyond the register-resident sizes
+    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device) if N > 16384 else None
+    with torch.cuda.device(points.device):
+        check(lib.pvn3d_furthest_point_sampling(B, N, int(nsamples), points.data_ptr(),
+                                                tmp.data_ptr() if tmp is not None else None,
+                                                out.data_ptr(), _stream(points)),
+              "furthest_point_sampling")
+    return out
+
+
+def gather_points(points, idx):
+    """points (B,C,N), idx (B,npoint) -> (B,C,npoint).  sampling.cpp:15-39"""
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(points, idx, "idx")
+    B, C, N = points.shape
+    m = idx.size(1)
+    out = torch.empty((B, C, m), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        check(lib.pvn3d_gather_points(B, C, N, m, points.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                      _stream(points)), "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """grad_out (B,C,npoint), idx (B,npoint) -> (B,C,n).  sampling.cpp:40-64"""
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(grad_out, idx, "idx")
+    B, C, m = grad_out.shape
+    out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        check(lib.pvn3d_gather_points_grad(B, C, int(n), m, grad_out.data_ptr(), idx.data_ptr(),
+                                           out.data_ptr(), _stream(grad_out)), "gather_points_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """new_xyz (B,npoint,3), xyz (B,N,3) -> (B,npoint,nsample) int32.  ball_query.cpp:8-32"""
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(xyz, "xyz", torch.float32)
+    _same_dev(new_xyz, xyz, "xyz")
+    B, m = new_xyz.size(0), new_xyz.size(1)
+    N = xyz.size(1)
+    idx = torch.empty((B, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        check(lib.pvn3d_ball_query(B, N, m, float(radius), int(nsample), new_xyz.data_ptr(),
+                                   xyz.data_ptr(), idx.data_ptr(), _stream(new_xyz)), "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample).  group_points.cpp:12-35"""
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(points, idx, "idx")
+    B, C, N = points.shape
+    npoint, nsample = idx.size(1), idx.size(2)
+    out = torch.empty((B, C, npoint, nsample), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        check(lib.pvn3d_group_points(B, C, N, npoint, nsample, points.data_ptr(), idx.data_ptr(),
+                                     out.data_ptr(), _stream(points)), "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """grad_out (B,C,npoint,nsample) -> (B,C,n).  group_points.cpp:37-60"""
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(grad_out, idx, "idx")
+    B, C, npoint, nsample = grad_out.shape
+    out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        check(lib.pvn3d_group_points_grad(B, C, int(n), npoint, nsample, grad_out.data_ptr(),
+                                          idx.data_ptr(), out.data_ptr(), _stream(grad_out)),
+              "group_points_grad")
+    return out
+
+
+def three_nn(unknowns, knows):
+    """unknowns (B,n,3), knows (B,m,3) -> [dist2 (B,n,3), idx (B,n,3)].  interpolate.cpp:14-40"""
+    _chk(unknowns, "unknowns", torch.float32)
+    _chk(knows, "knows", torch.float32)
+    _same_dev(unknowns, knows, "knows")
+    B, n = unknowns.size(0), unknowns.size(1)
+    m = knows.size(1)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    with torch.cuda.device(unknowns.device):
+        check(lib.pvn3d_three_nn(B, n, m, unknowns.data_ptr(), knows.data_ptr(), dist2.data_ptr(),
+                                 idx.data_ptr(), _stream(unknowns)), "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,C,m), idx/weight (B,n,3) -> (B,C,n).  interpolate.cpp:42-68"""
+    _chk(points, "points", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(weight, "weight", torch.float32)
+    _same_dev(points, idx, "idx")
+    _same_dev(points, weight, "weight")
+    B, C, m = points.shape
+    n = idx.size(1)
+    out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        check(lib.pvn3d_three_interpolate(B, C, m, n, points.data_ptr(), idx.data_ptr(),
+                                          weight.data_ptr(), out.data_ptr(), _stream(points)),
+              "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """grad_out (B,C,n), idx/weight (B,n,3) -> (B,C,m).  interpolate.cpp:70-99"""
+    _chk(grad_out, "grad_out", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(weight, "weight", torch.float32)
+    _same_dev(grad_out, idx, "idx")
+    _same_dev(grad_out, weight, "weight")
+    B, C, n = grad_out.shape
+    out = torch.empty((B, C, int(m)), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        check(lib.pvn3d_three_interpolate_grad(B, C, n, int(m), grad_out.data_ptr(), idx.data_ptr(),
+                                               weight.data_ptr(), out.data_ptr(),
+                                               1 if REFERENCE_BUG_COMPAT else 0, _stream(grad_out)),
+              "three_interpolate_grad")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# fused entry points (not in the reference's _ext; used by QueryAndGroup / SA-MSG modules)
+# ------------------------------------------------------------------------------------------
+
+def ball_query_pair(new_xyz, xyz, radius0, nsample0, radius1, nsample1):
+    """Two ball queries over the same (new_xyz, xyz) in one scan -> (idx0, idx1)."""
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(xyz, "xyz", torch.float32)
+    _same_dev(new_xyz, xyz, "xyz")
+    B, m = new_xyz.size(0), new_xyz.size(1)
+    N = xyz.size(1)
+    idx0 = torch.empty((B, m, int(nsample0)), dtype=torch.int32, device=new_xyz.device)
+    idx1 = torch.empty((B, m, int(nsample1)), dtype=torch.int32, device=new_xyz.device)
+    with torch.cuda.device(new_xyz.device):
+        check(lib.pvn3d_ball_query_pair(B, N, m, float(radius0), int(nsample0), float(radius1),
+                                        int(nsample1), new_xyz.data_ptr(), xyz.data_ptr(),
+                                        idx0.data_ptr(), idx1.data_ptr(), _stream(new_xyz)),
+              "ball_query_pair")
+    return idx0, idx1
+
+
+def group_xyz_features(xyz, new_xyz, features, idx, use_xyz=True):
+    """QueryAndGroup's gather + subtract + cat in one pass -> (B, 3*use_xyz + C, npoint, nsample)."""
+    _chk(xyz, "xyz", torch.float32)
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(xyz, new_xyz, "new_xyz")
+    _same_dev(xyz, idx, "idx")
+    C = 0
+    if features is not None:
+        _chk(features, "features", torch.float32)
+        _same_dev(xyz, features, "features")
+        C = features.size(1)
+    B, N = xyz.size(0), xyz.size(1)
+    m, nsample = idx.size(1), idx.size(2)
+    c_out = (3 if use_xyz else 0) + C
+    out = torch.empty((B, c_out, m, nsample), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        check(lib.pvn3d_group_xyz_features(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
+                                           new_xyz.data_ptr(),
+                                           features.data_ptr() if features is not None else None,
+                                           idx.data_ptr(), out.data_ptr(), _stream(xyz)),
+              "group_xyz_features")
+    return out

@@ -1,0 +1,110 @@
+"""Set-abstraction / feature-propagation modules with the reference's constructor signatures,
+attribute names (``npoint``, ``groupers``, ``mlps``, ``mlp``) and ``state_dict`` layout
+(pvn3d/lib/pointnet2_utils/pointnet2_modules.py: _PointnetSAModuleBase :20-71,
+PointnetSAModuleMSG :74-112, PointnetSAModule :115-143, PointnetFPModule :146-206).
+
+Data flow per SA level (reference :47-71):
+    FPS -> gather centres -> per scale: ball_query -> group(xyz-rel ++ features) -> SharedMLP
+    -> max over nsample -> concat scales.
+Here the two ball queries of a multi-scale level share one scan of the cloud
+(_ext.ball_query_pair) and grouping writes the concatenated tensor in one pass.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _ext
+from . import pointnet2_utils
+from ..utils import pytorch_utils as pt_utils
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super(_PointnetSAModuleBase, self).__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+
+    def _shared_idx(self, xyz, new_xyz):
+        """Precompute neighbour indices when two ball-query scales can share one scan."""
+        g = self.groupers
+        if (len(g) == 2 and all(isinstance(m, pointnet2_utils.QueryAndGroup) for m in g)
+                and xyz.is_cuda):
+            return _ext.ball_query_pair(new_xyz, xyz, g[0].radius, g[0].nsample,
+                                        g[1].radius, g[1].nsample)
+        return [None] * len(g)
+
+    def forward(self, xyz, features=None):
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum(mlp[-1]),npoint)"""
+        new_xyz = None
+        if self.npoint is not None:
+            sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            xyz_t = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
+            idxs = self._shared_idx(xyz, new_xyz)
+        else:
+            idxs = [None] * len(self.groupers)
+
+        pooled = []
+        for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
+            if idx is not None:
+                grouped = grouper(xyz, new_xyz, features, idx=idx)
+            else:
+                grouped = grouper(xyz, new_xyz, features)      # (B, C, npoint, nsample)
+            feats = mlp(grouped)                               # (B, mlp[-1], npoint, nsample)
+            feats = F.max_pool2d(feats, kernel_size=[1, feats.size(3)]).squeeze(-1)
+            pooled.append(feats)
+        return new_xyz, torch.cat(pooled, dim=1)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Set abstraction with multi-scale grouping.
+
+    npoint: number of sampled centres; radii / nsamples / mlps: one entry per scale;
+    ``mlps[i][0]`` is increased by 3 in place when use_xyz (reference :108-109).
+    """
+
+    def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
+        super(PointnetSAModuleMSG, self).__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(
+                pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction (one radius / nsample / mlp)."""
+
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True):
+        super(PointnetSAModule, self).__init__(
+            mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: inverse-distance interpolation from `known` to `unknown`, then MLP."""
+
+    def __init__(self, mlp, bn=True):
+        super(PointnetFPModule, self).__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
+        if unknow_feats is not None:
+            new_features = torch.cat([interpolated, unknow_feats], dim=1)
+        else:
+            new_features = interpolated
+        return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,224 @@
+"""Device-side vote -> cluster -> pose engine: thin host glue over section 3 of the C ABI
+(include/pvn3d_hip.h).  The reference-API mirrors (meanshift_pytorch.MeanShiftTorch,
+pvn3d_eval_utils.cal_frame_poses / cal_frame_poses_lm) call into this module.
+
+Everything stays on the GPU: vote assembly and mask compaction (pvn3d_vote_compact), all
+(K+1) mean-shift fits of every object of every frame in ONE batched call
+(pvn3d_meanshift_fit_batch), and the Kabsch fit (pvn3d_best_fit_transform).  The only host
+synchronisation is the optional convergence poll and the final read-back of the poses.
+"""
+import threading
+
+import numpy as np
+import torch
+
+from ..._lib import lib, check
+
+_tls = threading.local()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _poll_buf():
+    """Per-thread pinned int[2] for the convergence poll (the reference's post-processing is
+    called from a thread pool, pvn3d_eval_utils.py:373-380, so nothing here is shared)."""
+    b = getattr(_tls, "poll", None)
+    if b is None:
+        b = torch.zeros(2, dtype=torch.int32).pin_memory()
+        _tls.poll = b
+    return b
+
+
+def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300, labels=None,
+                        poll_every=8):
+    """Batched MeanShiftTorch.fit.
+
+    pts4 (total,4) float32 cuda; seg_off/seg_cnt (n_seg) int32 cuda; max_cnt: host bound on
+    seg_cnt.  Returns ctr (n_seg,3) float32, labels (total) uint8, iters (n_seg) int32.
+    poll_every = 0 -> fully asynchronous (enqueues max_iter+1 iterations).
+    """
+    dev = pts4.device
+    assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
+    n_seg = int(seg_off.numel())
+    total = int(pts4.size(0))
+    ctr = torch.empty((n_seg, 3), dtype=torch.float32, device=dev)
+    iters = torch.empty((n_seg,), dtype=torch.int32, device=dev)
+    if labels is None:
+        labels = torch.empty((total,), dtype=torch.uint8, device=dev)
+    if n_seg == 0:
+        return ctr, labels, iters
+    ws_bytes = int(lib.pvn3d_meanshift_workspace_bytes(n_seg, total, int(max_iter)))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    poll = _poll_buf() if poll_every > 0 else None
+    with torch.cuda.device(dev):
+        check(lib.pvn3d_meanshift_fit_batch(
+            pts4.data_ptr(), seg_off.data_ptr(), seg_cnt.data_ptr(), n_seg, total, int(max_cnt),
+            float(bandwidth), int(max_iter), ctr.data_ptr(), labels.data_ptr(), iters.data_ptr(),
+            ws.data_ptr(), ws_bytes, poll.data_ptr() if poll is not None else None,
+            int(poll_every), _stream(dev)), "meanshift_fit_batch")
+    return ctr, labels, iters
+
+
+def vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, v_first, v_count,
+                 sel=None, sel_inst_stride=0, out=None):
+    """pvn3d_vote_compact wrapper.  Returns (votes (n_seg*n_pts,4), seg_off, seg_cnt) where
+    n_seg = n_inst*(n_kps+1); only segments v_first..v_first+v_count-1 of each instance are
+    (re)written."""
+    dev = pcld.device
+    F, n_pts = pcld.size(0), pcld.size(1)
+    n_kps = pred_kp_of.size(1)
+    n_inst = int(inst_frame.numel())
+    n_seg = n_inst * (n_kps + 1)
+    if out is None:
+        votes = torch.empty((n_seg * n_pts, 4), dtype=torch.float32, device=dev)
+        seg_off = torch.zeros((n_seg,), dtype=torch.int32, device=dev)
+        seg_cnt = torch.zeros((n_seg,), dtype=torch.int32, device=dev)
+    else:
+        votes, seg_off, seg_cnt = out
+    with torch.cuda.device(dev):
+        check(lib.pvn3d_vote_compact(
+            F, n_pts, n_kps, n_inst, int(v_first), int(v_count), pcld.data_ptr(), mask.data_ptr(),
+            ctr_of.data_ptr(), pred_kp_of.data_ptr(), inst_frame.data_ptr(), inst_cls.data_ptr(),
+            sel.data_ptr() if sel is not None else None, int(sel_inst_stride), votes.data_ptr(),
+            seg_off.data_ptr(), seg_cnt.data_ptr(), _stream(dev)), "vote_compact")
+    return votes, seg_off, seg_cnt
+
+
+def best_fit_transform_batch(A, B, valid=None):
+    """A, B (S,npts,3) float32 cuda -> T (S,3,4) float64 cuda; valid (S) int32 or None."""
+    dev = A.device
+    S, npts = A.size(0), A.size(1)
+    T = torch.empty((S, 3, 4), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.pvn3d_best_fit_transform(S, npts, A.data_ptr(), B.data_ptr(),
+                                           valid.data_ptr() if valid is not None else None,
+                                           T.data_ptr(), _stream(dev)), "best_fit_transform")
+    return T
+
+
+def _prep(pcld, mask, ctr_of, pred_kp_of):
+    pcld = pcld.contiguous().float()
+    mask = mask.contiguous().to(torch.int32)
+    ctr_of = ctr_of.contiguous().float()
+    pred_kp_of = pred_kp_of.contiguous().float()
+    return pcld, mask, ctr_of, pred_kp_of
+
+
+def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1, use_ctr=True,
+                             use_ctr_clus_flter=False, radius=0.08, max_iter=300, poll_every=8):
+    """Batched cal_frame_poses_lm (pvn3d/lib/utils/pvn3d_eval_utils.py:156-201).
+
+    pcld (F,N,3); mask (F,N) integer; ctr_of (F,1,N,3); pred_kp_of (F,K,N,3);
+    mesh_kps (K+use_ctr,3) object-frame keypoints (+centre last).
+    Returns dict(poses (F,3,4) f64 cuda, cls_kps (F,K+1,3), iters (F,K+1), counts (F,K+1)).
+    """
+    pcld, mask, ctr_of, pred_kp_of = _prep(pcld, mask, ctr_of, pred_kp_of)
+    dev = pcld.device
+    F, N = pcld.size(0), pcld.size(1)
+    K = pred_kp_of.size(1)
+    inst_frame = torch.arange(F, dtype=torch.int32, device=dev)
+    inst_cls = torch.full((F,), int(cls_id), dtype=torch.int32, device=dev)
+    if not use_ctr_clus_flter:
+        votes, seg_off, seg_cnt = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame,
+                                               inst_cls, 0, K + 1)
+        ctr, _, iters = meanshift_fit_batch(votes, seg_off, seg_cnt, N, radius, max_iter,
+                                            poll_every=poll_every)
+    else:
+        out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
+        votes, seg_off, seg_cnt = out
+        so = seg_off.view(F, K + 1)
+        sc = seg_cnt.view(F, K + 1)
+        c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(),
+                                                    sc[:, K].contiguous(), N, radius, max_iter,
+                                                    poll_every=poll_every)
+        # keypoint votes filtered by the centre fit's inlier labels (rows of segment K)
+        sel = labels[K * N:]
+        vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
+                     sel_inst_stride=(K + 1) * N, out=out)
+        c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
+                                             sc[:, :K].contiguous().view(-1), N, radius, max_iter,
+                                             poll_every=poll_every)
+        ctr = torch.cat([c_kp.view(F, K, 3), c_ctr.view(F, 1, 3)], 1).view(-1, 3)
+        iters = torch.cat([it_kp.view(F, K), it_ctr.view(F, 1)], 1).view(-1)
+    cls_kps = ctr.view(F, K + 1, 3)
+    counts = seg_cnt.view(F, K + 1)
+    valid = (mask == int(cls_id)).any(dim=1).to(torch.int32)
+    npts = K + 1 if use_ctr else K
+    A = mesh_kps.to(device=dev, dtype=torch.float32)[:npts].unsqueeze(0).expand(F, npts, 3).contiguous()
+    B = cls_kps[:, :npts].contiguous()
+    poses = best_fit_transform_batch(A, B, valid)
+    return dict(poses=poses, cls_kps=cls_kps, iters=iters.view(F, K + 1), counts=counts)
+
+
+def relabel_by_centre(mask, pred_ctr, ctrs, present, thr_lst):
+    """Centre-cluster re-labelling of cal_frame_poses (pvn3d_eval_utils.py:58-72), batched over
+    frames with every class slot kept on the device (absent classes masked by `present`).
+    mask (F,N) int32; pred_ctr (F,N,3); ctrs (F,C,3) cluster centre per class id 1..C;
+    present (F,C) bool; thr_lst (C) float32 = fp32(0.8 * ycb_r_lst).  Returns the new mask."""
+    d = torch.norm(pred_ctr.unsqueeze(2) - ctrs.unsqueeze(1), dim=3)          # (F,N,C)
+    d = torch.where(present.unsqueeze(1), d, torch.full_like(d, float("inf")))
+    min_dis, min_idx = torch.min(d, dim=2)                                     # first min
+    closest = (min_idx + 1).to(mask.dtype)
+    thr = thr_lst.to(d.dtype)[min_idx]
+    upd = (mask > 0) & (min_dis < thr) & present.any(dim=1, keepdim=True)
+    return torch.where(upd, closest, mask)
+
+
+def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls, radius_lst,
+                            use_ctr=True, use_ctr_clus_flter=True, radius=0.08, max_iter=300,
+                            poll_every=8):
+    """Batched cal_frame_poses (pvn3d/lib/utils/pvn3d_eval_utils.py:37-110) for every class id
+    1..n_cls-1 of every frame; absent classes are empty segments.
+
+    mesh_kps_all (n_cls-1, K+1, 3): object-frame keypoints (+centre) per class id.
+    Returns dict(poses (F,n_cls-1,3,4), present (F,n_cls-1) bool [original mask], cls_kps (F,n_cls-1,K+1,3),
+                 iters, new_mask).
+    """
+    pcld, mask, ctr_of, pred_kp_of = _prep(pcld, mask, ctr_of, pred_kp_of)
+    dev = pcld.device
+    F, N = pcld.size(0), pcld.size(1)
+    K = pred_kp_of.size(1)
+    C = n_cls - 1
+    inst_frame = torch.arange(F, dtype=torch.int32, device=dev).repeat_interleave(C)
+    inst_cls = torch.arange(1, n_cls, dtype=torch.int32, device=dev).repeat(F)
+    n_inst = F * C
+    cls_ids = torch.arange(1, n_cls, device=dev, dtype=mask.dtype).view(1, C, 1)
+    present = (mask.unsqueeze(1) == cls_ids).any(dim=2)                        # (F,C)
+    present0 = present          # pred_cls_ids of the reference come from the ORIGINAL mask (:49)
+    out = None
+    if use_ctr_clus_flter:
+        out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
+        votes, seg_off, seg_cnt = out
+        so = seg_off.view(n_inst, K + 1)
+        sc = seg_cnt.view(n_inst, K + 1)
+        c0, _, _ = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
+                                       radius, max_iter, poll_every=poll_every)
+        pred_ctr = pcld - ctr_of[:, 0]
+        thr = torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)).to(dev)
+        mask = relabel_by_centre(mask, pred_ctr, c0.view(F, C, 3), present, thr).contiguous()
+        present = (mask.unsqueeze(1) == cls_ids).any(dim=2)
+    # per-class centre fit on the (re-labelled) mask
+    out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
+    votes, seg_off, seg_cnt = out
+    so = seg_off.view(n_inst, K + 1)
+    sc = seg_cnt.view(n_inst, K + 1)
+    c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(),
+                                                N, radius, max_iter, poll_every=poll_every)
+    sel = labels[K * N:] if use_ctr_clus_flter else None
+    vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
+                 sel_inst_stride=(K + 1) * N, out=out)
+    c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
+                                         sc[:, :K].contiguous().view(-1), N, radius, max_iter,
+                                         poll_every=poll_every)
+    cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
+    iters = torch.cat([it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)], 1)
+    npts = K + 1 if use_ctr else K
+    A = mesh_kps_all.to(device=dev, dtype=torch.float32)[:, :npts].unsqueeze(0) \
+        .expand(F, C, npts, 3).contiguous().view(n_inst, npts, 3)
+    B = cls_kps[:, :npts].contiguous()
+    valid = present.view(-1).to(torch.int32)
+    poses = best_fit_transform_batch(A, B, valid)
+    return dict(poses=poses.view(F, C, 3, 4), present=present0, present_new=present, cls_kps=cls_kps.view(F, C, K + 1, 3),
+                iters=iters.view(F, C, K + 1), new_mask=mask)

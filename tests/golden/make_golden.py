@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are committed
+so that tests never read /root/reference.  What is pinned by real reference outputs:
+  meanshift_ref.npz : MeanShiftTorch(bandwidth).fit(A) of pvn3d/lib/utils/meanshift_pytorch.py
+                      (module loaded file-level; cv2 / sklearn / neupeak stubbed -- they are only
+                      used by its visual test functions), incl. the iteration count `it`
+                      (read from the frame's locals with sys.settrace).
+  kabsch_ref.npz    : best_fit_transform(A,B) of pvn3d/lib/utils/basic_utils.py (file-level load,
+                      cv2 / plyfile / ip_basic stubbed).
+  frames_ref.npz    : cal_frame_poses_lm / cal_frame_poses restated (oracle/posecal.py) but
+                      DRIVEN BY the reference's MeanShiftTorch.fit and best_fit_transform.
+What cannot be pinned by the reference (CUDA-only native ops, no nvcc / NVIDIA GPU here):
+  native_oracle.npz : outputs of the C oracle for the pointnet2 ops on seeded inputs --
+                      regression vectors, labelled "oracle-generated".
+Usage: python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference/pvn3d"
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def load_reference():
+    for n in ["cv2", "plyfile", "neupeak", "neupeak.utils", "neupeak.utils.webcv2",
+              "lib", "lib.utils", "lib.utils.ip_basic", "lib.utils.ip_basic.ip_basic",
+              "lib.utils.ip_basic.ip_basic.depth_map_utils_ycb", "lib.utils.ip_basic.ip_basic.vis_utils"]:
+        if n not in sys.modules:
+            _stub(n)
+    sys.modules["neupeak.utils.webcv2"].imshow = None
+    sys.modules["neupeak.utils.webcv2"].waitKey = None
+    sys.modules["plyfile"].PlyData = None
+    sys.modules["lib.utils.ip_basic.ip_basic"].depth_map_utils_ycb = sys.modules["lib.utils.ip_basic.ip_basic.depth_map_utils_ycb"]
+    sys.modules["lib.utils.ip_basic.ip_basic"].vis_utils = sys.modules["lib.utils.ip_basic.ip_basic.vis_utils"]
+
+    def _load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ms = _load("ref_meanshift_pytorch", os.path.join(REF, "lib/utils/meanshift_pytorch.py"))
+    bu = _load("ref_basic_utils", os.path.join(REF, "lib/utils/basic_utils.py"))
+    return ms, bu
+
+
+def ref_fit_with_iters(ms_mod, A_np, bw, max_iter=300):
+    """Run the reference fit and read its local `it` when the frame returns."""
+    box = {}
+
+    def tracer(frame, event, arg):
+        if frame.f_code.co_name == "fit":
+            def local(frame, event, arg):
+                if event == "return":
+                    box["it"] = frame.f_locals.get("it")
+                return local
+            return local
+        return None
+    ms = ms_mod.MeanShiftTorch(bandwidth=bw, max_iter=max_iter)
+    sys.settrace(tracer)
+    try:
+        ctr, labels = ms.fit(torch.from_numpy(A_np))
+    finally:
+        sys.settrace(None)
+    return ctr.numpy().astype(np.float32), labels.numpy().astype(bool), int(box["it"])
+
+
+def vote_cloud(rng, n, sig_in, sig_out, out_frac, centre):
+    is_out = rng.random(n) < out_frac
+    eps = rng.normal(size=(n, 3)) * np.where(is_out, sig_out, sig_in)[:, None]
+    return (np.asarray(centre)[None] + eps).astype(np.float32)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ms_mod, bu_mod = load_reference()
+    from oracle import posecal
+    from pvn3d_amd import synth
+
+    # ------------------------------------------------------------------ mean shift
+    rng = np.random.default_rng(20260925)
+    cases = [
+        dict(n=1, sig_in=0.005, sig_out=0.05, out=0.0, bw=0.08),
+        dict(n=2, sig_in=0.005, sig_out=0.05, out=0.0, bw=0.08),
+        dict(n=64, sig_in=0.005, sig_out=0.05, out=0.1, bw=0.08),
+        dict(n=300, sig_in=0.005, sig_out=0.05, out=0.1, bw=0.08),
+        dict(n=512, sig_in=0.01, sig_out=0.3, out=0.1, bw=0.08),
+        dict(n=777, sig_in=0.005, sig_out=0.05, out=0.1, bw=0.05),
+        dict(n=1024, sig_in=0.005, sig_out=0.0, out=0.0, bw=0.08),
+        dict(n=1500, sig_in=0.02, sig_out=0.3, out=0.3, bw=0.08),
+        dict(n=2048, sig_in=0.005, sig_out=0.05, out=0.1, bw=0.08),
+    ]
+    ms_out = {}
+    for i, c in enumerate(cases):
+        A = vote_cloud(rng, c["n"], c["sig_in"], c["sig_out"], c["out"], [0.05, -0.02, 0.9])
+        ctr, labels, it = ref_fit_with_iters(ms_mod, A, c["bw"])
+        ms_out["A%d" % i] = A
+        ms_out["ctr%d" % i] = ctr
+        ms_out["labels%d" % i] = labels
+        ms_out["iters%d" % i] = np.int64(it)
+        ms_out["bw%d" % i] = np.float64(c["bw"])
+        print("meanshift case %d n=%d iters=%d" % (i, c["n"], it))
+    # two-cluster case: the pick must be the denser cluster
+    A = np.concatenate([vote_cloud(rng, 300, 0.004, 0, 0, [0.0, 0.0, 0.8]),
+                        vote_cloud(rng, 200, 0.004, 0, 0, [0.3, 0.1, 0.9])], 0)
+    A = A[rng.permutation(len(A))]
+    i = len(cases)
+    ctr, labels, it = ref_fit_with_iters(ms_mod, A, 0.08)
+    ms_out.update({"A%d" % i: A, "ctr%d" % i: ctr, "labels%d" % i: labels,
+                   "iters%d" % i: np.int64(it), "bw%d" % i: np.float64(0.08)})
+    # max_iter cap: it must stop at max_iter+1
+    i += 1
+    A = vote_cloud(rng, 400, 0.02, 0.3, 0.3, [0.05, -0.02, 0.9])
+    ctr, labels, it = ref_fit_with_iters(ms_mod, A, 0.08, max_iter=5)
+    ms_out.update({"A%d" % i: A, "ctr%d" % i: ctr, "labels%d" % i: labels,
+                   "iters%d" % i: np.int64(it), "bw%d" % i: np.float64(0.08),
+                   "max_iter%d" % i: np.int64(5)})
+    print("cap case iters", it)
+    ms_out["n_cases"] = np.int64(i + 1)
+    np.savez_compressed(os.path.join(HERE, "meanshift_ref.npz"), **ms_out)
+
+    # ------------------------------------------------------------------ kabsch
+    kb = {}
+    kps = synth.mesh_kps("ape", "lm", True)
+    nk = 0
+    for trial in range(12):
+        R = synth.random_rotation(rng)
+        t = rng.normal(size=3) * 0.3
+        if trial % 3 == 0:
+            A = kps
+        elif trial % 3 == 1:
+            A = rng.random((10, 3)).astype(np.float32)     # lib/utils/icp/test.py style
+        else:
+            A = synth.mesh_kps("cat", "lm", False)
+        noise = 0.0 if trial < 6 else 0.003
+        B = (A.astype(np.float64) @ R.T + t + rng.normal(size=A.shape) * noise).astype(np.float32)
+        if trial == 11:                                    # force the reflection branch
+            B = B * np.array([1, 1, -1], np.float32)
+        if trial == 10:                                    # planar (rank-2) point set
+            A = A.copy(); A[:, 2] = 0
+            B = (A.astype(np.float64) @ R.T + t).astype(np.float32)
+        T = bu_mod.best_fit_transform(A, B)
+        kb["A%d" % nk] = A.astype(np.float32); kb["B%d" % nk] = B; kb["T%d" % nk] = T
+        nk += 1
+    kb["n_cases"] = np.int64(nk)
+    np.savez_compressed(os.path.join(HERE, "kabsch_ref.npz"), **kb)
+    print("kabsch cases", nk)
+
+    # ------------------------------------------------------------------ whole frames
+    def ref_fit(A, bw):
+        if len(A) == 0:
+            raise RuntimeError("empty fit")
+        ctr, labels, it = ref_fit_with_iters(ms_mod, np.ascontiguousarray(A, np.float32), bw)
+        return ctr, labels, it
+    fr = {}
+    # config 1: N=2048, one object, all points on the object
+    f = synth.synth_frame(frame=0, n_pts=2048, n_obj=2048)
+    poses, cls_kps, iters = posecal.cal_frame_poses_lm(
+        f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], True, 2, False, f["mesh_kps"],
+        fit=ref_fit, bft=bu_mod.best_fit_transform, return_debug=True)
+    fr.update(lm0_pose=poses[0], lm0_cls_kps=cls_kps, lm0_iters=iters)
+    print("lm frame0 iters", iters)
+    # LineMOD-style frame with the centre-cluster filter on, n_obj=1024 of 4096
+    f = synth.synth_frame(frame=1, n_pts=4096, n_obj=1024)
+    poses, cls_kps, iters = posecal.cal_frame_poses_lm(
+        f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], True, 2, True, f["mesh_kps"],
+        fit=ref_fit, bft=bu_mod.best_fit_transform, return_debug=True)
+    fr.update(lm1_pose=poses[0], lm1_cls_kps=cls_kps, lm1_iters=iters)
+    print("lm frame1 iters", iters)
+    # YCB-style multi-instance frame
+    y = synth.synth_frame_ycb(frame=2, n_pts=4096, n_obj_total=2000, n_objs=4)
+    classes = y["classes"]
+    ids, poses, cls_kps, new_mask = posecal.cal_frame_poses(
+        y["pcld"], y["mask"], y["ctr_of"], y["pred_kp_of"], True, 22, True,
+        lambda c: synth.mesh_kps(classes[c - 1], "ycb", True), y["radius"],
+        fit=ref_fit, bft=bu_mod.best_fit_transform, return_debug=True)
+    fr.update(ycb_ids=ids, ycb_poses=np.stack(poses, 0), ycb_cls_kps=cls_kps, ycb_new_mask=new_mask)
+    np.savez_compressed(os.path.join(HERE, "frames_ref.npz"), **fr)
+    print("frames done; ycb ids", ids)
+
+    # ------------------------------------------------------------------ native ops (oracle)
+    from oracle import native as orc
+    nat = {}
+    g = np.random.default_rng(7)
+    cloud, _ = synth.synth_cloud(g, 4096, wrap_pad=0.1)
+    xyz = cloud[None]
+    nat["xyz"] = xyz
+    fps = orc.furthest_point_sampling(xyz, 512)
+    nat["fps"] = fps
+    new_xyz = np.take_along_axis(xyz, fps[..., None].astype(np.int64).repeat(3, -1), 1)
+    nat["bq_r0025_16"] = orc.ball_query(new_xyz, xyz, 0.025, 16)
+    nat["bq_r005_32"] = orc.ball_query(new_xyz, xyz, 0.05, 32)
+    d2, idx = orc.three_nn(xyz, new_xyz)
+    nat["nn_d2"] = d2; nat["nn_idx"] = idx
+    np.savez_compressed(os.path.join(HERE, "native_oracle.npz"), **nat)
+    print("native vectors done")
+
+
+if __name__ == "__main__":
+    main()

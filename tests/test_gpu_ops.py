@@ -1,0 +1,209 @@
+"""Parity of the gfx950 pointnet2 ops (through the C ABI, via the reference-API shim) against
+the CPU oracle on identical seeded inputs.  Indices bit-exact; gathers exact."""
+import numpy as np
+import pytest
+import torch
+
+from pvn3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def cloud(seed, n, wrap=0.0):
+    return synth.synth_cloud(np.random.default_rng(seed), n, wrap_pad=wrap)[0]
+
+
+def clouds(seed, b, n, wrap=0.0):
+    return np.stack([cloud(seed + i, n, wrap) for i in range(b)], 0)
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def ext(dev):
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    return _ext
+
+
+@pytest.mark.parametrize("b,n,m,wrap", [
+    (2, 64, 16, 0.0), (1, 100, 100, 0.3), (2, 256, 64, 0.0), (1, 500, 128, 0.2), (3, 512, 128, 0.1),
+    (2, 1000, 300, 0.1), (1, 1024, 512, 0.1), (2, 2048, 1024, 0.1), (1, 3000, 64, 0.0),
+    (1, 4096, 256, 0.1), (1, 8192, 128, 0.0), (1, 12288, 2048, 0.1), (1, 16000, 32, 0.0),
+    (1, 20000, 40, 0.05)])
+def test_fps_index_exact(ext, orc, dev, b, n, m, wrap):
+    xyz = clouds(n, b, n, wrap)
+    got = ext.furthest_point_sampling(T(xyz, dev), m).cpu().numpy()
+    assert np.array_equal(got, orc.furthest_point_sampling(xyz, m))
+
+
+def test_fps_skip_rule_duplicates_and_degenerate(ext, orc, dev):
+    xyz = clouds(11, 2, 777, 0.5)
+    xyz[0, 100:200] = 0.0                      # skipped points (|p|^2 <= 1e-3)
+    xyz[1, 0] = [0.01, 0.01, 0.0]              # seed itself skipped
+    got = ext.furthest_point_sampling(T(xyz, dev), 300).cpu().numpy()
+    assert np.array_equal(got, orc.furthest_point_sampling(xyz, 300))
+    z = np.zeros((1, 300, 3), np.float32)      # everything skipped -> all zeros
+    assert np.array_equal(ext.furthest_point_sampling(T(z, dev), 9).cpu().numpy(), np.zeros((1, 9), np.int32))
+    same = np.tile(np.array([[0.3, 0.2, 0.9]], np.float32), (1, 513, 1))   # all ties
+    assert np.array_equal(ext.furthest_point_sampling(T(same, dev), 50).cpu().numpy(),
+                          orc.furthest_point_sampling(same, 50))
+
+
+def test_fps_is_sampling_without_replacement_at_full_size(ext, dev):
+    """Size-independent property at the BASELINE size: indices distinct while unique points remain,
+    and min-distance of picks is non-increasing."""
+    xyz = clouds(99, 2, 12288, 0.0)
+    idx = ext.furthest_point_sampling(T(xyz, dev), 2048).cpu().numpy()
+    for b in range(2):
+        assert len(np.unique(idx[b])) == 2048 and idx[b, 0] == 0
+        p = xyz[b][idx[b]].astype(np.float64)
+        d_prev = np.inf
+        for j in range(1, 64):
+            d = np.min(np.linalg.norm(p[:j] - p[j], axis=1))
+            assert d <= d_prev + 1e-6
+            d_prev = d
+
+
+@pytest.mark.parametrize("b,n,m,r,ns", [
+    (2, 500, 77, 0.03, 16), (1, 2048, 1024, 0.025, 16), (1, 2048, 1024, 0.05, 32),
+    (2, 1024, 512, 0.1, 32), (1, 512, 128, 0.2, 32), (1, 12288, 2048, 0.0175, 16),
+    (1, 12288, 2048, 0.025, 32), (1, 130, 130, 0.5, 64), (1, 70, 5, 0.05, 100)])
+def test_ball_query_index_exact(ext, orc, dev, b, n, m, r, ns):
+    xyz = clouds(n + m, b, n, 0.1)
+    sel = np.random.default_rng(5).permutation(n)[:m]
+    new_xyz = np.ascontiguousarray(xyz[:, sel])
+    got = ext.ball_query(T(new_xyz, dev), T(xyz, dev), r, ns).cpu().numpy()
+    assert np.array_equal(got, orc.ball_query(new_xyz, xyz, r, ns))
+
+
+def test_ball_query_pair_equals_two_queries_and_no_hit_rows(ext, orc, dev):
+    xyz = clouds(21, 2, 3000, 0.1)
+    new_xyz = np.ascontiguousarray(xyz[:, :700])
+    new_xyz[0, 5] += 50.0                       # a centre with no neighbour -> zero row
+    i0, i1 = ext.ball_query_pair(T(new_xyz, dev), T(xyz, dev), 0.0175, 16, 0.025, 32)
+    assert np.array_equal(i0.cpu().numpy(), orc.ball_query(new_xyz, xyz, 0.0175, 16))
+    assert np.array_equal(i1.cpu().numpy(), orc.ball_query(new_xyz, xyz, 0.025, 32))
+    assert not i0[0, 5].any() and not i1[0, 5].any()
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 512, 128), (1, 1024, 512), (1, 2048, 1024), (1, 12288, 2048),
+                                   (2, 333, 7), (1, 50, 2), (1, 3000, 1025)])
+def test_three_nn_exact(ext, orc, dev, b, n, m):
+    unk = clouds(n, b, n, 0.1)
+    kn = np.ascontiguousarray(unk[:, np.random.default_rng(3).permutation(n)[:m]])
+    d2, idx = ext.three_nn(T(unk, dev), T(kn, dev))
+    od2, oidx = orc.three_nn(unk, kn)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(d2.cpu().numpy(), od2)
+
+
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 9, 300, 40, 16), (1, 99, 2048, 1024, 32), (2, 6, 100, 10, 3),
+                                        (1, 259, 1024, 512, 16), (1, 515, 512, 128, 32)])
+def test_group_points_exact(ext, orc, dev, b, c, n, m, ns):
+    g = np.random.default_rng(c)
+    pts = g.normal(size=(b, c, n)).astype(np.float32)
+    idx = g.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    got = ext.group_points(T(pts, dev), T(idx, dev)).cpu().numpy()
+    assert np.array_equal(got, orc.group_points(pts, idx))
+
+
+def test_group_xyz_features_equals_reference_composition(ext, orc, dev):
+    """QueryAndGroup.forward (pointnet2_utils.py:311-321): group(xyz^T) - new_xyz ++ group(features)."""
+    g = np.random.default_rng(8)
+    b, n, m, ns, c = 2, 1500, 256, 32, 20
+    xyz = clouds(31, b, n, 0.1)
+    new_xyz = np.ascontiguousarray(xyz[:, :m])
+    feats = g.normal(size=(b, c, n)).astype(np.float32)
+    idx = orc.ball_query(new_xyz, xyz, 0.05, ns)
+    want_xyz = orc.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) \
+        - new_xyz.transpose(0, 2, 1)[..., None]
+    want = np.concatenate([want_xyz, orc.group_points(feats, idx)], 1)
+    got = ext.group_xyz_features(T(xyz, dev), T(new_xyz, dev), T(feats, dev), T(idx, dev), True)
+    assert np.array_equal(got.cpu().numpy(), want.astype(np.float32))
+    got2 = ext.group_xyz_features(T(xyz, dev), T(new_xyz, dev), None, T(idx, dev), True)
+    assert np.array_equal(got2.cpu().numpy(), want_xyz.astype(np.float32))
+    got3 = ext.group_xyz_features(T(xyz, dev), T(new_xyz, dev), T(feats, dev), T(idx, dev), False)
+    assert np.array_equal(got3.cpu().numpy(), want[:, 3:])
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 7, 50, 200), (1, 256, 2048, 12288), (1, 5, 20, 101)])
+def test_three_interpolate_exact(ext, orc, dev, b, c, m, n):
+    g = np.random.default_rng(m)
+    pts = g.normal(size=(b, c, m)).astype(np.float32)
+    idx = g.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = g.random((b, n, 3)).astype(np.float32)
+    got = ext.three_interpolate(T(pts, dev), T(idx, dev), T(w, dev)).cpu().numpy()
+    assert np.array_equal(got, orc.three_interpolate(pts, idx, w))
+
+
+def test_gather_and_grads(ext, orc, dev):
+    g = np.random.default_rng(12)
+    b, c, n, m, ns = 2, 6, 400, 64, 8
+    pts = g.normal(size=(b, c, n)).astype(np.float32)
+    i1 = g.integers(0, n, size=(b, m)).astype(np.int32)
+    assert np.array_equal(ext.gather_points(T(pts, dev), T(i1, dev)).cpu().numpy(), orc.gather_points(pts, i1))
+    go = g.normal(size=(b, c, m)).astype(np.float32)
+    # atomics: fp32 summation order differs from the oracle's -> tolerance, not bit equality
+    assert np.allclose(ext.gather_points_grad(T(go, dev), T(i1, dev), n).cpu().numpy(),
+                       orc.gather_points_grad(go, i1, n), rtol=1e-5, atol=1e-5)
+    idx = g.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    gg = g.normal(size=(b, c, m, ns)).astype(np.float32)
+    assert np.allclose(ext.group_points_grad(T(gg, dev), T(idx, dev), n).cpu().numpy(),
+                       orc.group_points_grad(gg, idx, n), rtol=1e-5, atol=1e-5)
+    i3 = g.integers(0, m, size=(b, n, 3)).astype(np.int32)
+    w = g.random((b, n, 3)).astype(np.float32)
+    gi = g.normal(size=(b, c, n)).astype(np.float32)
+    assert np.allclose(ext.three_interpolate_grad(T(gi, dev), T(i3, dev), T(w, dev), m).cpu().numpy(),
+                       orc.three_interpolate_grad(gi, i3, w, m), rtol=1e-4, atol=1e-5)
+    try:
+        ext.REFERENCE_BUG_COMPAT = True
+        bug = ext.three_interpolate_grad(T(gi, dev), T(i3, dev), T(w, dev), m).cpu().numpy()
+    finally:
+        ext.REFERENCE_BUG_COMPAT = False
+    assert np.array_equal(bug, orc.three_interpolate_grad(gi, i3, w, m, refbug=True))
+
+
+def test_native_regression_vectors_on_gpu(ext, dev, golden):
+    z = golden("native_oracle.npz")
+    xyz = T(z["xyz"], dev)
+    fps = ext.furthest_point_sampling(xyz, 512)
+    assert np.array_equal(fps.cpu().numpy(), z["fps"])
+    new_xyz = torch.gather(xyz, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    assert np.array_equal(ext.ball_query(new_xyz, xyz, 0.025, 16).cpu().numpy(), z["bq_r0025_16"])
+    assert np.array_equal(ext.ball_query(new_xyz, xyz, 0.05, 32).cpu().numpy(), z["bq_r005_32"])
+    d2, idx = ext.three_nn(xyz, new_xyz)
+    assert np.array_equal(idx.cpu().numpy(), z["nn_idx"]) and np.array_equal(d2.cpu().numpy(), z["nn_d2"])
+
+
+def test_sa_fp_modules_run_and_match_unfused_composition(dev, orc):
+    """Module-level: SA-MSG forward through the fused path == the reference's op-by-op
+    composition evaluated with the oracle ops + the same torch MLP; autograd reaches features."""
+    from pvn3d_amd.lib.pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPModule
+    torch.manual_seed(0)
+    b, n = 2, 1024
+    xyz_np = clouds(77, b, n, 0.1)
+    xyz = T(xyz_np, dev)
+    feats = torch.randn(b, 6, n, device=dev, requires_grad=True)
+    sa = PointnetSAModuleMSG(npoint=256, radii=[0.025, 0.05], nsamples=[16, 32],
+                             mlps=[[6, 16, 16, 32], [6, 32, 32, 64]]).to(dev).eval()
+    new_xyz, out = sa(xyz, feats)
+    assert new_xyz.shape == (b, 256, 3) and out.shape == (b, 96, 256)
+    fps = orc.furthest_point_sampling(xyz_np, 256)
+    want_new = np.take_along_axis(xyz_np, fps[..., None].astype(np.int64).repeat(3, -1), 1)
+    assert np.array_equal(new_xyz.cpu().numpy(), want_new)
+    pooled = []
+    for i, (r, ns) in enumerate([(0.025, 16), (0.05, 32)]):
+        idx = orc.ball_query(want_new, xyz_np, r, ns)
+        gx = orc.group_points(np.ascontiguousarray(xyz_np.transpose(0, 2, 1)), idx) - want_new.transpose(0, 2, 1)[..., None]
+        gf = orc.group_points(feats.detach().cpu().numpy(), idx)
+        grouped = T(np.concatenate([gx, gf], 1).astype(np.float32), dev)
+        pooled.append(sa.mlps[i](grouped).max(dim=3)[0])
+    want = torch.cat(pooled, 1)
+    assert torch.allclose(out, want, rtol=1e-5, atol=1e-5)
+    out.sum().backward()
+    assert feats.grad is not None and torch.isfinite(feats.grad).all() and feats.grad.abs().sum() > 0
+    fp = PointnetFPModule(mlp=[96 + 6, 32, 32]).to(dev).eval()
+    up = fp(xyz, new_xyz.detach(), feats.detach(), out.detach())
+    assert up.shape == (b, 32, n) and torch.isfinite(up).all()

@@ -1,0 +1,181 @@
+"""Parity of the vote -> MeanShift -> pose path on the GPU against (a) outputs of the reference's
+own Python recorded in tests/golden and (b) the CPU oracle on fresh seeded inputs.
+Tolerances (north_star): centres and R,t within 1e-4; iteration counts +-1; labels exact."""
+import concurrent.futures
+
+import numpy as np
+import pytest
+import torch
+
+from pvn3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def test_meanshift_vs_reference_golden(dev, golden):
+    from pvn3d_amd.lib.utils.meanshift_pytorch import MeanShiftTorch
+    z = golden("meanshift_ref.npz")
+    for i in range(int(z["n_cases"])):
+        A, bw = z["A%d" % i], float(z["bw%d" % i])
+        mi = int(z["max_iter%d" % i]) if ("max_iter%d" % i) in z else 300
+        ms = MeanShiftTorch(bandwidth=bw, max_iter=mi)
+        ctr, labels = ms.fit(T(A, dev))
+        assert ctr.shape == (3,) and labels.shape == (len(A),) and labels.dtype == torch.bool
+        assert np.abs(ctr.cpu().numpy() - z["ctr%d" % i]).max() < TOL, i
+        assert abs(int(ms.last_iters[0]) - int(z["iters%d" % i])) <= 1, (i, int(ms.last_iters[0]))
+        assert np.array_equal(labels.cpu().numpy(), z["labels%d" % i]), i
+
+
+@pytest.mark.parametrize("n,sig_out,frac", [(3072, 0.05, 0.1), (3072, 0.3, 0.1), (5000, 0.3, 0.3), (257, 0.3, 0.2)])
+def test_meanshift_vs_oracle(dev, orc, n, sig_out, frac):
+    from pvn3d_amd.lib.utils.meanshift_pytorch import MeanShiftTorch
+    rng = np.random.default_rng(n)
+    is_out = rng.random(n) < frac
+    A = (np.array([0.05, -0.02, 0.9]) + rng.normal(size=(n, 3)) * np.where(is_out, sig_out, 0.005)[:, None]).astype(np.float32)
+    octr, olab, oit = orc.meanshift_fit(A, 0.08)
+    ms = MeanShiftTorch(bandwidth=0.08)
+    ctr, labels = ms.fit(T(A, dev))
+    assert np.abs(ctr.cpu().numpy() - octr).max() < TOL
+    assert abs(int(ms.last_iters[0]) - oit) <= 1
+    assert np.array_equal(labels.cpu().numpy(), olab)
+
+
+def test_meanshift_batch_equals_single_and_async_equals_polled(dev):
+    from pvn3d_amd.lib.utils.meanshift_pytorch import MeanShiftTorch
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    rng = np.random.default_rng(3)
+    sets = [(rng.normal(size=(n, 3)) * s + 0.5).astype(np.float32)
+            for n, s in [(700, 0.01), (1, 0.01), (1300, 0.05), (64, 0.2), (2049, 0.02)]]
+    ms = MeanShiftTorch(bandwidth=0.08)
+    ctrs, labels = ms.fit_batch([T(a, dev) for a in sets])
+    it_b = ms.last_iters.cpu().numpy()
+    for i, a in enumerate(sets):
+        c1, l1 = ms.fit(T(a, dev))
+        assert torch.equal(c1, ctrs[i]) and torch.equal(l1, labels[i])
+        assert int(ms.last_iters[0]) == it_b[i]
+    # fully asynchronous mode (no host poll) gives identical results
+    pts4 = torch.zeros((len(sets[2]), 4), device=dev)
+    pts4[:, :3] = T(sets[2], dev)
+    so = torch.zeros(1, dtype=torch.int32, device=dev)
+    sc = torch.full((1,), len(sets[2]), dtype=torch.int32, device=dev)
+    a = eng.meanshift_fit_batch(pts4, so, sc, len(sets[2]), 0.08, poll_every=0)
+    b = eng.meanshift_fit_batch(pts4, so, sc, len(sets[2]), 0.08, poll_every=3)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[0][0], ctrs[2])
+
+
+def test_kabsch_vs_reference_golden_and_icp_test(dev, golden):
+    from pvn3d_amd.lib.utils.basic_utils import best_fit_transform
+    z = golden("kabsch_ref.npz")
+    for i in range(int(z["n_cases"])):
+        A, B, Tref = z["A%d" % i], z["B%d" % i], z["T%d" % i]
+        Tg = best_fit_transform(A, B)
+        assert Tg.shape == (3, 4) and Tg.dtype == np.float64
+        if i == 10:   # planar set: solution not unique, check the residual instead
+            assert np.abs(A @ Tg[:, :3].T + Tg[:, 3] - B).max() < 1e-5
+            continue
+        assert np.abs(Tg - Tref).max() < TOL, i
+    rng = np.random.RandomState(1)       # lib/utils/icp/test.py:24-64 restated
+    A = rng.rand(10, 3)
+    for _ in range(20):
+        ax = rng.rand(3); ax /= np.linalg.norm(ax)
+        th = rng.rand() * .1
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        B = (A + rng.rand(3) * .1) @ R.T + rng.randn(10, 3) * .01
+        Tg = best_fit_transform(B.astype(np.float32), A.astype(np.float32))
+        assert np.allclose(B @ Tg[:, :3].T + Tg[:, 3], A, atol=0.06)
+        assert np.allclose(Tg[:, :3].T, R, atol=0.06)
+
+
+def test_frames_vs_reference_driven_golden(dev, golden):
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    z = golden("frames_ref.npz")
+    f = synth.synth_frame(frame=0, n_pts=2048, n_obj=2048)       # BASELINE config 1
+    res = ev.cal_batch_poses_lm(T(f["pcld"], dev)[None], T(f["mask"], dev)[None], T(f["ctr_of"], dev)[None],
+                                T(f["pred_kp_of"], dev)[None], True, 2, False, 1)
+    assert np.abs(res["poses"][0].cpu().numpy() - z["lm0_pose"]).max() < TOL
+    assert np.abs(res["cls_kps"][0].cpu().numpy() - z["lm0_cls_kps"]).max() < TOL
+    assert np.abs(res["iters"][0].cpu().numpy() - z["lm0_iters"]).max() <= 1
+    poses = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(f["mask"], dev), T(f["ctr_of"], dev),
+                                  T(f["pred_kp_of"], dev), True, 2, False, 1)
+    assert isinstance(poses, list) and poses[0].shape == (3, 4)
+    assert np.abs(poses[0] - z["lm0_pose"]).max() < TOL
+    f = synth.synth_frame(frame=1, n_pts=4096, n_obj=1024)       # centre-cluster filter on
+    poses = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(f["mask"], dev), T(f["ctr_of"], dev),
+                                  T(f["pred_kp_of"], dev), True, 2, True, 1)
+    assert np.abs(poses[0] - z["lm1_pose"]).max() < TOL
+    y = synth.synth_frame_ycb(frame=2, n_pts=4096, n_obj_total=2000, n_objs=4)
+    ids, poses = ev.cal_frame_poses(T(y["pcld"], dev), T(y["mask"], dev), T(y["ctr_of"], dev),
+                                    T(y["pred_kp_of"], dev), True, 22, True)
+    assert np.array_equal(ids, z["ycb_ids"])
+    assert np.abs(np.stack(poses, 0) - z["ycb_poses"]).max() < TOL
+    res = ev.cal_batch_poses(T(y["pcld"], dev)[None], T(y["mask"], dev)[None], T(y["ctr_of"], dev)[None],
+                             T(y["pred_kp_of"], dev)[None], True, 22, True)
+    assert np.array_equal(res["new_mask"][0].cpu().numpy(), z["ycb_new_mask"])
+    kp = res["cls_kps"][0].cpu().numpy()
+    for c in ids:
+        assert np.abs(kp[c - 1] - z["ycb_cls_kps"][c]).max() < TOL
+
+
+def test_frame_edge_cases(dev, orc):
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    f = synth.synth_frame(frame=5, n_pts=1024, n_obj=300)
+    empty = np.zeros_like(f["mask"])                               # no object point -> identity
+    p = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(empty, dev), T(f["ctr_of"], dev), T(f["pred_kp_of"], dev), True, 2, False, 1)
+    assert np.array_equal(p[0], np.identity(4)[:3, :])
+    one = empty.copy(); one[17] = 1                                # a single object point
+    p = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(one, dev), T(f["ctr_of"], dev), T(f["pred_kp_of"], dev), True, 2, True, 1)
+    assert np.isfinite(p[0]).all()
+    from oracle import posecal
+    want = posecal.cal_frame_poses_lm(f["pcld"], one, f["ctr_of"], f["pred_kp_of"], True, 2, True, f["mesh_kps"])
+    # 9 voted points from one pixel: rank-deficient but well defined translation
+    assert np.abs((f["mesh_kps"] @ p[0][:, :3].T + p[0][:, 3]) - (f["mesh_kps"] @ want[0][:, :3].T + want[0][:, 3])).max() < 1e-3
+    # use_ctr False: pose from the K keypoints only
+    p8 = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(f["mask"], dev), T(f["ctr_of"], dev), T(f["pred_kp_of"], dev), False, 2, False, 1)
+    w8 = posecal.cal_frame_poses_lm(f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], False, 2, False, f["mesh_kps"])
+    assert np.abs(p8[0] - w8[0]).max() < TOL
+
+
+def test_full_size_frame_vs_oracle_and_ground_truth(dev, orc):
+    """BASELINE config 2 shape: N=12288, n_obj=3072, K=8 (+centre)."""
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    from oracle import posecal
+    f = synth.synth_frame(frame=7, n_pts=12288, n_obj=3072)
+    res = ev.cal_batch_poses_lm(T(f["pcld"], dev)[None], T(f["mask"], dev)[None], T(f["ctr_of"], dev)[None],
+                                T(f["pred_kp_of"], dev)[None], True, 2, False, 1)
+    want, kps, iters = posecal.cal_frame_poses_lm(f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], True, 2, False,
+                                                  f["mesh_kps"], return_debug=True)
+    assert np.abs(res["poses"][0].cpu().numpy() - want[0]).max() < TOL
+    assert np.abs(res["cls_kps"][0].cpu().numpy() - kps).max() < TOL
+    assert np.abs(res["iters"][0].cpu().numpy() - iters).max() <= 1
+    assert (res["counts"][0].cpu().numpy() == 3072).all()
+    pose = res["poses"][0].cpu().numpy()
+    assert np.abs(pose[:, :3] - f["R"]).max() < 2e-2 and np.abs(pose[:, 3] - f["t"]).max() < 2e-3
+
+
+def test_batch_of_frames_equals_per_frame_and_threadpool(dev):
+    """Frames are independent: a batched call equals per-frame calls; and the per-frame API is
+    safe under the reference's ThreadPoolExecutor usage (pvn3d_eval_utils.py:373-380)."""
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    fr = [synth.synth_frame(frame=10 + i, n_pts=2048, n_obj=400 + 100 * i) for i in range(4)]
+    st = lambda k: torch.stack([T(f[k], dev) for f in fr], 0)
+    res = ev.cal_batch_poses_lm(st("pcld"), st("mask"), st("ctr_of"), st("pred_kp_of"), True, 2, False, 1)
+    poses_b = res["poses"].cpu().numpy()
+
+    def one(f):
+        return ev.cal_frame_poses_lm(T(f["pcld"], dev), T(f["mask"], dev), T(f["ctr_of"], dev),
+                                     T(f["pred_kp_of"], dev), True, 2, False, 1)[0]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        singles = list(ex.map(one, fr))
+    for i in range(4):
+        assert np.array_equal(singles[i], poses_b[i])
+    te = ev.TorchEval(n_cls=2)
+    out = te.eval_pose_parallel(st("pcld"), None, st("mask"), st("ctr_of"), None, None, 0, None, None,
+                                st("pred_kp_of"), use_ctr_clus_flter=False, use_ctr=True, ds_type="linemod", obj_id=1)
+    assert len(out) == 4 and np.array_equal(out[2][0], poses_b[2])
