@@ -140,17 +140,20 @@ def three_interpolate_grad(grad_out, idx, weight, m, refbug=False):
 
 
 def meanshift_fit(A, bandwidth, max_iter=300, return_all=False):
-    """MeanShiftTorch(bandwidth, max_iter).fit(A) -> (ctr[3], labels[n] bool, iters)."""
+    """MeanShiftTorch(bandwidth, max_iter).fit(A) -> (ctr[3], labels[n] bool, iters).
+    return_all adds the final seed positions and the last iteration's max shift."""
     A, pa = _fa(A)
     n = A.shape[0]
     ctr = np.zeros(3, np.float32)
     labels = np.zeros(n, np.uint8)
     iters = ctypes.c_int(0)
     cfin = np.zeros((n, 3), np.float32)
+    last = ctypes.c_float(0)
     lib().orc_meanshift_fit(pa, n, ctypes.c_float(bandwidth), int(max_iter), ctr.ctypes.data_as(_f),
-                            labels.ctypes.data_as(_u8), ctypes.byref(iters), cfin.ctypes.data_as(_f))
+                            labels.ctypes.data_as(_u8), ctypes.byref(iters), cfin.ctypes.data_as(_f),
+                            ctypes.byref(last))
     if return_all:
-        return ctr, labels.astype(bool), iters.value, cfin
+        return ctr, labels.astype(bool), iters.value, cfin, float(last.value)
     return ctr, labels.astype(bool), iters.value
 
 

@@ -297,16 +297,21 @@ void orc_three_interpolate_grad_refbug(int b, int c, int n, int m, const float *
  * double (torch's fp32 CPU sum is a vectorised cascade sum whose order is an
  * implementation detail of the installed torch; double accumulation is the order-free
  * stand-in).  Pinned against the reference's own outputs in tests/golden/meanshift_*.npz.
- * If C_traj != NULL it receives the seed positions after the last iteration (n,3).
+ * If C_final != NULL it receives the seed positions after the last iteration (n,3);
+ * last_max_shift (optional) receives max(Adis) of the last iteration -- tests use it to tell
+ * when the stop decision is marginal (a slowly creeping outlier within a few % of the
+ * threshold makes the iteration COUNT chaotic in any fp32 implementation; the centre is not).
  * ---------------------------------------------------------------------------------- */
 void orc_meanshift_fit(const float *A, int n, float bandwidth, int max_iter, float *ctr_out,
-                       uint8_t *labels_out, int *iters_out, float *C_final) {
+                       uint8_t *labels_out, int *iters_out, float *C_final,
+                       float *last_max_shift) {
   const float stop_thresh = (float)((double)bandwidth * 1e-3);
   const float kconst = 1.0f / (bandwidth * sqrtf(2.0f * (float)M_PI));
   float *C = (float *)malloc(sizeof(float) * (size_t)n * 3);
   float *Cn = (float *)malloc(sizeof(float) * (size_t)n * 3);
   memcpy(C, A, sizeof(float) * (size_t)n * 3);
   int it = 0;
+  float final_shift = 0.0f;
   while (1) {
     ++it;
     float max_adis = 0.0f;
@@ -333,6 +338,7 @@ void orc_meanshift_fit(const float *A, int n, float bandwidth, int max_iter, flo
       if (adis > max_adis) max_adis = adis;
     }
     float *t = C; C = Cn; Cn = t;
+    final_shift = max_adis;
     if (max_adis < stop_thresh || it > max_iter) break; /* :42 */
   }
   /* :46-51 -- note both operands are built from A: neighbour counts of ORIGINAL points */
@@ -357,6 +363,7 @@ void orc_meanshift_fit(const float *A, int n, float bandwidth, int max_iter, flo
   }
   ctr_out[0] = C[best_i * 3 + 0]; ctr_out[1] = C[best_i * 3 + 1]; ctr_out[2] = C[best_i * 3 + 2];
   if (iters_out) *iters_out = it;
+  if (last_max_shift) *last_max_shift = final_shift; /* how close the stop decision was */
   if (C_final) memcpy(C_final, C, sizeof(float) * (size_t)n * 3);
   free(C);
   free(Cn);

@@ -7,20 +7,48 @@
 //   * every point and its running min-distance live in VGPRs for the whole kernel
 //     (PPT points per thread); global memory is read once.  The reference re-reads xyz and
 //     temp from global memory every round.
-//   * per round: VALU scan -> wave64 butterfly arg-max on a packed 64-bit key -> one LDS slot
-//     per wave -> ONE barrier (double-buffered slots) -> winner coordinates from an LDS copy
-//     of the cloud.  The reference uses 9 __syncthreads per round.
-//   * the packed key reproduces the reference's tie-break exactly without emulating its
-//     block: the reference's 512-thread strided scan + halving tree picks, among equal
-//     distances, the smallest bit-reversed (k mod bs), then the smallest k
-//     (sampling_gpu.cu:59-65,96-168, bs = opt_n_threads(n)).  key = (bits(d2) << 32) | ~prio
-//     with prio(k) = bitrev(k mod bs) * ceil(n/bs) + k / bs, so ANY reduction order gives the
-//     reference's winner.
+//   * one wave per SIMD (256 threads, up to 64 points per lane): the round is VALU-issue bound
+//     (~12 instructions per point), so fewer, fatter waves minimise the per-round reduction
+//     tail: DPP wave reductions (no LDS), one 8-byte LDS slot per wave, ONE barrier per round
+//     (double-buffered slots), winner coordinates from an LDS copy of the cloud.  The
+//     reference uses 9 __syncthreads per round.
+//   * the reference's tie-break is reproduced exactly without emulating its block: its
+//     512-thread strided scan + halving tree picks, among equal distances, the smallest
+//     bit-reversed (k mod bs), then the smallest k (sampling_gpu.cu:59-65,96-168,
+//     bs = opt_n_threads(n)).  With prio(k) = bitrev(k mod bs) * ceil(n/bs) + k / bs the winner
+//     is (max d2, then min prio) under ANY reduction order; points are laid out so that a
+//     thread's slots ascend in prio and a strict '>' scan suffices inside a thread.
 // Arithmetic: this TU is compiled with -ffp-contract=off; d is evaluated as
 // ((dx*dx + dy*dy) + dz*dz) with one rounding per operation (oracle/pvn3d_oracle.c).
 #include "common.h"
 
 namespace {
+
+// ---- wave64 reductions on the DPP path (no LDS traffic): quad swaps, half-row / row mirrors,
+// then row_bcast15 / row_bcast31; the full result lands in lane 63 and is broadcast as a scalar.
+#define PVN3D_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xf, false)
+
+// Distances are >= 0 (or a negative "invalid" marker), so their bit patterns order like signed
+// integers: v_max_i32 needs no NaN canonicalisation and fuses with the DPP operand.
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, PVN3D_DPP(v, 0xB1, 0xf));   // quad_perm [1,0,3,2]
+  v = max(v, PVN3D_DPP(v, 0x4E, 0xf));   // quad_perm [2,3,0,1]
+  v = max(v, PVN3D_DPP(v, 0x141, 0xf));  // row_half_mirror
+  v = max(v, PVN3D_DPP(v, 0x140, 0xf));  // row_mirror
+  v = max(v, PVN3D_DPP(v, 0x142, 0xa));  // row_bcast:15
+  v = max(v, PVN3D_DPP(v, 0x143, 0xc));  // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0xB1, 0xf));
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0x4E, 0xf));
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0x141, 0xf));
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0x140, 0xf));
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0x142, 0xa));
+  v = min(v, (unsigned)PVN3D_DPP((int)v, 0x143, 0xc));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 __device__ __forceinline__ long long shfl_xor_i64(long long v, int mask) {
   int lo = __shfl_xor((int)(v & 0xffffffffLL), mask, 64);
@@ -37,6 +65,8 @@ __device__ __forceinline__ long long wave_max_i64(long long v) {
   return v;
 }
 
+// Tie-break priority of point k in the reference block (bs = opt_n_threads(n) threads,
+// L = log2 bs, Q = ceil(n/bs)): smaller = wins ties.  A bijection between k and prio.
 __device__ __forceinline__ unsigned fps_prio(int k, int L, int Q) {
   unsigned r = L ? (__brev((unsigned)k & ((1u << L) - 1u)) >> (32 - L)) : 0u;
   return r * (unsigned)Q + ((unsigned)k >> L);
@@ -54,87 +84,149 @@ __device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
   return (double)mag <= 1e-3;
 }
 
-// Register-resident FPS.  THREADS in {64,256,1024}; PPT = points per thread.
-// lds_xyz != 0: dynamic LDS holds an SoA copy of the cloud (3*n floats) for the winner fetch.
-template <int THREADS, int PPT>
+// Register-resident FPS.  THREADS in {64,256} (one wave per SIMD at most); PPT points per
+// thread.  Slot (thread t, i) holds the point whose tie-break priority is i*THREADS + t, so
+// within a thread priorities ascend with i; the per-thread arg-max is an order-preserving
+// pairwise TREE (ties keep the left = lower-priority-number operand) instead of the
+// reference's serial scan -- same winner, log-depth dependency chain.  Across threads the
+// winner is (max d2, then min priority).
+// lds_xyz != 0: dynamic LDS holds an SoA copy of the cloud in PRIORITY order (3*slots floats),
+// so the winner's coordinates are fetched by priority and the priority->index conversion
+// (an integer division) happens once, after the serial loop.
+// PVN3D_FPS_PROBE (tools/fps_probe.hip only): per-phase s_memtime accounting of the round.
+#ifdef PVN3D_FPS_PROBE
+#define FPS_PROBE_ARG , long long* __restrict__ dbg
+#define FPS_PROBE_NULL , (long long*)nullptr
+#define FPS_T(i) { const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; }
+#else
+#define FPS_PROBE_ARG
+#define FPS_PROBE_NULL
+#define FPS_T(i)
+#endif
+
+template <int THREADS, int PPT, bool lds_xyz>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, int Q,
-                                                          int lds_xyz,
                                                           const float* __restrict__ dataset,
-                                                          int* __restrict__ idxs) {
+                                                          int* __restrict__ idxs FPS_PROBE_ARG) {
   constexpr int NW = THREADS / 64;
+  constexpr int SLOTS = THREADS * PPT;
   extern __shared__ float s_dyn[];
-  __shared__ long long s_slot[2][NW > 1 ? NW : 1];
+  __shared__ unsigned long long s_slot[2][NW];
   if (m <= 0) return;
   const int tid = threadIdx.x;
   dataset += (size_t)blockIdx.x * n * 3;
   idxs += (size_t)blockIdx.x * m;
+  const unsigned n_prio = (unsigned)Q << L;  // priorities in use: [0, bs*Q)
 
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
-  unsigned nprio[PPT];  // ~prio
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = tid + i * THREADS;
+    const unsigned p = (unsigned)(i * THREADS + tid);
+    const int k = p < n_prio ? fps_prio_to_k(p, L, Q) : n;
     if (k < n) {
       px[i] = dataset[k * 3 + 0];
       py[i] = dataset[k * 3 + 1];
       pz[i] = dataset[k * 3 + 2];
-      // skipped points never update temp and never win: temp = -inf makes d2 = -inf, whose
-      // key is below the "no candidate" key -1.
+      // skipped points never update temp and never win: temp = -inf keeps d2 = -inf (negative
+      // as an integer too), below every real distance.
       tmp[i] = fps_skipped(px[i], py[i], pz[i]) ? -__builtin_inff() : 1e10f;
-      nprio[i] = ~fps_prio(k, L, Q);
-      if (lds_xyz) {
-        s_dyn[k] = px[i];
-        s_dyn[n + k] = py[i];
-        s_dyn[2 * n + k] = pz[i];
-      }
     } else {
       px[i] = py[i] = pz[i] = 0.f;
       tmp[i] = -__builtin_inff();
-      nprio[i] = 0u;
+    }
+    if (lds_xyz) {
+      s_dyn[p] = px[i];
+      s_dyn[SLOTS + p] = py[i];
+      s_dyn[2 * SLOTS + p] = pz[i];
     }
   }
-  int old = 0;
-  if (tid == 0) idxs[0] = 0;
+  const unsigned prio0 = fps_prio(0, L, Q);  // == 0
+  if (tid == 0) idxs[0] = lds_xyz ? (int)prio0 : 0;
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
   if (NW > 1 || lds_xyz) __syncthreads();
 
+  // In the loop only LDS traffic is ever waited for: the per-round index store stays in
+  // flight (a __syncthreads() would drain it -- its release fence waits vmcnt(0), ~1 us per
+  // round), so the cross-wave exchange uses a raw s_barrier behind an LDS-only wait.
+#ifdef PVN3D_FPS_PROBE
+  long long acc_[6] = {0, 0, 0, 0, 0, 0};
+  long long last_ = __builtin_readcyclecounter();
+  const long long w0_ = wall_clock64();
+#endif
   for (int j = 1; j < m; ++j) {
-    long long best = -1LL;
+    int v[PPT], ix[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
       const float d = dx * dx + dy * dy + dz * dz;
-      const float d2 = fminf(d, tmp[i]);
+      const float d2 = __builtin_fminf(d, tmp[i]);
       tmp[i] = d2;
-      const long long key = ((long long)__float_as_int(d2) << 32) | (long long)nprio[i];
-      best = key > best ? key : best;
+      v[i] = __float_as_int(d2);
+      ix[i] = i;
     }
-    best = wave_max_i64(best);
+    FPS_T(0)
+#pragma unroll
+    for (int s = 1; s < PPT; s *= 2) {
+#pragma unroll
+      for (int i = 0; i + s < PPT; i += 2 * s) {
+        const bool gt = v[i + s] > v[i];   // strict: ties keep the lower slot
+        v[i] = gt ? v[i + s] : v[i];
+        ix[i] = gt ? ix[i + s] : ix[i];
+      }
+    }
+    const int best = v[0];
+    FPS_T(1)
+    const int wmax = wave_max_i32(best);
+    const unsigned cand = (best == wmax) ? (unsigned)(ix[0] * THREADS + tid) : 0xffffffffu;
+    unsigned wprio = wave_min_u32(cand);
+    int gmax = wmax;
+    FPS_T(2)
     if (NW > 1) {
       const int buf = j & 1;
-      if ((tid & 63) == 0) s_slot[buf][tid >> 6] = best;
-      __syncthreads();
-      long long b2 = s_slot[buf][0];
+      if ((tid & 63) == 0)
+        s_slot[buf][tid >> 6] = ((unsigned long long)(unsigned)wmax << 32) | wprio;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-      for (int w = 1; w < NW; ++w) {
-        long long o = s_slot[buf][w];
-        b2 = o > b2 ? o : b2;
+      for (int w = 0; w < NW; ++w) {
+        const unsigned long long o = s_slot[buf][w];
+        const int om = (int)(unsigned)(o >> 32);
+        const unsigned op = (unsigned)(o & 0xffffffffu);
+        const bool take = (om > gmax) || (om == gmax && op < wprio);
+        gmax = take ? om : gmax;
+        wprio = take ? op : wprio;
       }
-      best = b2;
     }
-    // "no candidate": every thread kept (best=-1, besti=0) -> the tree returns index 0
-    old = (best == -1LL) ? 0 : fps_prio_to_k(~(unsigned)(best & 0xffffffffLL), L, Q);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (tid == 0) idxs[j] = old;
+    // no valid point at all (every distance is the negative marker): the reference's threads
+    // all keep (best=-1, besti=0) and its tree returns index 0
+    unsigned win = (gmax < 0) ? prio0 : wprio;
+    win = (unsigned)__builtin_amdgcn_readfirstlane((int)win);
+    FPS_T(3)
     if (lds_xyz) {
-      x1 = s_dyn[old];
-      y1 = s_dyn[n + old];
-      z1 = s_dyn[2 * n + old];
+      if (tid == 0) idxs[j] = (int)win;   // priority for now; converted after the loop
+      x1 = s_dyn[win];
+      y1 = s_dyn[SLOTS + win];
+      z1 = s_dyn[2 * SLOTS + win];
     } else {
+      const int old = fps_prio_to_k(win, L, Q);
+      if (tid == 0) idxs[j] = old;
       x1 = dataset[old * 3 + 0];
       y1 = dataset[old * 3 + 1];
       z1 = dataset[old * 3 + 2];
     }
+#ifdef PVN3D_FPS_PROBE
+    asm volatile("" :: "v"(x1), "v"(y1), "v"(z1));
+    FPS_T(4)
+#endif
+  }
+#ifdef PVN3D_FPS_PROBE
+  if (tid == 0 && blockIdx.x == 0 && dbg) {
+    for (int i = 0; i < 5; ++i) dbg[i] = acc_[i];
+    dbg[5] = wall_clock64() - w0_;
+  }
+#endif
+  if (lds_xyz) {
+    __syncthreads();  // tid 0's stores are visible to the block after the barrier
+    for (int j = tid; j < m; j += THREADS) idxs[j] = fps_prio_to_k((unsigned)idxs[j], L, Q);
   }
 }
 
@@ -163,6 +255,7 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(int n, int m, int L, i
       const float d = dx * dx + dy * dy + dz * dz;
       const float d2 = fminf(d, temp[k]);
       temp[k] = d2;
+      // signed key: skipped points (d2 = -inf) sort below the "none" key -1
       const long long key =
           ((long long)__float_as_int(d2) << 32) | (long long)(~fps_prio(k, L, Q));
       best = key > best ? key : best;
@@ -186,15 +279,21 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(int n, int m, int L, i
 template <int THREADS, int PPT>
 int launch_fps_reg(int b, int n, int m, int L, int Q, const float* dataset, int* idxs,
                    hipStream_t st) {
-  size_t lds = (size_t)n * 3 * sizeof(float);
+  size_t lds = (size_t)THREADS * PPT * 3 * sizeof(float);
   int use_lds = lds + 1024 <= 160 * 1024;
   if (!use_lds) lds = 0;
-  auto kern = fps_reg_kernel<THREADS, PPT>;
-  if (lds > 48 * 1024)
-    PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-  hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, st, n, m, L, Q, use_lds, dataset, idxs);
+  if (use_lds) {
+    auto kern = fps_reg_kernel<THREADS, PPT, true>;
+    if (lds > 48 * 1024)
+      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)lds));
+    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, st, n, m, L, Q, dataset,
+                       idxs FPS_PROBE_NULL);
+  } else {
+    hipLaunchKernelGGL((fps_reg_kernel<THREADS, PPT, false>), dim3(b), dim3(THREADS), 0, st, n, m,
+                       L, Q, dataset, idxs FPS_PROBE_NULL);
+  }
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
@@ -243,16 +342,17 @@ extern "C" int pvn3d_furthest_point_sampling(int b, int n, int m, const float* d
   int L = 0;
   while ((1 << L) < bs) ++L;
   const int Q = (n + bs - 1) / bs;
-  if (n <= 64) return launch_fps_reg<64, 1>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 128) return launch_fps_reg<64, 2>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 256) return launch_fps_reg<64, 4>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 512) return launch_fps_reg<64, 8>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 1024) return launch_fps_reg<256, 4>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 2048) return launch_fps_reg<256, 8>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 4096) return launch_fps_reg<1024, 4>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 8192) return launch_fps_reg<1024, 8>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 12288) return launch_fps_reg<1024, 12>(b, n, m, L, Q, dataset, idxs, st);
-  if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, L, Q, dataset, idxs, st);
+  const int slots = bs * Q;  // priority slots to cover (>= n)
+  if (slots <= 64) return launch_fps_reg<64, 1>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 128) return launch_fps_reg<64, 2>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 256) return launch_fps_reg<64, 4>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 512) return launch_fps_reg<64, 8>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 1024) return launch_fps_reg<256, 4>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 2048) return launch_fps_reg<256, 8>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 4096) return launch_fps_reg<256, 16>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 8192) return launch_fps_reg<256, 32>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 12288) return launch_fps_reg<256, 48>(b, n, m, L, Q, dataset, idxs, st);
+  if (slots <= 16384) return launch_fps_reg<256, 64>(b, n, m, L, Q, dataset, idxs, st);
   if (!temp) return (int)hipErrorInvalidValue;  // large clouds need the caller's scratch
   hipLaunchKernelGGL(fps_global_kernel, dim3(b), dim3(1024), 0, st, n, m, L, Q, dataset, temp,
                      idxs);
