@@ -102,6 +102,16 @@ int pvn3d_ball_query_pair(int b, int n, int m, float radius0, int nsample0, floa
                           int nsample1, const float* new_xyz, const float* xyz, int* idx0,
                           int* idx1, void* stream);
 
+/* Same outputs as pvn3d_ball_query_pair (bit-identical), computed through a toroidal uniform
+ * grid so that only points in the 27 cells around a centre are distance-tested -- for large
+ * clouds (PVN3D level 0: n = 12288) this examines ~100 candidates per centre instead of n.
+ * nsample1 == 0 runs a single query (idx1 may be NULL).  n <= 32768.
+ * workspace: >= pvn3d_ball_query_grid_workspace_bytes(b, n) bytes of device scratch. */
+size_t pvn3d_ball_query_grid_workspace_bytes(int b, int n);
+int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, int nsample0, float radius1,
+                               int nsample1, const float* new_xyz, const float* xyz, int* idx0,
+                               int* idx1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* QueryAndGroup.forward (pvn3d/lib/pointnet2_utils/pointnet2_utils.py:293-330) minus the
  * ball query: writes the concatenated tensor directly.
  *   out (b, 3*use_xyz + c, m, nsample):

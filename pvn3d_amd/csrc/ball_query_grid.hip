@@ -1,0 +1,289 @@
+// ball_query_grid.hip -- exact ball query through a toroidal uniform grid, for large clouds.
+//
+// Same results, bit for bit, as the brute-force scan in ball_query.hip (and therefore as
+// query_ball_point_kernel, pvn3d/_ext-src/src/ball_query_gpu.cu:9-44): for every centre the
+// first `nsample` indices k in ascending order with d2 < r^2, padded with the first hit.
+// Only the set of (centre, point) pairs whose distance is EVALUATED shrinks:
+//
+//   build  (one workgroup per cloud): cell = floor(p / h) per axis with h = 1.001 * r_max,
+//          bucket = (cx & 31) | (cy & 31) << 5 | (cz & 31) << 10   (32^3 toroidal grid);
+//          LDS histogram -> exclusive scan -> scatter of (x, y, z, k) into bucket order.
+//          The 27 neighbour cells of any cell map to 27 DISTINCT buckets (32 >= 3), and any
+//          point within r_max of a centre lies in one of the centre's 27 neighbour cells, so
+//          the candidate set is a superset of the ball; aliased far cells only add candidates
+//          that the distance test rejects.
+//   query  (one wave per centre): the 27 bucket ranges are flattened, lanes evaluate
+//          candidates 64 at a time with EXACTLY the brute-force arithmetic
+//          (d2 = ((dx*dx + dy*dy) + dz*dz), dx = centre - point, -ffp-contract=off), and a hit
+//          sets bit k of a per-wave LDS bitmap over the index space.  Reading the bitmap back
+//          in word order yields the hits in ascending k -- no sort, any hit count.
+//
+// With the PVN3D level-0 shapes (n = 12288, m = 2048) ~100 candidates per centre are examined
+// instead of 12288.  Scratch (bucket offsets + the bucket-ordered copy of the cloud) is
+// passed in by the caller; nothing is allocated here.
+#include "common.h"
+
+namespace {
+
+// toroidal extent per axis is 2^AL: 32 (32768 buckets) for large clouds, 16 (4096 buckets) for
+// small ones, where zero-filling and scanning the bucket table would dominate the build
+constexpr int GRID_T_MAX = 32 * 32 * 32;
+constexpr int BQG_MAX_N = 32768;                // bitmap capacity (bits) per wave
+__host__ __device__ constexpr int grid_t(int AL) { return 1 << (3 * AL); }
+
+struct GridWs {
+  int* cell_start;    // [b][T + 1]
+  float4* sorted;     // [b][n]  (x, y, z, bits(k))
+};
+
+inline int grid_al_for(int n) { return n >= 8192 ? 5 : 4; }
+
+inline size_t grid_ws_layout(int b, int n, char* base, GridWs* ws) {
+  const size_t cs = ((size_t)b * (GRID_T_MAX + 1) * sizeof(int) + 255) / 256 * 256;
+  const size_t so = (size_t)b * n * sizeof(float4);
+  if (ws) {
+    ws->cell_start = (int*)base;
+    ws->sorted = (float4*)(base + cs);
+  }
+  return cs + so;
+}
+
+template <int AL>
+__device__ __forceinline__ int grid_bucket_c(int cx, int cy, int cz) {
+  constexpr int M = (1 << AL) - 1;
+  return (cx & M) | ((cy & M) << AL) | ((cz & M) << (2 * AL));
+}
+
+template <int AL>
+__device__ __forceinline__ int grid_bucket(float x, float y, float z, float inv_h) {
+  return grid_bucket_c<AL>((int)floorf(x * inv_h), (int)floorf(y * inv_h), (int)floorf(z * inv_h));
+}
+
+// LDS index of bucket c, padded by one word per 32 so that a thread scanning its own 32 (or 4)
+// consecutive buckets does not fight its neighbours for one bank
+__device__ __forceinline__ int pad32(int c) { return c + (c >> 5); }
+
+// one workgroup (1024 threads) per cloud; dynamic LDS = padded bucket table (132 KiB at AL=5)
+template <int AL>
+__global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
+                                                          const float* __restrict__ xyz,
+                                                          int* __restrict__ cell_start,
+                                                          float4* __restrict__ sorted) {
+  constexpr int T = grid_t(AL);
+  constexpr int PER = T / 1024;
+  extern __shared__ int s_cnt[];  // [pad32(T)]
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  xyz += (size_t)blockIdx.x * n * 3;
+  cell_start += (size_t)blockIdx.x * (T + 1);
+  sorted += (size_t)blockIdx.x * n;
+  for (int i = tid; i < T + (T >> 5); i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024)
+    atomicAdd(&s_cnt[pad32(grid_bucket<AL>(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2], inv_h))], 1);
+  __syncthreads();
+  // exclusive scan: each thread owns PER consecutive buckets
+  int local = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) local += s_cnt[pad32(tid * PER + i)];
+  // block scan of the 1024 partials: wave scan, then the 16 wave totals
+  const int lane = tid & 63, wv = tid >> 6;
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_part[wv] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wv; ++w) wave_off += s_part[w];
+  int run = wave_off + incl - local;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = s_cnt[pad32(tid * PER + i)];
+    s_cnt[pad32(tid * PER + i)] = run;  // becomes the scatter cursor
+    cell_start[tid * PER + i] = run;
+    run += c;
+  }
+  if (tid == 1023) cell_start[T] = run;
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) {
+    const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+    const int pos = atomicAdd(&s_cnt[pad32(grid_bucket<AL>(x, y, z, inv_h))], 1);
+    sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+  }
+}
+
+__device__ __forceinline__ int wave_excl_scan_add(int v, int lane, int* total) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(x, o, 64);
+    if (lane >= o) x += t;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// Pull the hits of one bitmap out in ascending index order.  words = ceil(n/32) <= 1024.
+__device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int nsample,
+                                                 int* __restrict__ out, int lane) {
+  // lane owns WPL consecutive words
+  const int wpl = (words + 63) >> 6;
+  const int w0 = lane * wpl;
+  int mine = 0;
+  for (int i = 0; i < wpl; ++i) {
+    const int w = w0 + i;
+    if (w < words) mine += __builtin_popcount(bm[w]);
+  }
+  int total;
+  int rank = wave_excl_scan_add(mine, lane, &total);
+  // first hit (smallest index) = first set bit overall
+  const unsigned long long has = __ballot(mine > 0);
+  int first = 0;
+  if (has) {
+    const int fl = __builtin_ctzll(has);
+    int f = 0;
+    if (lane == fl) {
+      for (int i = 0; i < wpl; ++i) {
+        const unsigned v = bm[w0 + i];
+        if (v) { f = (w0 + i) * 32 + __builtin_ctz(v); break; }
+      }
+    }
+    first = __shfl(f, fl, 64);
+  }
+  if (mine > 0) {
+    for (int i = 0; i < wpl; ++i) {
+      const int w = w0 + i;
+      if (w >= words) break;
+      unsigned v = bm[w];
+      if (!v) continue;
+      bm[w] = 0u;  // leave the bitmap clean for the next centre
+      while (v && rank < nsample) {
+        const int bit = __builtin_ctz(v);
+        v &= v - 1;
+        out[rank++] = w * 32 + bit;
+      }
+      if (v) rank += __builtin_popcount(v);
+    }
+  }
+  // pad slots [min(total, nsample), nsample) with the first hit; no hit -> zeros
+  const int filled = total < nsample ? total : nsample;
+  for (int l = filled + lane; l < nsample; l += 64) out[l] = first;
+}
+
+// one wave per centre, 4 waves per workgroup.  dynamic LDS: per wave 2 bitmaps of `words` words.
+template <bool PAIR, int AL>
+__global__ __launch_bounds__(256) void ball_query_grid_kernel(
+    int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb, int words,
+    const float* __restrict__ new_xyz, const int* __restrict__ cell_start,
+    const float4* __restrict__ sorted, int* __restrict__ idxa, int* __restrict__ idxb) {
+  extern __shared__ unsigned s_bm[];  // [4 waves][PAIR ? 2 : 1][words]
+  __shared__ int s_pref[4][32];
+  __shared__ int s_beg[4][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int bi = blockIdx.y;
+  const int j = blockIdx.x * 4 + wave;
+  unsigned* bma = s_bm + (size_t)wave * (PAIR ? 2 : 1) * words;
+  unsigned* bmb = bma + words;
+  for (int i = lane; i < (PAIR ? 2 : 1) * words; i += 64) bma[i] = 0u;
+  if (j >= m) return;
+  new_xyz += ((size_t)bi * m + j) * 3;
+  cell_start += (size_t)bi * (grid_t(AL) + 1);
+  sorted += (size_t)bi * n;
+  const float cx = new_xyz[0], cy = new_xyz[1], cz = new_xyz[2];
+  const int gx = (int)floorf(cx * inv_h), gy = (int)floorf(cy * inv_h), gz = (int)floorf(cz * inv_h);
+  // lanes 0..26: one neighbour cell each
+  int beg = 0, cnt = 0;
+  if (lane < 27) {
+    const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
+    const int bucket = grid_bucket_c<AL>(gx + ox, gy + oy, gz + oz);
+    beg = cell_start[bucket];
+    cnt = cell_start[bucket + 1] - beg;
+  }
+  int total;
+  const int pref = wave_excl_scan_add(cnt, lane, &total);
+  if (lane < 32) {
+    s_pref[wave][lane] = (lane < 27) ? pref : 0x7fffffff;
+    s_beg[wave][lane] = beg;
+  }
+  // (single wave: LDS writes above are ordered before the reads below by lgkmcnt waits)
+  for (int f0 = 0; f0 < total; f0 += 64) {
+    const int f = f0 + lane;
+    if (f < total) {
+      // owner cell q: largest q with pref[q] <= f  (pref is non-decreasing, 27 entries)
+      int q = 0;
+#pragma unroll
+      for (int s = 16; s >= 1; s >>= 1) {
+        const int t = q + s;
+        if (t < 27 && s_pref[wave][t] <= f) q = t;
+      }
+      const int qbeg = s_beg[wave][q];   // (LDS, not a shuffle: the owner lane may be inactive here)
+      const int qpref = s_pref[wave][q];
+      const float4 p = sorted[qbeg + (f - qpref)];
+      const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const int k = __float_as_int(p.w);
+      if (d2 < r2a) atomicOr(&bma[k >> 5], 1u << (k & 31));
+      if (PAIR && d2 < r2b) atomicOr(&bmb[k >> 5], 1u << (k & 31));
+    }
+  }
+  emit_from_bitmap(bma, words, nsa, idxa + ((size_t)bi * m + j) * nsa, lane);
+  if (PAIR) emit_from_bitmap(bmb, words, nsb, idxb + ((size_t)bi * m + j) * nsb, lane);
+}
+
+}  // namespace
+
+extern "C" size_t pvn3d_ball_query_grid_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 0;
+  return grid_ws_layout(b, n, nullptr, nullptr);
+}
+
+extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, int nsample0,
+                                          float radius1, int nsample1, const float* new_xyz,
+                                          const float* xyz, int* idx0, int* idx1,
+                                          void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  if (b <= 0 || m <= 0) return 0;
+  const bool pair = nsample1 > 0;
+  if (nsample0 <= 0 || n <= 0 || n > BQG_MAX_N || !new_xyz || !xyz || !idx0 || (pair && !idx1) ||
+      !workspace || !(radius0 > 0.f) || (pair && !(radius1 > 0.f)))
+    return (int)hipErrorInvalidValue;
+  if (workspace_bytes < pvn3d_ball_query_grid_workspace_bytes(b, n))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  GridWs ws;
+  grid_ws_layout(b, n, (char*)workspace, &ws);
+  const float rmax = pair ? fmaxf(radius0, radius1) : radius0;
+  const float inv_h = 1.0f / (rmax * 1.001f);
+  const int words = (n + 31) / 32;
+  const size_t qlds = (size_t)4 * (pair ? 2 : 1) * words * sizeof(unsigned);
+  const dim3 qgrid(pvn3d_ceil_div(m, 4), b);
+  const float r2a = radius0 * radius0, r2b = radius1 * radius1;
+#define BQG_RUN(AL)                                                                             \
+  do {                                                                                          \
+    auto bk = grid_build_kernel<AL>;                                                            \
+    const size_t blds = (size_t)(grid_t(AL) + (grid_t(AL) >> 5)) * sizeof(int);                 \
+    if (blds > 48 * 1024)                                                                       \
+      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(bk),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                              (int)blds));                                      \
+    hipLaunchKernelGGL(bk, dim3(b), dim3(1024), blds, st, n, inv_h, xyz, ws.cell_start,         \
+                       ws.sorted);                                                              \
+    PVN3D_LAUNCH_CHECK();                                                                       \
+    if (pair)                                                                                   \
+      hipLaunchKernelGGL((ball_query_grid_kernel<true, AL>), qgrid, dim3(256), qlds, st, n, m,  \
+                         inv_h, r2a, nsample0, r2b, nsample1, words, new_xyz, ws.cell_start,    \
+                         ws.sorted, idx0, idx1);                                                \
+    else                                                                                        \
+      hipLaunchKernelGGL((ball_query_grid_kernel<false, AL>), qgrid, dim3(256), qlds, st, n, m, \
+                         inv_h, r2a, nsample0, 0.f, 0, words, new_xyz, ws.cell_start,           \
+                         ws.sorted, idx0, nullptr);                                             \
+  } while (0)
+  if (grid_al_for(n) == 5) BQG_RUN(5); else BQG_RUN(4);
+#undef BQG_RUN
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

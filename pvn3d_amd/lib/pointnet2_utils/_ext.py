@@ -84,6 +84,18 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+# Clouds at least this large go through the uniform-grid ball query (identical output; the
+# brute-force scan is faster for small clouds).  32768 is the grid kernel's bitmap capacity.
+import os as _os
+GRID_MIN_N = int(_os.environ.get("PVN3D_GRID_MIN_N", "1024"))
+GRID_MAX_N = 32768
+
+
+def _grid_ws(B, N, dev):
+    nbytes = int(lib.pvn3d_ball_query_grid_workspace_bytes(B, N))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """new_xyz (B,npoint,3), xyz (B,N,3) -> (B,npoint,nsample) int32.  ball_query.cpp:8-32"""
     _chk(new_xyz, "new_xyz", torch.float32)
@@ -93,8 +105,15 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     idx = torch.empty((B, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        check(lib.pvn3d_ball_query(B, N, m, float(radius), int(nsample), new_xyz.data_ptr(),
-                                   xyz.data_ptr(), idx.data_ptr(), _stream(new_xyz)), "ball_query")
+        if GRID_MIN_N <= N <= GRID_MAX_N and radius > 0 and m > 0:
+            ws, nbytes = _grid_ws(B, N, new_xyz.device)
+            check(lib.pvn3d_ball_query_pair_grid(B, N, m, float(radius), int(nsample), 0.0, 0,
+                                                 new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+                                                 None, ws.data_ptr(), nbytes, _stream(new_xyz)),
+                  "ball_query")
+        else:
+            check(lib.pvn3d_ball_query(B, N, m, float(radius), int(nsample), new_xyz.data_ptr(),
+                                       xyz.data_ptr(), idx.data_ptr(), _stream(new_xyz)), "ball_query")
     return idx
 
 
@@ -189,10 +208,18 @@ def ball_query_pair(new_xyz, xyz, radius0, nsample0, radius1, nsample1):
     idx0 = torch.empty((B, m, int(nsample0)), dtype=torch.int32, device=new_xyz.device)
     idx1 = torch.empty((B, m, int(nsample1)), dtype=torch.int32, device=new_xyz.device)
     with torch.cuda.device(new_xyz.device):
-        check(lib.pvn3d_ball_query_pair(B, N, m, float(radius0), int(nsample0), float(radius1),
-                                        int(nsample1), new_xyz.data_ptr(), xyz.data_ptr(),
-                                        idx0.data_ptr(), idx1.data_ptr(), _stream(new_xyz)),
-              "ball_query_pair")
+        if GRID_MIN_N <= N <= GRID_MAX_N and radius0 > 0 and radius1 > 0 and m > 0:
+            ws, nbytes = _grid_ws(B, N, new_xyz.device)
+            check(lib.pvn3d_ball_query_pair_grid(B, N, m, float(radius0), int(nsample0),
+                                                 float(radius1), int(nsample1), new_xyz.data_ptr(),
+                                                 xyz.data_ptr(), idx0.data_ptr(), idx1.data_ptr(),
+                                                 ws.data_ptr(), nbytes, _stream(new_xyz)),
+                  "ball_query_pair")
+        else:
+            check(lib.pvn3d_ball_query_pair(B, N, m, float(radius0), int(nsample0), float(radius1),
+                                            int(nsample1), new_xyz.data_ptr(), xyz.data_ptr(),
+                                            idx0.data_ptr(), idx1.data_ptr(), _stream(new_xyz)),
+                  "ball_query_pair")
     return idx0, idx1
 
 

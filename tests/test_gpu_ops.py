@@ -207,3 +207,42 @@ def test_sa_fp_modules_run_and_match_unfused_composition(dev, orc):
     fp = PointnetFPModule(mlp=[96 + 6, 32, 32]).to(dev).eval()
     up = fp(xyz, new_xyz.detach(), feats.detach(), out.detach())
     assert up.shape == (b, 32, n) and torch.isfinite(up).all()
+
+
+@pytest.mark.parametrize("case", ["scene", "dense", "negative_far", "dups", "tiny_radius", "single"])
+def test_ball_query_grid_path_index_exact(ext, orc, dev, case):
+    """Clouds with n >= _ext.GRID_MIN_N go through the uniform-grid kernel: identical to the oracle,
+    including >64 hits per ball, toroidal aliasing (points > 32 cells away), negative coordinates,
+    duplicate points and balls without any hit."""
+    g = np.random.default_rng(abs(hash(case)) % 1000)
+    n, m = 8192, 700
+    if case == "scene":
+        xyz = clouds(5, 2, n, 0.1)
+        r0, ns0, r1, ns1 = 0.0175, 16, 0.025, 32
+    elif case == "dense":                     # hundreds of hits per ball, nsample 16/32 of them kept
+        xyz = (g.normal(size=(1, n, 3)) * 0.03).astype(np.float32) + np.float32(0.5)
+        r0, ns0, r1, ns1 = 0.02, 16, 0.04, 32
+    elif case == "negative_far":              # spans many grid periods, both signs
+        xyz = (g.uniform(-3, 3, size=(1, n, 3))).astype(np.float32)
+        r0, ns0, r1, ns1 = 0.05, 8, 0.3, 64
+    elif case == "dups":
+        base = (g.normal(size=(1, n // 4, 3)) * 0.2).astype(np.float32)
+        xyz = np.tile(base, (1, 4, 1))
+        r0, ns0, r1, ns1 = 0.01, 16, 0.05, 32
+    elif case == "tiny_radius":               # most balls contain only the centre itself
+        xyz = clouds(6, 1, n, 0.0)
+        r0, ns0, r1, ns1 = 1e-4, 4, 2e-4, 4
+    else:
+        xyz = clouds(7, 1, n, 0.1)
+        r0, ns0, r1, ns1 = 0.03, 32, 0.0, 0
+    assert n >= ext.GRID_MIN_N
+    sel = g.permutation(n)[:m]
+    new_xyz = np.ascontiguousarray(xyz[:, sel])
+    new_xyz[0, 3] += 77.0                      # a centre far from everything -> zero row
+    if case == "single":
+        got = ext.ball_query(T(new_xyz, dev), T(xyz, dev), r0, ns0).cpu().numpy()
+        assert np.array_equal(got, orc.ball_query(new_xyz, xyz, r0, ns0))
+        return
+    i0, i1 = ext.ball_query_pair(T(new_xyz, dev), T(xyz, dev), r0, ns0, r1, ns1)
+    assert np.array_equal(i0.cpu().numpy(), orc.ball_query(new_xyz, xyz, r0, ns0))
+    assert np.array_equal(i1.cpu().numpy(), orc.ball_query(new_xyz, xyz, r1, ns1))
