@@ -137,13 +137,19 @@ int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xy
  * has converged (the call then blocks on events every `poll_every` iterations, like the
  * reference's per-iteration host test, meanshift_pytorch.py:42); with poll_host == NULL the
  * call is fully asynchronous and enqueues all max_iter+1 iterations (finished fits exit at
- * block start). */
+ * block start).
+ * flags: PVN3D_MS_ALIGNED32 -- the caller guarantees seg_off[s] % 32 == 0 and that rows
+ * [seg_off[s], seg_off[s] + roundup32(seg_cnt[s])) belong to segment s (pvn3d_vote_compact's
+ * layout does).  PVN3D_MS_USE_MFMA (needs ALIGNED32) selects the experimental MFMA-assisted
+ * iteration kernel instead of the default pure-VALU one (same results within 1e-4). */
+#define PVN3D_MS_ALIGNED32 1
+#define PVN3D_MS_USE_MFMA 4
 size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
 int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,
                               int n_seg, int total, int max_cnt_host, float bandwidth,
                               int max_iter, float* ctr, uint8_t* labels, int* iters,
                               void* workspace, size_t workspace_bytes, int* poll_host,
-                              int poll_every, void* stream);
+                              int poll_every, int flags, void* stream);
 
 /* Vote assembly + order-preserving mask compaction
  * (cal_frame_poses_lm, pvn3d/lib/utils/pvn3d_eval_utils.py:160-175; cal_frame_poses :41-42,83,91-92).

@@ -7,6 +7,7 @@ Everything stays on the GPU: vote assembly and mask compaction (pvn3d_vote_compa
 (pvn3d_meanshift_fit_batch), and the Kabsch fit (pvn3d_best_fit_transform).  The only host
 synchronisation is the optional convergence poll and the final read-back of the poses.
 """
+import os
 import threading
 
 import numpy as np
@@ -31,14 +32,23 @@ def _poll_buf():
     return b
 
 
+MS_ALIGNED32 = 1    # include/pvn3d_hip.h PVN3D_MS_ALIGNED32
+MS_USE_MFMA = 4     # PVN3D_MS_USE_MFMA (experimental kernel, opt-in)
+
+
 def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300, labels=None,
-                        poll_every=8):
+                        poll_every=8, aligned32=False):
     """Batched MeanShiftTorch.fit.
 
     pts4 (total,4) float32 cuda; seg_off/seg_cnt (n_seg) int32 cuda; max_cnt: host bound on
     seg_cnt.  Returns ctr (n_seg,3) float32, labels (total) uint8, iters (n_seg) int32.
     poll_every = 0 -> fully asynchronous (enqueues max_iter+1 iterations).
+    aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows
+    (layout promise needed by the opt-in MFMA-assisted kernel, env PVN3D_MS_MFMA=1).
     """
+    flags = MS_ALIGNED32 if aligned32 else 0
+    if aligned32 and os.environ.get("PVN3D_MS_MFMA", "0") == "1":
+        flags |= MS_USE_MFMA
     dev = pts4.device
     assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
     n_seg = int(seg_off.numel())
@@ -57,7 +67,7 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
             pts4.data_ptr(), seg_off.data_ptr(), seg_cnt.data_ptr(), n_seg, total, int(max_cnt),
             float(bandwidth), int(max_iter), ctr.data_ptr(), labels.data_ptr(), iters.data_ptr(),
             ws.data_ptr(), ws_bytes, poll.data_ptr() if poll is not None else None,
-            int(poll_every), _stream(dev)), "meanshift_fit_batch")
+            int(poll_every), int(flags), _stream(dev)), "meanshift_fit_batch")
     return ctr, labels, iters
 
 
@@ -124,7 +134,7 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         votes, seg_off, seg_cnt = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame,
                                                inst_cls, 0, K + 1)
         ctr, _, iters = meanshift_fit_batch(votes, seg_off, seg_cnt, N, radius, max_iter,
-                                            poll_every=poll_every)
+                                            poll_every=poll_every, aligned32=(N % 32 == 0))
     else:
         out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
         votes, seg_off, seg_cnt = out
@@ -132,14 +142,14 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         sc = seg_cnt.view(F, K + 1)
         c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(),
                                                     sc[:, K].contiguous(), N, radius, max_iter,
-                                                    poll_every=poll_every)
+                                                    poll_every=poll_every, aligned32=(N % 32 == 0))
         # keypoint votes filtered by the centre fit's inlier labels (rows of segment K)
         sel = labels[K * N:]
         vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
                      sel_inst_stride=(K + 1) * N, out=out)
         c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
                                              sc[:, :K].contiguous().view(-1), N, radius, max_iter,
-                                             poll_every=poll_every)
+                                             poll_every=poll_every, aligned32=(N % 32 == 0))
         ctr = torch.cat([c_kp.view(F, K, 3), c_ctr.view(F, 1, 3)], 1).view(-1, 3)
         iters = torch.cat([it_kp.view(F, K), it_ctr.view(F, 1)], 1).view(-1)
     cls_kps = ctr.view(F, K + 1, 3)
@@ -194,7 +204,8 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
         so = seg_off.view(n_inst, K + 1)
         sc = seg_cnt.view(n_inst, K + 1)
         c0, _, _ = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
-                                       radius, max_iter, poll_every=poll_every)
+                                       radius, max_iter, poll_every=poll_every,
+                                       aligned32=(N % 32 == 0))
         pred_ctr = pcld - ctr_of[:, 0]
         thr = torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)).to(dev)
         mask = relabel_by_centre(mask, pred_ctr, c0.view(F, C, 3), present, thr).contiguous()
@@ -205,13 +216,14 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     so = seg_off.view(n_inst, K + 1)
     sc = seg_cnt.view(n_inst, K + 1)
     c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(),
-                                                N, radius, max_iter, poll_every=poll_every)
+                                                N, radius, max_iter, poll_every=poll_every,
+                                                aligned32=(N % 32 == 0))
     sel = labels[K * N:] if use_ctr_clus_flter else None
     vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
                  sel_inst_stride=(K + 1) * N, out=out)
     c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
                                          sc[:, :K].contiguous().view(-1), N, radius, max_iter,
-                                         poll_every=poll_every)
+                                         poll_every=poll_every, aligned32=(N % 32 == 0))
     cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
     iters = torch.cat([it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)], 1)
     npts = K + 1 if use_ctr else K

@@ -28,7 +28,7 @@ class MeanShiftTorch(object):
         if not A.is_cuda:
             raise RuntimeError("CPU not supported")  # same contract as the native ops
         n = A.size(0)
-        pts4 = torch.zeros((max(n, 1), 4), dtype=torch.float32, device=A.device)
+        pts4 = torch.zeros((max((n + 31) // 32 * 32, 32), 4), dtype=torch.float32, device=A.device)
         if n:
             pts4[:n, :3] = A
         return pts4
@@ -41,7 +41,8 @@ class MeanShiftTorch(object):
         seg_off = torch.zeros(1, dtype=torch.int32, device=A.device)
         seg_cnt = torch.full((1,), N, dtype=torch.int32, device=A.device)
         ctr, labels, iters = _eng.meanshift_fit_batch(pts4, seg_off, seg_cnt, max(N, 1),
-                                                      self.bandwidth, self.max_iter)
+                                                      self.bandwidth, self.max_iter,
+                                                      aligned32=True)
         self.last_iters = iters
         return ctr[0].to(A.dtype), labels[:N].bool()
 
@@ -49,16 +50,18 @@ class MeanShiftTorch(object):
         """List of (n_i,3) tensors -> (centres (S,3), list of bool label tensors)."""
         dev = A_list[0].device
         cnts = [int(a.size(0)) for a in A_list]
-        offs = [0]
+        offs = [0]                      # every segment starts on a multiple of 32 rows
         for n in cnts[:-1]:
-            offs.append(offs[-1] + n)
-        total = max(sum(cnts), 1)
+            offs.append(offs[-1] + (n + 31) // 32 * 32)
+        total = max(offs[-1] + (cnts[-1] + 31) // 32 * 32, 32)
         pts4 = torch.zeros((total, 4), dtype=torch.float32, device=dev)
-        if sum(cnts):
-            pts4[:sum(cnts), :3] = torch.cat([a.detach().float() for a in A_list], 0)
+        for o, a in zip(offs, A_list):
+            if a.size(0):
+                pts4[o:o + a.size(0), :3] = a.detach().float()
         seg_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         seg_cnt = torch.tensor(cnts, dtype=torch.int32, device=dev)
         ctr, labels, iters = _eng.meanshift_fit_batch(pts4, seg_off, seg_cnt, max(max(cnts), 1),
-                                                      self.bandwidth, self.max_iter)
+                                                      self.bandwidth, self.max_iter,
+                                                      aligned32=True)
         self.last_iters = iters
         return ctr, [labels[o:o + n].bool() for o, n in zip(offs, cnts)]

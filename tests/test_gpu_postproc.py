@@ -186,3 +186,20 @@ def test_batch_of_frames_equals_per_frame_and_threadpool(dev):
     out = te.eval_pose_parallel(st("pcld"), None, st("mask"), st("ctr_of"), None, None, 0, None, None,
                                 st("pred_kp_of"), use_ctr_clus_flter=False, use_ctr=True, ds_type="linemod", obj_id=1)
     assert len(out) == 4 and np.array_equal(out[2][0], poses_b[2])
+
+
+def test_mfma_assisted_kernel_matches_valu_and_is_deterministic(dev, monkeypatch):
+    """Opt-in MFMA-assisted iteration kernel (PVN3D_MS_MFMA=1): same centres within tolerance as
+    the default VALU kernel, bit-identical across repeated batched runs."""
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    fr = [synth.synth_frame(frame=30 + i, n_pts=2048, n_obj=400 + 100 * i) for i in range(4)]
+    st = lambda k: torch.stack([T(f[k], dev) for f in fr], 0)
+    args = (st("pcld"), st("mask"), st("ctr_of"), st("pred_kp_of"), True, 2, False, 1)
+    base = ev.cal_batch_poses_lm(*args)
+    monkeypatch.setenv("PVN3D_MS_MFMA", "1")
+    a = ev.cal_batch_poses_lm(*args)
+    b = ev.cal_batch_poses_lm(*args)
+    assert torch.equal(a["cls_kps"], b["cls_kps"]) and torch.equal(a["iters"], b["iters"])
+    assert (a["cls_kps"] - base["cls_kps"]).abs().max().item() < TOL
+    assert (a["iters"] - base["iters"]).abs().max().item() <= 1
+    assert (a["poses"] - base["poses"]).abs().max().item() < TOL
