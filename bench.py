@@ -324,6 +324,19 @@ def main():
                                                   unit="TFLOP/s", frac=tfl / PEAK_FP32_VALU_TFLOPS, traffic=None,
                                                   ms_per_step=per_step["vote_cluster_pose"],
                                                   algorithmic_flops_per_step=flops)
+        # HBM traffic from the PMC passes of tools/pmc_traffic.py (same command, separate run)
+        try:
+            with open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("frames_per_step") == F and args.n_pts == 12288:
+                sb = pmc["stage_bytes_per_step"]
+                for name in rooflines:
+                    parts = name.split("+")
+                    if all(p in sb for p in parts):
+                        rooflines[name]["traffic"] = sum(sb[p]["total_bytes"] for p in parts)
+                        rooflines[name]["traffic_source"] = "profiles/%s_pmc_traffic.json" % pmc.get("tag")
+        except (OSError, ValueError, KeyError):
+            pass
         dominant = max(per_step, key=per_step.get) if per_step else None
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
@@ -338,6 +351,7 @@ def main():
             "stage_ms_per_step": per_step,
             "dominant_stage": dominant,
             "roofline": rooflines.get(dominant if dominant in rooflines else "ball_query+group"),
+            "roofline_hbm": rooflines.get("ball_query+group"),
             "rooflines": rooflines,
             "meanshift_iters": {"min": int(iters.min()), "max": int(iters.max()), "mean": float(iters.mean())},
             "pose_err_vs_ground_truth": pose_err,

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""HBM traffic per bench step from rocprofv3 PMC counters (MI355X_MICROARCH.md, HBM section):
+two separate passes (FETCH_SIZE, WRITE_SIZE; KB units), FETCH_SIZE doubled (gfx950 reports half
+of a wide coalesced read -- calibrated here on a 1 GiB hipMemcpy D2D: WRITE_SIZE = 1048576 KB
+exactly, FETCH_SIZE = 524300 KB).  Runs `bench.py --serial` under the profiler and writes
+profiles/<tag>_pmc_traffic.json (+ profiles/latest_pmc_traffic.json, read by bench.py to fill
+roofline.traffic).  Usage on the GPU box:  python tools/pmc_traffic.py r01"""
+import collections
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+STAGE_OF = [("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
+            ("ball_query", "ball_query"), ("grid_build", "ball_query"), ("three_nn", "three_nn"),
+            ("fps_", "fps"), ("gather_points", "gather"), ("ms_", "vote_cluster_pose"),
+            ("vote_compact", "vote_cluster_pose"), ("best_fit", "vote_cluster_pose")]
+WARMUP, STEPS = 3, 2
+
+
+def run_pass(counter, outdir):
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "p", "--output-format", "csv", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--serial", "--steps", str(STEPS), "--warmup", str(WARMUP),
+           "--no-cpu-baseline", "--no-stage-events"]
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
+    per_kernel = collections.defaultdict(float)
+    with open(os.path.join(outdir, "p_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            per_kernel[r["Kernel_Name"]] += float(r["Counter_Value"]) * 1024.0
+    return per_kernel
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+    out = os.path.join(ROOT, "gpurun_out", "pmc_%s" % tag)
+    fetch = run_pass("FETCH_SIZE", out + "_fetch")
+    write = run_pass("WRITE_SIZE", out + "_write")
+    n_steps = WARMUP + STEPS
+    stages = collections.defaultdict(lambda: dict(read_bytes=0.0, write_bytes=0.0))
+    kernels = {}
+    for name in set(fetch) | set(write):
+        rd = 2.0 * fetch.get(name, 0.0) / n_steps      # gfx950 FETCH_SIZE correction
+        wr = write.get(name, 0.0) / n_steps
+        kernels[name[:80]] = dict(read_bytes_per_step=rd, write_bytes_per_step=wr)
+        for key, st in STAGE_OF:
+            if key in name:
+                stages[st]["read_bytes"] += rd
+                stages[st]["write_bytes"] += wr
+                break
+    res = dict(tag=tag, command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --serial "
+               "--steps %d --warmup %d --no-cpu-baseline --no-stage-events" % (STEPS, WARMUP),
+               frames_per_step=64, correction="FETCH_SIZE x2 (gfx950), KB->bytes x1024, totals / %d steps" % n_steps,
+               stage_bytes_per_step={k: dict(v, total_bytes=v["read_bytes"] + v["write_bytes"]) for k, v in stages.items()},
+               kernels=kernels)
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    for fn in ("%s_pmc_traffic.json" % tag, "latest_pmc_traffic.json"):
+        with open(os.path.join(ROOT, "profiles", fn), "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "%s_pmc_traffic.json" % tag), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(json.dumps(res["stage_bytes_per_step"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
