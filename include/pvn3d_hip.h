@@ -122,6 +122,31 @@ int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xy
                              const float* xyz, const float* new_xyz, const float* features,
                              const int* idx, float* out, void* stream);
 
+/* Fused set abstraction for inference: gather (QueryAndGroup, pointnet2_utils.py:311-321) ->
+ * SharedMLP = [1x1 conv -> BatchNorm (eval) -> ReLU] x n_layers (pytorch_utils.py:25-50) ->
+ * max over nsample (pointnet2_modules.py:63-66), on fp32 MFMA; the (b, 3+c, m, nsample)
+ * grouped tensor is never written.  out (b, dims[n_layers], m).
+ * dims_host: HOST int[n_layers+1], dims[0] = 3*use_xyz + c.  For layer l (K = dims[l],
+ * M = dims[l+1]) with BatchNorm folded in (W' = W*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)):
+ *   w_packed[l]   DEVICE float[ceil(K/2)][ceil(M/32)][64], entry (k2, mt, lane) =
+ *                 W'[mt*32 + (lane&31)][2*k2 + (lane>>5)]  (0 outside M x K)
+ *   bias_padded[l] DEVICE float[ceil(M/32)*32], zero padded.
+ * w_packed / bias_padded are HOST arrays of device pointers.  nsample: power of two <= 64;
+ * every dims[l] <= 512. */
+int pvn3d_sa_mlp_maxpool(int b, int n, int m, int c, int nsample, int use_xyz, const float* xyz,
+                         const float* new_xyz, const float* features, const int* idx,
+                         int n_layers, const int* dims_host, const float* const* w_packed,
+                         const float* const* bias_padded, float* out, void* stream);
+
+/* Fused feature propagation for inference (PointnetFPModule.forward,
+ * pointnet2_modules.py:183-206): three_interpolate(known_feats, idx, weight) ++ unknow_feats ->
+ * SharedMLP.  known_feats (b,c2,m), unknow_feats (b,c1,n) or NULL (c1 = 0), idx/weight (b,n,3)
+ * -> out (b, dims[n_layers], n); dims[0] = c2 + c1; weights as in pvn3d_sa_mlp_maxpool. */
+int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_feats,
+                        const float* unknow_feats, const int* idx, const float* weight,
+                        int n_layers, const int* dims_host, const float* const* w_packed,
+                        const float* const* bias_padded, float* out, void* stream);
+
 /* ========================= 3. vote -> MeanShift -> pose (post-proc) ===================== */
 
 /* Batched MeanShiftTorch.fit (pvn3d/lib/utils/meanshift_pytorch.py:18-51).

@@ -1,0 +1,354 @@
+// sa_mlp.hip -- fused "group -> SharedMLP -> max-pool" (set abstraction) and
+// "three_interpolate -> concat -> SharedMLP" (feature propagation) for gfx950, eval mode.
+//
+// Replaces, for inference, the data flow of _PointnetSAModuleBase.forward
+// (pvn3d/lib/pointnet2_utils/pointnet2_modules.py:57-69): QueryAndGroup's gather + concat
+// (pointnet2_utils.py:311-321), SharedMLP = [1x1 Conv2d -> BatchNorm2d -> ReLU] x L
+// (lib/utils/etw_pytorch_utils/pytorch_utils.py:25-50) and F.max_pool2d over nsample; and of
+// PointnetFPModule.forward (:183-206): three_interpolate, torch.cat, SharedMLP.
+// The grouped (B, 3+C, npoint, nsample) tensor -- 69 MB per frame, the HBM-bound piece of the
+// unfused path -- is never materialised: a workgroup gathers its 64 columns ((centre, sample)
+// pairs, or 64 unknown points) channel-chunk by channel-chunk into LDS and runs the whole MLP
+// chain on them.
+//
+// The contraction is the ONLY MFMA work of the hot path (north_star).  fp32 in / fp32 accumulate:
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the 157 TFLOP/s peak); the
+// reference computes these layers in fp32 (cuDNN), so no reduced-precision shortcut is taken.
+// BatchNorm (eval) is folded into the weights/bias on the host: W' = W * g/sqrt(var+eps),
+// b' = beta - mean * g/sqrt(var+eps).
+//
+// Workgroup = 4 waves, 64 columns.  Layer l: D[M_l x 64] = relu(W_l[M_l x K_l] . H_{l-1}[K_l x 64] + b_l)
+//   * A operand (weights): pre-packed on the host as [K/2][M/32][64 lanes] so that one
+//     32x32x2 fragment is one coalesced 256-byte load (lane l: W[mt*32 + (l&31)][2*k2 + (l>>5)]);
+//     weights are shared by every workgroup and stay L2-resident.
+//   * B operand (activations): LDS, H[k][64 cols] row-major -- a fragment read is two
+//     conflict-free 128-byte rows (lane l: H[2*k2 + (l>>5)][ct*32 + (l&31)]).
+//   * a wave owns row tiles mt = wave, wave+4, ... (<= 4) x 2 column tiles = <= 8 accumulator
+//     tiles (128 VGPRs); after a layer the tile (bias, ReLU) is written back to the same LDS
+//     buffer (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+//   * layer 0 reads its input in 32-channel chunks that the loader gathers into a
+//     double-buffered LDS chunk; later layers read the full previous activation from LDS.
+// Epilogue SA: max over the nsample columns of each centre (lanes), store (B, M, npoint).
+// Epilogue FP: store (B, M, n).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int SM_COLS = 64;
+constexpr int SM_KC = 32;            // input channels per layer-0 chunk
+constexpr int SM_MAX_LAYERS = 4;
+constexpr int SM_MAX_MT = 16;        // M <= 512
+
+struct MlpDesc {
+  int n_layers;
+  int K[SM_MAX_LAYERS];              // true input width of layer l
+  int M[SM_MAX_LAYERS];              // true output width
+  const float* W[SM_MAX_LAYERS];     // packed [ceil(K/2)][ceil(M/32)][64]
+  const float* bias[SM_MAX_LAYERS];  // [ceil(M/32)*32], zero padded
+};
+
+struct SaSrc {      // loader of the set-abstraction input: column = (centre j, sample s)
+  const float* xyz;       // (B, n, 3)
+  const float* new_xyz;   // (B, m, 3)
+  const float* feat;      // (B, C, n) or null
+  const int* idx;         // (B, m, ns)
+  int n, m, ns, C, use_xyz;
+};
+
+struct FpSrc {      // loader of the feature-propagation input: column = unknown point j
+  const float* known_feats;   // (B, C2, m)
+  const float* unknow_feats;  // (B, C1, n) or null
+  const int* idx;             // (B, n, 3)
+  const float* weight;        // (B, n, 3)
+  int n, m, C2, C1;
+};
+
+// ---- one layer on the matrix cores --------------------------------------------------------
+// acc tiles [t][ct]; Hin in LDS [K][64] (layer >= 1) or streamed in chunks (layer 0).
+template <int NT>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __restrict__ Wp,
+                                          int mt_total, int wave, int nt, int k2_begin,
+                                          int k2_end, const float* __restrict__ Hrows /*row 2*k2_begin*/,
+                                          int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  if (nt <= 0 || k2_begin >= k2_end) return;
+  const size_t kstride = (size_t)mt_total * 64;
+  const float* wp = Wp + ((size_t)k2_begin * mt_total + wave) * 64 + lane;
+  // the weight fragments of step k2+1 are fetched (L2) while step k2 runs on the matrix pipe
+  // (a deeper, two-step pipeline measured slower: 40.1 vs 36.0 ms for the whole network)
+  float a_nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * 256] : 0.f;
+  for (int k2 = k2_begin; k2 < k2_end; ++k2) {
+    float a_cur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    if (k2 + 1 < k2_end) {
+      wp += kstride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * 256] : 0.f;
+    }
+    const float* hr = Hrows + ((k2 - k2_begin) * 2 + half) * SM_COLS + col;
+    const float b0 = hr[0], b1 = hr[32];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b1, acc[t][1], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], const float* __restrict__ bias,
+                                          int wave, int nt, float* __restrict__ H, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
+      const int mt = wave + 4 * t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float bv = bias[row];
+        H[row * SM_COLS + col] = fmaxf(acc[t][0][r] + bv, 0.f);
+        H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r] + bv, 0.f);
+      }
+    }
+  }
+}
+
+// dynamic LDS: H [hrows][64] | chunk [2][32][64]
+template <bool IS_SA, int NT>
+__global__ __launch_bounds__(256) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
+                                                        int cols_total, float* __restrict__ out) {
+  extern __shared__ float s_mem[];
+  float* H = s_mem;
+  float* chunk = s_mem + (size_t)hrows * SM_COLS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.y;
+  const int col0 = blockIdx.x * SM_COLS;
+
+  // ---- per-thread loader state: this thread fills column lc, rows lr0 + 4*i of every chunk
+  const int lc = tid & 63, lr0 = tid >> 6;
+  const int gcol = col0 + lc;
+  const bool cvalid = gcol < cols_total;
+  int id0 = 0, id1 = 0, id2 = 0;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, cxv = 0.f, cyv = 0.f, czv = 0.f;
+  if (IS_SA) {
+    if (cvalid) {
+      id0 = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
+      const int j = gcol / sa.ns;
+      const float* c = sa.new_xyz + ((size_t)bi * sa.m + j) * 3;
+      cxv = c[0]; cyv = c[1]; czv = c[2];
+    }
+  } else {
+    if (cvalid) {
+      const int* ip = fp.idx + ((size_t)bi * fp.n + gcol) * 3;
+      const float* wp = fp.weight + ((size_t)bi * fp.n + gcol) * 3;
+      id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
+      w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
+    }
+  }
+  // plain local copies: capturing the by-value kernel-argument structs by reference would pin
+  // them in scratch memory and turn every field access of the loader into a scratch load
+  const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
+  const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
+  const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
+  const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
+  auto load_input = [=](int c) -> float {   // value of input channel c for this thread's column
+    if (!cvalid) return 0.f;
+    if (IS_SA) {
+      if (c < sa_c3) {
+        const float p = sa_xyz[((size_t)bi * sa_n + id0) * 3 + c];
+        return p - (c == 0 ? cxv : (c == 1 ? cyv : czv));   // grouped_xyz -= new_xyz
+      }
+      const int cf = c - sa_c3;
+      return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
+    } else {
+      if (c < fp_C2) {
+        const float* row = fp_kf + ((size_t)bi * fp_C2 + c) * fp_m;
+        return row[id0] * w0 + row[id1] * w1 + row[id2] * w2;   // three_interpolate, unfused order
+      }
+      const int cu = c - fp_C2;
+      return cu < fp_C1 ? fp_uf[((size_t)bi * fp_C1 + cu) * fp_n + gcol] : 0.f;
+    }
+  };
+
+  f32x16 acc[NT][2];
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int K = d.K[l], M = d.M[l];
+    const int mt_total = (M + 31) >> 5;
+    const int nt = (mt_total - wave + 3) >> 2;     // row tiles of this wave (<= NT)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
+    const int k2_total = (K + 1) >> 1;
+    if (l == 0) {
+      const int n_chunks = (K + SM_KC - 1) / SM_KC;
+      float stage[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stage[i] = load_input(lr0 + 4 * i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) chunk[(lr0 + 4 * i) * SM_COLS + lc] = stage[i];
+      __syncthreads();
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < n_chunks;
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) stage[i] = load_input((ch + 1) * SM_KC + lr0 + 4 * i);
+        }
+        const int k2b = ch * (SM_KC / 2);
+        const int k2e = min(k2b + SM_KC / 2, k2_total);
+        mma_chunk<NT>(acc, d.W[l], mt_total, wave, nt, k2b, k2e, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
+        if (more) {
+          float* cb = chunk + (size_t)(buf ^ 1) * SM_KC * SM_COLS;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cb[(lr0 + 4 * i) * SM_COLS + lc] = stage[i];
+        }
+        __syncthreads();
+      }
+    } else {
+      mma_chunk<NT>(acc, d.W[l], mt_total, wave, nt, 0, k2_total, H, lane);
+      __syncthreads();   // every wave has finished reading H_{l-1}
+    }
+    if (l + 1 < d.n_layers) {
+      store_act<NT>(acc, d.bias[l], wave, nt, H, lane);
+      // rows [M, roundup2(M)) of H must read as zero for the next layer's odd K
+      if ((M & 1) && tid < SM_COLS) H[M * SM_COLS + tid] = 0.f;
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue on the last layer's accumulators
+  const int L = d.n_layers - 1;
+  const int M = d.M[L];
+  const int mt_total = (M + 31) >> 5;
+  const int nt = (mt_total - wave + 3) >> 2;
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
+      const int mt = wave + 4 * t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float bv = d.bias[L][row];
+        float v0 = fmaxf(acc[t][0][r] + bv, 0.f), v1 = fmaxf(acc[t][1][r] + bv, 0.f);
+        if (IS_SA) {
+          // max over the nsample consecutive columns of each centre (ns = 16 or 32 here;
+          // columns beyond cols_total hold relu(bias) of zero inputs and are never stored)
+          const int ns = sa.ns;
+          for (int o = 1; o < ns && o < 32; o <<= 1) {
+            v0 = fmaxf(v0, __shfl_xor(v0, o, 64));
+            v1 = fmaxf(v1, __shfl_xor(v1, o, 64));
+          }
+          float v = v0;
+          int jcol = col;                               // column of tile 0
+          if (ns > 32) { v = fmaxf(v0, v1); }           // ns == 64: both tiles are one centre
+          if (row < M) {
+            if (ns >= 64) {
+              if (col == 0) {
+                const int j = col0 / ns;
+                if (j < sa.m) out[((size_t)bi * M + row) * sa.m + j] = v;
+              }
+            } else if ((col & (ns - 1)) == 0) {
+              const int j0 = (col0 + jcol) / ns, j1 = (col0 + 32 + jcol) / ns;
+              if (j0 < sa.m) out[((size_t)bi * M + row) * sa.m + j0] = v0;
+              if (j1 < sa.m) out[((size_t)bi * M + row) * sa.m + j1] = v1;
+            }
+          }
+        } else {
+          if (row < M) {
+            const int g0 = col0 + col, g1 = col0 + 32 + col;
+            if (g0 < cols_total) out[((size_t)bi * M + row) * fp.n + g0] = v0;
+            if (g1 < cols_total) out[((size_t)bi * M + row) * fp.n + g1] = v1;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool IS_SA>
+int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
+                 float* out, hipStream_t st) {
+  int hrows = 2, max_mt = 1;
+  for (int l = 0; l < d.n_layers; ++l) {
+    if (l + 1 < d.n_layers) hrows = max(hrows, ((d.M[l] + 31) / 32) * 32 + 2);
+    max_mt = max(max_mt, (d.M[l] + 31) / 32);
+  }
+  if (max_mt > SM_MAX_MT) return (int)hipErrorInvalidValue;
+  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS) * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
+#define SM_LAUNCH(NT)                                                                          \
+  do {                                                                                         \
+    auto kern = mlp_chain_kernel<IS_SA, NT>;                                                   \
+    if (lds > 48 * 1024)                                                                       \
+      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                              (int)lds));                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, sa, fp, hrows, cols_total, out);     \
+  } while (0)
+  const int nt = (max_mt + 3) / 4;
+  if (nt <= 1) SM_LAUNCH(1); else if (nt == 2) SM_LAUNCH(2); else if (nt == 3) SM_LAUNCH(3); else SM_LAUNCH(4);
+#undef SM_LAUNCH
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+bool fill_desc(MlpDesc* d, int n_layers, const int* dims, const float* const* W,
+               const float* const* bias) {
+  if (n_layers < 1 || n_layers > SM_MAX_LAYERS) return false;
+  d->n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    d->K[l] = dims[l];
+    d->M[l] = dims[l + 1];
+    d->W[l] = W[l];
+    d->bias[l] = bias[l];
+    if (dims[l] <= 0 || dims[l + 1] <= 0 || !W[l] || !bias[l]) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int pvn3d_sa_mlp_maxpool(int b, int n, int m, int c, int nsample, int use_xyz,
+                                    const float* xyz, const float* new_xyz,
+                                    const float* features, const int* idx, int n_layers,
+                                    const int* dims_host, const float* const* w_packed,
+                                    const float* const* bias_padded, float* out, void* stream) {
+  if (b <= 0 || m <= 0) return 0;
+  if (nsample <= 0 || (nsample & (nsample - 1)) || nsample > 64 || !xyz || !new_xyz || !idx ||
+      !out || !dims_host || !w_packed || !bias_padded)
+    return (int)hipErrorInvalidValue;
+  MlpDesc d;
+  if (!fill_desc(&d, n_layers, dims_host, w_packed, bias_padded)) return (int)hipErrorInvalidValue;
+  if (dims_host[0] != (use_xyz ? 3 : 0) + (features ? c : 0)) return (int)hipErrorInvalidValue;
+  SaSrc sa = {xyz, new_xyz, features, idx, n, m, nsample, features ? c : 0, use_xyz};
+  FpSrc fp = {};
+  return launch_chain<true>(d, sa, fp, b, m * nsample, out, (hipStream_t)stream);
+}
+
+extern "C" int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_feats,
+                                   const float* unknow_feats, const int* idx,
+                                   const float* weight, int n_layers, const int* dims_host,
+                                   const float* const* w_packed, const float* const* bias_padded,
+                                   float* out, void* stream) {
+  if (b <= 0 || n <= 0) return 0;
+  if (!known_feats || !idx || !weight || !out || !dims_host || !w_packed || !bias_padded ||
+      (c1 > 0 && !unknow_feats))
+    return (int)hipErrorInvalidValue;
+  MlpDesc d;
+  if (!fill_desc(&d, n_layers, dims_host, w_packed, bias_padded)) return (int)hipErrorInvalidValue;
+  if (dims_host[0] != c2 + c1) return (int)hipErrorInvalidValue;
+  SaSrc sa = {};
+  FpSrc fp = {known_feats, unknow_feats, idx, weight, n, m, c2, c1};
+  return launch_chain<false>(d, sa, fp, b, n, out, (hipStream_t)stream);
+}

@@ -1,0 +1,53 @@
+"""Pointnet2MSG -- the PointNet++ branch of PVN3D with the reference's hyper-parameters and
+module tree (pvn3d/lib/pvn3d.py:46-154: 4 multi-scale set-abstraction levels, 4 feature
+propagation levels), built from this package's SA/FP modules.  Only this class of
+lib/pvn3d.py is on the hot path; the CNN, DenseFusion and heads are out of scope."""
+import torch.nn as nn
+
+from .pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPModule
+
+
+class Pointnet2MSG(nn.Module):
+    def __init__(self, input_channels=6, use_xyz=True):
+        super(Pointnet2MSG, self).__init__()
+        self.SA_modules = nn.ModuleList()
+        c_in = input_channels
+        self.SA_modules.append(PointnetSAModuleMSG(
+            npoint=2048, radii=[0.0175, 0.025], nsamples=[16, 32],
+            mlps=[[c_in, 16, 16, 32], [c_in, 32, 32, 64]], use_xyz=use_xyz))
+        c_out_0 = 32 + 64
+        self.SA_modules.append(PointnetSAModuleMSG(
+            npoint=1024, radii=[0.025, 0.05], nsamples=[16, 32],
+            mlps=[[c_out_0, 64, 64, 128], [c_out_0, 64, 96, 128]], use_xyz=use_xyz))
+        c_out_1 = 128 + 128
+        self.SA_modules.append(PointnetSAModuleMSG(
+            npoint=512, radii=[0.05, 0.1], nsamples=[16, 32],
+            mlps=[[c_out_1, 128, 196, 256], [c_out_1, 128, 196, 256]], use_xyz=use_xyz))
+        c_out_2 = 256 + 256
+        self.SA_modules.append(PointnetSAModuleMSG(
+            npoint=128, radii=[0.1, 0.2], nsamples=[16, 32],
+            mlps=[[c_out_2, 256, 256, 512], [c_out_2, 256, 384, 512]], use_xyz=use_xyz))
+        c_out_3 = 512 + 512
+        self.FP_modules = nn.ModuleList()
+        self.FP_modules.append(PointnetFPModule(mlp=[256 + input_channels, 128, 128]))
+        self.FP_modules.append(PointnetFPModule(mlp=[512 + c_out_0, 256, 256]))
+        self.FP_modules.append(PointnetFPModule(mlp=[512 + c_out_1, 512, 512]))
+        self.FP_modules.append(PointnetFPModule(mlp=[c_out_3 + c_out_2, 512, 512]))
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud):
+        """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N)."""
+        xyz, features = self._break_up_pc(pointcloud)
+        l_xyz, l_features = [xyz], [features]
+        for sa in self.SA_modules:
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+            l_xyz.append(li_xyz)
+            l_features.append(li_features)
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+        return l_features[0]

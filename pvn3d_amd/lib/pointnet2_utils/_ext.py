@@ -246,3 +246,53 @@ def group_xyz_features(xyz, new_xyz, features, idx, use_xyz=True):
                                            idx.data_ptr(), out.data_ptr(), _stream(xyz)),
               "group_xyz_features")
     return out
+
+
+def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed):
+    """Fused group -> SharedMLP (BN folded, fp32 MFMA) -> max over nsample, inference only.
+    packed: _fused_mlp.PackedMLP.  Returns (B, packed.dims[-1], npoint)."""
+    _chk(xyz, "xyz", torch.float32)
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _same_dev(xyz, new_xyz, "new_xyz")
+    _same_dev(xyz, idx, "idx")
+    C = 0
+    if features is not None:
+        _chk(features, "features", torch.float32)
+        _same_dev(xyz, features, "features")
+        C = features.size(1)
+    B, N = xyz.size(0), xyz.size(1)
+    m, nsample = idx.size(1), idx.size(2)
+    out = torch.empty((B, packed.dims[-1], m), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        check(lib.pvn3d_sa_mlp_maxpool(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
+                                       new_xyz.data_ptr(),
+                                       features.data_ptr() if features is not None else None,
+                                       idx.data_ptr(), packed.n_layers, packed.dims_c, packed.w_c,
+                                       packed.b_c, out.data_ptr(), _stream(xyz)), "sa_mlp_maxpool")
+    return out
+
+
+def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed):
+    """Fused three_interpolate ++ unknow_feats -> SharedMLP (BN folded, fp32 MFMA), inference
+    only.  Returns (B, packed.dims[-1], n)."""
+    _chk(known_feats, "known_feats", torch.float32)
+    _chk(idx, "idx", torch.int32)
+    _chk(weight, "weight", torch.float32)
+    _same_dev(known_feats, idx, "idx")
+    _same_dev(known_feats, weight, "weight")
+    C1 = 0
+    if unknow_feats is not None:
+        _chk(unknow_feats, "unknow_feats", torch.float32)
+        _same_dev(known_feats, unknow_feats, "unknow_feats")
+        C1 = unknow_feats.size(1)
+    B, C2, m = known_feats.shape
+    n = idx.size(1)
+    out = torch.empty((B, packed.dims[-1], n), dtype=torch.float32, device=known_feats.device)
+    with torch.cuda.device(known_feats.device):
+        check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, known_feats.data_ptr(),
+                                      unknow_feats.data_ptr() if unknow_feats is not None else None,
+                                      idx.data_ptr(), weight.data_ptr(), packed.n_layers,
+                                      packed.dims_c, packed.w_c, packed.b_c, out.data_ptr(),
+                                      _stream(known_feats)), "fp_interp_mlp")
+    return out

@@ -1,0 +1,97 @@
+"""Host side of the fused set-abstraction / feature-propagation kernels (csrc/sa_mlp.hip):
+BatchNorm folding and weight packing for a SharedMLP
+(pvn3d/lib/utils/etw_pytorch_utils/pytorch_utils.py:25-50), cached per module.
+
+A layer is eligible when it is exactly [1x1 Conv2d] -> [BatchNorm2d in eval mode]? -> ReLU
+(the only form PVN3D's Pointnet2MSG builds).  Anything else makes ``pack_shared_mlp`` return
+None and the caller keeps the unfused torch path.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+
+class PackedMLP(object):
+    """Device buffers + the host pointer arrays pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp take."""
+
+    def __init__(self, dims, w_list, b_list):
+        self.dims = list(dims)
+        self.n_layers = len(w_list)
+        self.w = w_list            # keep the tensors alive
+        self.b = b_list
+        self.dims_c = (ctypes.c_int * len(dims))(*dims)
+        self.w_c = (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in w_list])
+        self.b_c = (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in b_list])
+
+
+def _pack_weight(W):
+    """W (M,K) float32 -> [ceil(K/2)][ceil(M/32)][64]: entry (k2, mt, lane) =
+    W[mt*32 + (lane & 31)][2*k2 + (lane >> 5)], zero outside."""
+    M, K = W.shape
+    MT, K2 = (M + 31) // 32, (K + 1) // 2
+    Wp = torch.zeros((MT * 32, K2 * 2), dtype=torch.float32, device=W.device)
+    Wp[:M, :K] = W
+    return Wp.view(MT, 32, K2, 2).permute(2, 0, 3, 1).contiguous().view(K2, MT, 64)
+
+
+def _fold(layer):
+    """One SharedMLP layer (nn.Sequential of conv / normlayer / activation) -> (W', b') or None."""
+    conv = getattr(layer, "conv", None)
+    if not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1) or conv.stride != (1, 1) \
+            or conv.padding != (0, 0) or conv.groups != 1:
+        return None
+    names = [n for n, _ in layer.named_children()]
+    if names and names[0] != "conv":          # pre-activation layout: not handled
+        return None
+    act = getattr(layer, "activation", None)
+    if not isinstance(act, nn.ReLU):
+        return None
+    W = conv.weight.detach().float().view(conv.out_channels, conv.in_channels)
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=W.device)
+    norm = getattr(layer, "normlayer", None)
+    if norm is not None:
+        bn = getattr(norm, "bn", None)
+        if not isinstance(bn, nn.BatchNorm2d) or bn.training or not bn.track_running_stats:
+            return None
+        g = bn.weight.detach().float() if bn.affine else torch.ones_like(bn.running_var)
+        beta = bn.bias.detach().float() if bn.affine else torch.zeros_like(bn.running_var)
+        s = g / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        W = W * s[:, None]
+        b = (b - bn.running_mean.detach().float()) * s + beta
+    return W, b
+
+
+def pack_shared_mlp(mlp, max_width=512):
+    """SharedMLP -> PackedMLP (cached on the module until a parameter/buffer changes), or None."""
+    sig = []
+    for t in list(mlp.parameters()) + list(mlp.buffers()):
+        sig.append((t.data_ptr(), t._version))
+    sig = (tuple(sig), mlp.training)
+    cache = getattr(mlp, "_pvn3d_packed", None)
+    if cache is not None and cache[0] == sig:
+        return cache[1]
+    folded = []
+    for layer in mlp.children():
+        f = _fold(layer)
+        if f is None:
+            mlp._pvn3d_packed = (sig, None)
+            return None
+        folded.append(f)
+    if not folded or len(folded) > 4:
+        mlp._pvn3d_packed = (sig, None)
+        return None
+    dims = [folded[0][0].shape[1]] + [W.shape[0] for W, _ in folded]
+    if max(dims[1:]) > max_width or any(folded[i][0].shape[1] != dims[i] for i in range(len(folded))):
+        mlp._pvn3d_packed = (sig, None)
+        return None
+    w_list, b_list = [], []
+    for W, b in folded:
+        w_list.append(_pack_weight(W))
+        M = W.shape[0]
+        bp = torch.zeros(((M + 31) // 32) * 32, dtype=torch.float32, device=W.device)
+        bp[:M] = b
+        b_list.append(bp)
+    packed = PackedMLP(dims, w_list, b_list)
+    mlp._pvn3d_packed = (sig, packed)
+    return packed

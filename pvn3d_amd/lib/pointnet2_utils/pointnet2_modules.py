@@ -14,8 +14,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _ext
+from . import _fused_mlp
 from . import pointnet2_utils
 from ..utils import pytorch_utils as pt_utils
+
+# Inference fast path: gather -> SharedMLP -> max-pool (and interpolate -> SharedMLP) as one
+# fp32-MFMA kernel each (csrc/sa_mlp.hip).  Used when the module is in eval mode and autograd
+# is not recording; set to False to force the reference's op-by-op composition.
+FUSED_INFERENCE = True
+
+
+def _no_grad_needed(*tensors):
+    if not torch.is_grad_enabled():
+        return True
+    return not any(t is not None and t.requires_grad for t in tensors)
+
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -46,7 +59,18 @@ class _PointnetSAModuleBase(nn.Module):
             idxs = [None] * len(self.groupers)
 
         pooled = []
+        fuse = (FUSED_INFERENCE and not self.training and self.npoint is not None and xyz.is_cuda
+                and _no_grad_needed(xyz, features)
+                and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters()))
         for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
+            if fuse and isinstance(grouper, pointnet2_utils.QueryAndGroup):
+                ns = grouper.nsample
+                packed = _fused_mlp.pack_shared_mlp(mlp) if (ns & (ns - 1)) == 0 and ns <= 64 else None
+                if packed is not None:
+                    if idx is None:
+                        idx = pointnet2_utils.ball_query(grouper.radius, ns, xyz, new_xyz)
+                    pooled.append(_ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed))
+                    continue
             if idx is not None:
                 grouped = grouper(xyz, new_xyz, features, idx=idx)
             else:
@@ -100,6 +124,13 @@ class PointnetFPModule(nn.Module):
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+            if (FUSED_INFERENCE and not self.training and known_feats.is_cuda
+                    and _no_grad_needed(unknow_feats, known_feats)
+                    and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters())):
+                packed = _fused_mlp.pack_shared_mlp(self.mlp)
+                if packed is not None:
+                    uf = unknow_feats.contiguous() if unknow_feats is not None else None
+                    return _ext.fp_interp_mlp(known_feats.contiguous(), uf, idx, weight.contiguous(), packed)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))

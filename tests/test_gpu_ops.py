@@ -246,3 +246,81 @@ def test_ball_query_grid_path_index_exact(ext, orc, dev, case):
     i0, i1 = ext.ball_query_pair(T(new_xyz, dev), T(xyz, dev), r0, ns0, r1, ns1)
     assert np.array_equal(i0.cpu().numpy(), orc.ball_query(new_xyz, xyz, r0, ns0))
     assert np.array_equal(i1.cpu().numpy(), orc.ball_query(new_xyz, xyz, r1, ns1))
+
+
+def _randomize_bn(module):
+    g = torch.Generator().manual_seed(5)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+@pytest.mark.parametrize("c_in,mlps,nsamples,npoint,n", [
+    (6, [[6, 16, 16, 32], [6, 32, 32, 64]], [16, 32], 256, 1500),
+    (96, [[96, 64, 64, 128], [96, 64, 96, 128]], [16, 32], 200, 700),
+    (256, [[256, 128, 196, 256]], [32], 96, 400),
+    (7, [[7, 33, 70]], [8], 50, 300),
+])
+def test_fused_sa_mlp_matches_unfused_modules(dev, c_in, mlps, nsamples, npoint, n):
+    """gather -> SharedMLP(BN eval) -> max-pool on fp32 MFMA == the op-by-op torch composition
+    (fp32, summation order differs): 1e-4 of the output scale."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    torch.manual_seed(1)
+    radii = [0.05, 0.1][:len(nsamples)]
+    sa = pm.PointnetSAModuleMSG(npoint=npoint, radii=radii, nsamples=nsamples,
+                                mlps=[list(x) for x in mlps]).to(dev).eval()
+    _randomize_bn(sa)
+    xyz = T(clouds(3, 2, n, 0.1), dev)
+    feats = torch.randn(2, c_in, n, device=dev)
+    with torch.no_grad():
+        pm.FUSED_INFERENCE = True
+        new_xyz_f, out_f = sa(xyz, feats)
+        pm.FUSED_INFERENCE = False
+        try:
+            new_xyz_u, out_u = sa(xyz, feats)
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert torch.equal(new_xyz_f, new_xyz_u)
+    scale = out_u.abs().max().item()
+    assert (out_f - out_u).abs().max().item() < 1e-4 * max(scale, 1.0)
+    assert getattr(sa.mlps[0], "_pvn3d_packed")[1] is not None      # the fused path really ran
+
+
+def test_fused_fp_mlp_and_full_pointnet2msg(dev):
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    torch.manual_seed(2)
+    fp = pm.PointnetFPModule(mlp=[64 + 10, 48, 40]).to(dev).eval()
+    _randomize_bn(fp)
+    unknown = T(clouds(8, 2, 900, 0.1), dev)
+    known = unknown[:, :250].contiguous()
+    uf, kf = torch.randn(2, 10, 900, device=dev), torch.randn(2, 64, 250, device=dev)
+    with torch.no_grad():
+        a = fp(unknown, known, uf, kf)
+        pm.FUSED_INFERENCE = False
+        try:
+            b = fp(unknown, known, uf, kf)
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert a.shape == (2, 40, 900)
+    assert (a - b).abs().max().item() < 1e-4 * max(b.abs().max().item(), 1.0)
+    # whole PointNet++ branch at a reduced size (same widths as lib/pvn3d.py:65-118)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    _randomize_bn(net)
+    pc = torch.cat([T(clouds(9, 1, 12288, 0.05), dev), torch.randn(1, 12288, 6, device=dev)], 2)
+    with torch.no_grad():
+        y = net(pc)
+        pm.FUSED_INFERENCE = False
+        try:
+            y_ref = net(pc)
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert y.shape == (1, 128, 12288)
+    assert (y - y_ref).abs().max().item() < 2e-4 * max(y_ref.abs().max().item(), 1.0)
+    # training mode / autograd keeps the unfused differentiable path
+    net.train()
+    out = net(pc[:, :2048].clone().requires_grad_(False))
+    assert out.requires_grad

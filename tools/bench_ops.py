@@ -95,6 +95,20 @@ def main():
             mn, _ = timeit(lambda: ev.cal_batch_poses_lm(inp["pcld"], inp["mask"], inp["ctr_of"], inp["pred_kp_of"], True, 2, False, 1, poll_every=poll), args.reps)
             print("vote+cluster+pose F=%d n_obj=%d poll=%d  %8.1f us" % (F, args.n_obj, poll, mn * 1e3))
         tot["ms"] = mn
+    if "msg" in ops:
+        from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+        from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+        net = Pointnet2MSG(input_channels=6).to(dev).eval()
+        pc = torch.cat([inp["pcld"], inp["feats"].transpose(1, 2)], 2).contiguous()
+        with torch.no_grad():
+            mn, _ = timeit(lambda: net(pc), args.reps)
+            print("Pointnet2MSG fused   F=%d  %8.1f us  (%.1f us/frame)" % (F, mn * 1e3, mn * 1e3 / F))
+            pm.FUSED_INFERENCE = False
+            sub = pc[: min(F, 16)].contiguous()
+            mn2, _ = timeit(lambda: net(sub), args.reps)
+            pm.FUSED_INFERENCE = True
+            print("Pointnet2MSG unfused F=%d  %8.1f us  (%.1f us/frame)" % (sub.size(0), mn2 * 1e3, mn2 * 1e3 / sub.size(0)))
+        tot["msg"] = mn
     print("totals (ms):", {k: round(v, 3) for k, v in tot.items()})
 
 
