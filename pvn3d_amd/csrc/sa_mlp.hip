@@ -67,7 +67,7 @@ struct FpSrc {      // loader of the feature-propagation input: column = unknown
 
 // ---- one layer on the matrix cores --------------------------------------------------------
 // acc tiles [t][ct]; Hin in LDS [K][64] (layer >= 1) or streamed in chunks (layer 0).
-template <int NT>
+template <int NT, int NW>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __restrict__ Wp,
                                           int mt_total, int wave, int nt, int k2_begin,
                                           int k2_end, const float* __restrict__ Hrows /*row 2*k2_begin*/,
@@ -80,7 +80,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __r
   // (a deeper, two-step pipeline measured slower: 40.1 vs 36.0 ms for the whole network)
   float a_nxt[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * 256] : 0.f;
+  for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
   for (int k2 = k2_begin; k2 < k2_end; ++k2) {
     float a_cur[NT];
 #pragma unroll
@@ -88,7 +88,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __r
     if (k2 + 1 < k2_end) {
       wp += kstride;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * 256] : 0.f;
+      for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
     }
     const float* hr = Hrows + ((k2 - k2_begin) * 2 + half) * SM_COLS + col;
     const float b0 = hr[0], b1 = hr[32];
@@ -102,14 +102,14 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __r
   }
 }
 
-template <int NT>
+template <int NT, int NW>
 __device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], const float* __restrict__ bias,
                                           int wave, int nt, float* __restrict__ H, int lane) {
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt) {
-      const int mt = wave + 4 * t;
+      const int mt = wave + NW * t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -122,17 +122,20 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], const floa
 }
 
 // dynamic LDS: H [hrows][64] | chunk [2][32][64]
-template <bool IS_SA, int NT>
-__global__ __launch_bounds__(256) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
+template <bool IS_SA, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
                                                         int cols_total, float* __restrict__ out) {
   extern __shared__ float s_mem[];
   float* H = s_mem;
   float* chunk = s_mem + (size_t)hrows * SM_COLS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // scalar wave index: keeps every "does this wave own row tile t" test a uniform branch
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bi = blockIdx.y;
   const int col0 = blockIdx.x * SM_COLS;
 
   // ---- per-thread loader state: this thread fills column lc, rows lr0 + 4*i of every chunk
+  constexpr int LROWS = SM_KC / NW;   // chunk rows filled per thread
   const int lc = tid & 63, lr0 = tid >> 6;
   const int gcol = col0 + lc;
   const bool cvalid = gcol < cols_total;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpS
   for (int l = 0; l < d.n_layers; ++l) {
     const int K = d.K[l], M = d.M[l];
     const int mt_total = (M + 31) >> 5;
-    const int nt = (mt_total - wave + 3) >> 2;     // row tiles of this wave (<= NT)
+    const int nt = (mt_total - wave + NW - 1) / NW;     // row tiles of this wave (<= NT)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -190,35 +193,35 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpS
     const int k2_total = (K + 1) >> 1;
     if (l == 0) {
       const int n_chunks = (K + SM_KC - 1) / SM_KC;
-      float stage[8];
+      float stage[LROWS];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) stage[i] = load_input(lr0 + 4 * i);
+      for (int i = 0; i < LROWS; ++i) stage[i] = load_input(lr0 + NW * i);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) chunk[(lr0 + 4 * i) * SM_COLS + lc] = stage[i];
+      for (int i = 0; i < LROWS; ++i) chunk[(lr0 + NW * i) * SM_COLS + lc] = stage[i];
       __syncthreads();
       for (int ch = 0; ch < n_chunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < n_chunks;
         if (more) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) stage[i] = load_input((ch + 1) * SM_KC + lr0 + 4 * i);
+          for (int i = 0; i < LROWS; ++i) stage[i] = load_input((ch + 1) * SM_KC + lr0 + NW * i);
         }
         const int k2b = ch * (SM_KC / 2);
         const int k2e = min(k2b + SM_KC / 2, k2_total);
-        mma_chunk<NT>(acc, d.W[l], mt_total, wave, nt, k2b, k2e, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
+        mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, k2b, k2e, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
         if (more) {
           float* cb = chunk + (size_t)(buf ^ 1) * SM_KC * SM_COLS;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) cb[(lr0 + 4 * i) * SM_COLS + lc] = stage[i];
+          for (int i = 0; i < LROWS; ++i) cb[(lr0 + NW * i) * SM_COLS + lc] = stage[i];
         }
         __syncthreads();
       }
     } else {
-      mma_chunk<NT>(acc, d.W[l], mt_total, wave, nt, 0, k2_total, H, lane);
+      mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, 0, k2_total, H, lane);
       __syncthreads();   // every wave has finished reading H_{l-1}
     }
     if (l + 1 < d.n_layers) {
-      store_act<NT>(acc, d.bias[l], wave, nt, H, lane);
+      store_act<NT, NW>(acc, d.bias[l], wave, nt, H, lane);
       // rows [M, roundup2(M)) of H must read as zero for the next layer's odd K
       if ((M & 1) && tid < SM_COLS) H[M * SM_COLS + tid] = 0.f;
       __syncthreads();
@@ -229,12 +232,12 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpS
   const int L = d.n_layers - 1;
   const int M = d.M[L];
   const int mt_total = (M + 31) >> 5;
-  const int nt = (mt_total - wave + 3) >> 2;
+  const int nt = (mt_total - wave + NW - 1) / NW;
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt) {
-      const int mt = wave + 4 * t;
+      const int mt = wave + NW * t;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -287,17 +290,20 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
-#define SM_LAUNCH(NT)                                                                          \
+#define SM_LAUNCH(NT, NW)                                                                      \
   do {                                                                                         \
-    auto kern = mlp_chain_kernel<IS_SA, NT>;                                                   \
+    auto kern = mlp_chain_kernel<IS_SA, NT, NW>;                                               \
     if (lds > 48 * 1024)                                                                       \
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                               (int)lds));                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, sa, fp, hrows, cols_total, out);     \
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, d, sa, fp, hrows, cols_total, out); \
   } while (0)
-  const int nt = (max_mt + 3) / 4;
-  if (nt <= 1) SM_LAUNCH(1); else if (nt == 2) SM_LAUNCH(2); else if (nt == 3) SM_LAUNCH(3); else SM_LAUNCH(4);
+  // wide layers: 8 waves (two per SIMD hide each other's L2 / LDS waits), <= 2 row tiles each;
+  // narrow layers (<= 4 row tiles): 4 waves, one row tile each
+  if (max_mt <= 4) SM_LAUNCH(1, 4);
+  else if (max_mt <= 8) SM_LAUNCH(1, 8);
+  else SM_LAUNCH(2, 8);
 #undef SM_LAUNCH
   PVN3D_LAUNCH_CHECK();
   return 0;
