@@ -278,6 +278,147 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Narrow layers (every M <= 128): column-sliced variant.  A wave owns 32 columns and ALL row
+// tiles (<= 4), keeps its own slice of the activations in LDS and gathers its own input
+// chunk, so there is no workgroup barrier anywhere -- with M <= 64 the row-split kernel above
+// leaves 2-3 of its 4 waves without a row tile.  Workgroup = 2 waves = 64 columns.
+// dynamic LDS per wave: H [hrows][32] | chunk [32][32].
+// ---------------------------------------------------------------------------------------
+template <bool IS_SA, int NTR>
+__global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa, FpSrc fp,
+                                                             int hrows, int cols_total,
+                                                             float* __restrict__ out) {
+  extern __shared__ float s_mem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* H = s_mem + (size_t)wave * (hrows + SM_KC) * 32;
+  float* chunk = H + (size_t)hrows * 32;
+  const int bi = blockIdx.y;
+  const int col0 = blockIdx.x * 64 + wave * 32;
+  if (col0 >= cols_total) return;          // wave-uniform; no barriers in this kernel
+  const int half = lane >> 5, col = lane & 31;
+
+  // loader: lane fills column `col`, rows half + 2*i (i < 16) of every 32-row chunk
+  const int gcol = col0 + col;
+  const bool cvalid = gcol < cols_total;
+  int id0 = 0, id1 = 0, id2 = 0;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, cxv = 0.f, cyv = 0.f, czv = 0.f;
+  if (IS_SA) {
+    if (cvalid) {
+      id0 = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
+      const float* c = sa.new_xyz + ((size_t)bi * sa.m + gcol / sa.ns) * 3;
+      cxv = c[0]; cyv = c[1]; czv = c[2];
+    }
+  } else if (cvalid) {
+    const int* ip = fp.idx + ((size_t)bi * fp.n + gcol) * 3;
+    const float* wp = fp.weight + ((size_t)bi * fp.n + gcol) * 3;
+    id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
+    w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
+  }
+  const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
+  const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
+  const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
+  const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
+  auto load_input = [=](int c) -> float {
+    if (!cvalid) return 0.f;
+    if (IS_SA) {
+      if (c < sa_c3) {
+        const float p = sa_xyz[((size_t)bi * sa_n + id0) * 3 + c];
+        return p - (c == 0 ? cxv : (c == 1 ? cyv : czv));
+      }
+      const int cf = c - sa_c3;
+      return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
+    } else {
+      if (c < fp_C2) {
+        const float* row = fp_kf + ((size_t)bi * fp_C2 + c) * fp_m;
+        return row[id0] * w0 + row[id1] * w1 + row[id2] * w2;
+      }
+      const int cu = c - fp_C2;
+      return cu < fp_C1 ? fp_uf[((size_t)bi * fp_C1 + cu) * fp_n + gcol] : 0.f;
+    }
+  };
+
+  f32x16 acc[NTR];
+  auto mma = [&](const float* __restrict__ Wp, int mt_total, int k2_begin, int k2_end,
+                 const float* __restrict__ rows) {
+    const float* wp = Wp + (size_t)k2_begin * mt_total * 64 + lane;
+    for (int k2 = k2_begin; k2 < k2_end; ++k2) {
+      const float b = rows[((k2 - k2_begin) * 2 + half) * 32 + col];
+#pragma unroll
+      for (int t = 0; t < NTR; ++t)
+        if (t < mt_total)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(size_t)t * 64], b, acc[t], 0, 0, 0);
+      wp += (size_t)mt_total * 64;
+    }
+  };
+
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int K = d.K[l], M = d.M[l];
+    const int mt_total = (M + 31) >> 5;
+#pragma unroll
+    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int k2_total = (K + 1) >> 1;
+    if (l == 0) {
+      const int n_chunks = (K + SM_KC - 1) / SM_KC;
+      float stage[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stage[i] = load_input(half + 2 * i);
+      for (int ch = 0; ch < n_chunks; ++ch) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) chunk[(half + 2 * i) * 32 + col] = stage[i];
+        if (ch + 1 < n_chunks) {   // gathers of the next chunk fly while this one is multiplied
+#pragma unroll
+          for (int i = 0; i < 16; ++i) stage[i] = load_input((ch + 1) * SM_KC + half + 2 * i);
+        }
+        const int k2b = ch * (SM_KC / 2);
+        mma(d.W[l], mt_total, k2b, min(k2b + SM_KC / 2, k2_total), chunk);
+      }
+    } else {
+      mma(d.W[l], mt_total, 0, k2_total, H);
+    }
+    if (l + 1 < d.n_layers) {
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        if (t < mt_total) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            H[row * 32 + col] = fmaxf(acc[t][r] + d.bias[l][row], 0.f);
+          }
+        }
+      }
+      if ((M & 1) && lane < 32) H[M * 32 + lane] = 0.f;
+    }
+  }
+
+  const int L = d.n_layers - 1;
+  const int M = d.M[L];
+  const int mt_total = (M + 31) >> 5;
+#pragma unroll
+  for (int t = 0; t < NTR; ++t) {
+    if (t < mt_total) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = fmaxf(acc[t][r] + d.bias[L][row], 0.f);
+        if (IS_SA) {
+          const int ns = sa.ns;   // 2..32, power of two
+          for (int o = 1; o < ns; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+          if (row < M && (col & (ns - 1)) == 0) {
+            const int j = (col0 + col) / ns;
+            if (j < sa.m) out[((size_t)bi * M + row) * sa.m + j] = v;
+          }
+        } else if (row < M && gcol < cols_total) {
+          out[((size_t)bi * M + row) * fp.n + gcol] = v;
+        }
+      }
+    }
+  }
+}
+
 template <bool IS_SA>
 int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
                  float* out, hipStream_t st) {
@@ -287,6 +428,29 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
     max_mt = max(max_mt, (d.M[l] + 31) / 32);
   }
   if (max_mt > SM_MAX_MT) return (int)hipErrorInvalidValue;
+  const bool ns_ok = !IS_SA || sa.ns <= 32;
+  // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0:
+  // 0.82 -> 0.36 ms and 2.66 -> 1.86 ms) and loses for M = 128 with K >= 99 (every wave
+  // re-fetches all weight fragments): 1.4 -> 2.4 ms, so it is used for <= 2 row tiles only.
+  if (max_mt <= 2 && ns_ok) {   // narrow chain: barrier-free column-sliced kernel
+    int hr = 2;
+    for (int l = 0; l + 1 < d.n_layers; ++l) hr = max(hr, ((d.M[l] + 31) / 32) * 32 + 2);
+    const size_t lds2 = (size_t)2 * (hr + SM_KC) * 32 * sizeof(float);
+    const dim3 grid2(pvn3d_ceil_div(cols_total, 64), b);
+#define SM_LAUNCH_COLS(NTR)                                                                    \
+  do {                                                                                         \
+    auto kern = mlp_chain_cols_kernel<IS_SA, NTR>;                                             \
+    if (lds2 > 48 * 1024)                                                                      \
+      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                              (int)lds2));                                     \
+    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hr, cols_total, out);      \
+  } while (0)
+    if (max_mt <= 1) SM_LAUNCH_COLS(1); else if (max_mt <= 2) SM_LAUNCH_COLS(2); else SM_LAUNCH_COLS(4);
+#undef SM_LAUNCH_COLS
+    PVN3D_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
