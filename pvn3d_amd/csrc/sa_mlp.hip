@@ -73,30 +73,51 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __r
                                           int k2_end, const float* __restrict__ Hrows /*row 2*k2_begin*/,
                                           int lane) {
   const int half = lane >> 5, col = lane & 31;
-  if (nt <= 0 || k2_begin >= k2_end) return;
+  const int steps = k2_end - k2_begin;
+  if (nt <= 0 || steps <= 0) return;
   const size_t kstride = (size_t)mt_total * 64;
   const float* wp = Wp + ((size_t)k2_begin * mt_total + wave) * 64 + lane;
-  // the weight fragments of step k2+1 are fetched (L2) while step k2 runs on the matrix pipe
-  // (a deeper, two-step pipeline measured slower: 40.1 vs 36.0 ms for the whole network)
-  float a_nxt[NT];
+  const float* hr = Hrows + half * SM_COLS + col;
+  // Two register sets (even / odd K-steps), each refilled right after its MFMAs issue, i.e. two
+  // steps before it is needed again: weight fragments come from L2 (~600-900 cycles), one step
+  // of this wave plus its SIMD partner is ~512 cycles of matrix-pipe time.
+  float ae[NT], ao[NT], be0, be1, bo0 = 0.f, bo1 = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
-  for (int k2 = k2_begin; k2 < k2_end; ++k2) {
-    float a_cur[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
-    if (k2 + 1 < k2_end) {
-      wp += kstride;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) a_nxt[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
-    }
-    const float* hr = Hrows + ((k2 - k2_begin) * 2 + half) * SM_COLS + col;
-    const float b0 = hr[0], b1 = hr[32];
+  for (int t = 0; t < NT; ++t) {
+    ae[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
+    ao[t] = (t < nt && steps > 1) ? wp[kstride + (size_t)t * NW * 64] : 0.f;
+  }
+  be0 = hr[0]; be1 = hr[32];
+  if (steps > 1) { bo0 = hr[2 * SM_COLS]; bo1 = hr[2 * SM_COLS + 32]; }
+  for (int s = 0; s < steps; s += 2) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b0, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b1, acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], be0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], be1, acc[t][1], 0, 0, 0);
+      }
+    }
+    if (s + 2 < steps) {
+      const float* w2 = wp + (size_t)(s + 2) * kstride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ae[t] = (t < nt) ? w2[(size_t)t * NW * 64] : 0.f;
+      const float* h2 = hr + (size_t)(s + 2) * 2 * SM_COLS;
+      be0 = h2[0]; be1 = h2[32];
+    }
+    if (s + 1 < steps) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao[t], bo0, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao[t], bo1, acc[t][1], 0, 0, 0);
+        }
+      }
+      if (s + 3 < steps) {
+        const float* w3 = wp + (size_t)(s + 3) * kstride;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ao[t] = (t < nt) ? w3[(size_t)t * NW * 64] : 0.f;
+        const float* h3 = hr + (size_t)(s + 3) * 2 * SM_COLS;
+        bo0 = h3[0]; bo1 = h3[32];
       }
     }
   }
