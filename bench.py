@@ -8,12 +8,16 @@ ranks, rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1], "LineMOD 'ape' eval path, N=12 288 pts"): one STEP = one
 batch of ``--frames`` synthetic frames per GPU, resident in HBM, through the hot path:
-  (A) the Pointnet2MSG op chain of lib/pvn3d.py:65-118 -- 4 set-abstraction levels
-      (FPS -> gather -> two-radius ball_query -> group xyz+features) and 4 feature-propagation
-      levels (three_nn -> weights -> three_interpolate) -- with the network's channel widths;
-      feature tensors are synthetic because the SharedMLP GEMMs between the ops are SURVEY.md
-      section 8(f) rank 1 ("next"), not yet part of the measured path;
+  (A) the Pointnet2MSG forward of lib/pvn3d.py:46-154 (random-init weights, eval mode) -- 4
+      multi-scale set-abstraction levels (FPS -> gather -> two-radius ball_query -> fused
+      [group xyz+features -> SharedMLP -> max-pool] on fp32 MFMA) and 4 feature-propagation
+      levels (three_nn -> weights -> fused [three_interpolate -> concat -> SharedMLP]);
+      ``--ops-only`` replaces it by the bare op chain with synthetic feature tensors (the
+      round-1 first measurement, no GEMMs);
   (B) vote assembly -> (K+1) MeanShift fits per frame -> Kabsch pose (cal_frame_poses_lm).
+The HBM rooflines of the data-movement ops (ball_query, group, three_interpolate, ...) are
+measured on the unfused op chain in a separate, untimed-for-`value` pass, because in (A)
+grouping and interpolation never touch HBM (they feed the MFMA kernel through LDS).
 Frames are independent, so N GPUs run N x frames per step with no data-path collective (weak
 scaling); the only communication is the timing reduction.
 
@@ -38,6 +42,7 @@ if ROOT not in sys.path:
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_VALU_TFLOPS = 157.3
+PEAK_FP32_MFMA_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32, exact fp32 (guide: matrix fp32 = vector peak)
 
 # Pointnet2MSG hyper-parameters, pvn3d/lib/pvn3d.py:65-118 (input_channels = 6)
 SA_LEVELS = [  # (n_in, npoint, C_in, radii, nsamples, C_out)
@@ -153,6 +158,58 @@ def run_ops(inp, timer, scale):
     return keep
 
 
+class _HookStage(object):
+    """Context manager handed to pointnet2_modules.STAGE_HOOK: one event pair per stage."""
+
+    def __init__(self, timer, name):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.e1 = self.timer.start(self.name)
+
+    def __exit__(self, *exc):
+        StageTimer.stop(self.e1)
+        return False
+
+
+def make_net(dev):
+    """Pointnet2MSG with the reference's hyper-parameters, random-init weights (seeded), eval mode."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    torch.manual_seed(20260925)
+    return Pointnet2MSG(input_channels=6).to(dev).eval()
+
+
+def run_net(net, inp, timer):
+    """(A) the fused Pointnet2MSG forward; `timer` (if enabled) brackets its stages."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    pm.STAGE_HOOK = (lambda name: _HookStage(timer, name)) if timer.enabled else None
+    try:
+        with torch.no_grad():
+            t = timer.start("pointnet2_msg_total")
+            out = net(inp["pc"])
+            timer.stop(t)
+    finally:
+        pm.STAGE_HOOK = None
+    return out
+
+
+def mlp_flops_per_frame(net, scale):
+    """2*K*M flops per column of every 1x1-conv layer x the columns it runs on."""
+    sa = fp = 0.0
+    for mod in net.SA_modules:
+        m = int(mod.npoint * scale)
+        for grouper, mlp in zip(mod.groupers, mod.mlps):
+            per_col = sum(2.0 * c.weight.shape[0] * c.weight.shape[1]
+                          for c in mlp.modules() if isinstance(c, (torch.nn.Conv2d, torch.nn.Conv1d)))
+            sa += per_col * m * grouper.nsample
+    n_unknown = [int(v * scale) for v in (12288, 2048, 1024, 512)]    # FP_modules[0..3] outputs
+    for mod, n in zip(net.FP_modules, n_unknown):
+        per_col = sum(2.0 * c.weight.shape[0] * c.weight.shape[1]
+                      for c in mod.mlp.modules() if isinstance(c, (torch.nn.Conv2d, torch.nn.Conv1d)))
+        fp += per_col * n
+    return sa, fp
+
+
 def run_postproc(inp, timer, poll_every):
     """(B) vote -> MeanShift x (K+1) -> Kabsch for the whole batch."""
     from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
@@ -223,6 +280,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream, islands back to back")
+    ap.add_argument("--ops-only", action="store_true",
+                    help="island (A) = bare SA/FP op chain with synthetic features (no MLP GEMMs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,7 +298,12 @@ def main():
 
     scale = args.n_pts / 12288.0
     inp = make_inputs(args.frames, args.n_pts, args.n_obj, dev, seed_base=1000 * rank)
+    inp["pc"] = torch.cat([inp["pcld"], inp["feats"].transpose(1, 2)], 2).contiguous()   # (F, N, 3+6)
+    net = None if args.ops_only else make_net(dev)
     timer_off = StageTimer(False)
+
+    def island_a(timer):
+        return run_ops(inp, timer, scale) if net is None else run_net(net, inp, timer)
 
     # The two halves of the path are independent islands (the CNN + heads
     # sit between them), so a pipelined evaluator runs them concurrently on different frames.
@@ -250,12 +314,12 @@ def main():
 
     def step(timer):
         if args.serial:
-            keep = run_ops(inp, timer, scale)
+            keep = island_a(timer)
             res = run_postproc(inp, timer, args.poll_every)
             return keep, res
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            keep = run_ops(inp, timer_off, scale)
+            keep = island_a(timer_off)
         res = run_postproc(inp, timer_off, args.poll_every)
         torch.cuda.current_stream(dev).wait_stream(side)
         return keep, res
@@ -275,16 +339,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if not args.serial and not args.no_stage_events:
+    op_timer = StageTimer(False)
+    if not args.no_stage_events:
         # per-stage kernel time: the same K steps once more, serialised on one stream so that the
         # event pairs bracket exactly one stage each (not part of `value`)
-        run_ops(inp, timer_off, scale)     # warm this stream's allocator pool (untimed)
-        torch.cuda.synchronize()
-        timer = StageTimer(True)
-        for _ in range(args.steps):
-            run_ops(inp, timer, scale)
-            run_postproc(inp, timer, args.poll_every)
-        torch.cuda.synchronize()
+        if not args.serial:
+            island_a(timer_off)                # warm this stream's allocator pool (untimed)
+            torch.cuda.synchronize()
+            timer = StageTimer(True)
+            for _ in range(args.steps):
+                island_a(timer)
+                run_postproc(inp, timer, args.poll_every)
+            torch.cuda.synchronize()
+        if net is not None:
+            # HBM rooflines of the data-movement ops: the unfused op chain at the same shapes
+            run_ops(inp, timer_off, scale)
+            torch.cuda.synchronize()
+            op_timer = StageTimer(True)
+            for _ in range(args.steps):
+                run_ops(inp, op_timer, scale)
+            torch.cuda.synchronize()
+        else:
+            op_timer = timer
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -300,17 +376,33 @@ def main():
         total_frames = args.frames * world * args.steps
         stage_ms = timer.totals_ms()
         per_step = {k: v / args.steps for k, v in stage_ms.items()}
+        op_step = {k: v / args.steps for k, v in op_timer.totals_ms().items()}
         alg = algorithmic_bytes_per_frame(args.n_pts)
         rooflines = {}
         F = args.frames
         for name in ["ball_query", "group", "three_interpolate", "three_nn", "gather", "fps"]:
-            if name in per_step and per_step[name] > 0:
-                gbs = alg[name] * F / (per_step[name] * 1e-3) / 1e9
+            if name in op_step and op_step[name] > 0:
+                gbs = alg[name] * F / (op_step[name] * 1e-3) / 1e9
                 rooflines[name] = dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
-                                       frac=gbs / PEAK_HBM_GBS, traffic=None, ms_per_step=per_step[name],
+                                       frac=gbs / PEAK_HBM_GBS, traffic=None, ms_per_step=op_step[name],
                                        algorithmic_bytes_per_frame=alg[name])
-        if "ball_query" in per_step and "group" in per_step:
-            tms = per_step["ball_query"] + per_step["group"]
+        if net is not None:
+            sa_fl, fp_fl = mlp_flops_per_frame(net, scale)
+            for name, fl in (("sa_mlp", sa_fl), ("fp_mlp", fp_fl)):
+                if per_step.get(name, 0) > 0:
+                    tfl = fl * F / (per_step[name] * 1e-3) / 1e12
+                    rooflines[name] = dict(bound="mfma", achieved=tfl, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                           frac=tfl / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                                           ms_per_step=per_step[name], algorithmic_flops_per_frame=fl)
+            if per_step.get("sa_mlp", 0) > 0 and per_step.get("fp_mlp", 0) > 0:
+                tms = per_step["sa_mlp"] + per_step["fp_mlp"]
+                tfl = (sa_fl + fp_fl) * F / (tms * 1e-3) / 1e12
+                rooflines["sa_mlp+fp_mlp"] = dict(bound="mfma", achieved=tfl, peak=PEAK_FP32_MFMA_TFLOPS,
+                                                  unit="TFLOP/s", frac=tfl / PEAK_FP32_MFMA_TFLOPS, traffic=None,
+                                                  ms_per_step=tms, algorithmic_flops_per_frame=sa_fl + fp_fl)
+        if "ball_query" in op_step and "group" in op_step:
+            per_step_bg = op_step
+            tms = per_step_bg["ball_query"] + per_step_bg["group"]
             gbs = (alg["ball_query"] + alg["group"]) * F / (tms * 1e-3) / 1e9
             rooflines["ball_query+group"] = dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                                  frac=gbs / PEAK_HBM_GBS, traffic=None, ms_per_step=tms,
@@ -337,17 +429,29 @@ def main():
                         rooflines[name]["traffic_source"] = "profiles/%s_pmc_traffic.json" % pmc.get("tag")
         except (OSError, ValueError, KeyError):
             pass
-        dominant = max(per_step, key=per_step.get) if per_step else None
+        leaf = {k: v for k, v in per_step.items() if k != "pointnet2_msg_total"}
+        dominant = max(leaf, key=leaf.get) if leaf else None
+        if net is not None and "pointnet2_msg_total" in per_step:
+            # torch glue inside the forward (transposes, concat, interpolation weights)
+            per_step["pointnet2_msg_other"] = per_step["pointnet2_msg_total"] - sum(
+                per_step.get(k, 0.0) for k in ("fps", "gather", "ball_query", "sa_mlp", "three_nn", "fp_mlp"))
+        if net is None:
+            island = ("Pointnet2MSG SA/FP op chain only (FPS, gather, ball_query, group, three_nn, "
+                      "three_interpolate; synthetic features, no MLP GEMMs)")
+        else:
+            island = ("Pointnet2MSG forward (4 SA-MSG + 4 FP levels, random-init weights, eval): FPS, gather, "
+                      "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP "
+                      "on fp32 MFMA")
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LineMOD 'ape' eval path: Pointnet2MSG SA/FP op chain (FPS, gather, ball_query, "
-                                   "group, three_nn, three_interpolate; MLP GEMMs not yet in path) + vote -> "
-                                   "MeanShift x9 -> Kabsch; N=%d pts, n_obj=%d, K=8" % (args.n_pts, args.n_obj),
+            "config": {"workload": "LineMOD 'ape' eval path: %s + vote -> MeanShift x9 -> Kabsch; N=%d pts, "
+                                   "n_obj=%d, K=8" % (island, args.n_pts, args.n_obj),
                        "frames_per_gpu_per_step": args.frames, "parallelism": "frames sharded x%d, no collective" % world,
-                       "streams": "1 (serial)" if args.serial else "2 (SA/FP ops || vote-cluster-pose)"},
+                       "streams": "1 (serial)" if args.serial else "2 (Pointnet2MSG || vote-cluster-pose)"},
+            "op_chain_stage_ms_per_step": op_step if net is not None else None,
             "stage_ms_per_step": per_step,
             "dominant_stage": dominant,
             "roofline": rooflines.get(dominant if dominant in rooflines else "ball_query+group"),

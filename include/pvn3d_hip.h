@@ -128,8 +128,8 @@ int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xy
  * grouped tensor is never written.  out (b, dims[n_layers], m).
  * dims_host: HOST int[n_layers+1], dims[0] = 3*use_xyz + c.  For layer l (K = dims[l],
  * M = dims[l+1]) with BatchNorm folded in (W' = W*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)):
- *   w_packed[l]   DEVICE float[ceil(K/2)][ceil(M/32)][64], entry (k2, mt, lane) =
- *                 W'[mt*32 + (lane&31)][2*k2 + (lane>>5)]  (0 outside M x K)
+ *   w_packed[l]   DEVICE float[ceil(K/4)][ceil(M/32)][64][2], entry (k4, mt, lane, j) =
+ *                 W'[mt*32 + (lane&31)][4*k4 + 2*j + (lane>>5)]  (0 outside M x K)
  *   bias_padded[l] DEVICE float[ceil(M/32)*32], zero padded.
  * w_packed / bias_padded are HOST arrays of device pointers.  nsample: power of two <= 64;
  * every dims[l] <= 512. */

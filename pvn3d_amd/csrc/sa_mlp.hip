@@ -18,9 +18,10 @@
 // b' = beta - mean * g/sqrt(var+eps).
 //
 // Workgroup = 4 waves, 64 columns.  Layer l: D[M_l x 64] = relu(W_l[M_l x K_l] . H_{l-1}[K_l x 64] + b_l)
-//   * A operand (weights): pre-packed on the host as [K/2][M/32][64 lanes] so that one
-//     32x32x2 fragment is one coalesced 256-byte load (lane l: W[mt*32 + (l&31)][2*k2 + (l>>5)]);
-//     weights are shared by every workgroup and stay L2-resident.
+//   * A operand (weights): pre-packed on the host as [K/4][M/32][64 lanes][2] so that the
+//     fragments of two consecutive 32x32x2 steps are one coalesced 512-byte load
+//     (lane l, j: W[mt*32 + (l&31)][4*k4 + 2*j + (l>>5)]); K and M are zero padded to
+//     multiples of 4 and 32; weights are shared by every workgroup and stay L2-resident.
 //   * B operand (activations): LDS, H[k][64 cols] row-major -- a fragment read is two
 //     conflict-free 128-byte rows (lane l: H[2*k2 + (l>>5)][ct*32 + (l&31)]).
 //   * a wave owns row tiles mt = wave, wave+4, ... (<= 4) x 2 column tiles = <= 8 accumulator
@@ -45,7 +46,7 @@ struct MlpDesc {
   int n_layers;
   int K[SM_MAX_LAYERS];              // true input width of layer l
   int M[SM_MAX_LAYERS];              // true output width
-  const float* W[SM_MAX_LAYERS];     // packed [ceil(K/2)][ceil(M/32)][64]
+  const float* W[SM_MAX_LAYERS];     // packed [ceil(K/4)][ceil(M/32)][64][2]
   const float* bias[SM_MAX_LAYERS];  // [ceil(M/32)*32], zero padded
 };
 
@@ -67,59 +68,66 @@ struct FpSrc {      // loader of the feature-propagation input: column = unknown
 
 // ---- one layer on the matrix cores --------------------------------------------------------
 // acc tiles [t][ct]; Hin in LDS [K][64] (layer >= 1) or streamed in chunks (layer 0).
+// K is consumed in PAIRS of 32x32x2 steps (4 input channels): one 8-byte load per lane fetches
+// the A fragments of both steps of a row tile.  The loop is branch-free (exact tile count NTC,
+// clamped prefetch addresses, odd pair peeled after the loop) so that the compiler can count
+// outstanding loads -- with conditional loads in the loop it falls back to s_waitcnt vmcnt(0)
+// at the loop head and the prefetch is lost.  Two register sets, each refilled right after its
+// MFMAs issue (two pairs = 4 steps ahead of its next use).
+template <int NTC, int NT, int CT>
+__device__ __forceinline__ void mma_pairs(f32x16 (&acc)[NT][CT], const float2* __restrict__ wp,
+                                          size_t tstride, size_t pstride,
+                                          const float* __restrict__ hr, int hstride, int pairs) {
+  if (pairs <= 0) return;
+  const int last = pairs - 1;
+  float2 ac[NTC], an[NTC];
+  float bc[2][CT], bn[2][CT];
+#define SM_LD(A, B, P)                                                          \
+  do {                                                                          \
+    const float2* w_ = wp + (size_t)(P) * pstride;                              \
+    _Pragma("unroll") for (int t = 0; t < NTC; ++t) A[t] = w_[(size_t)t * tstride]; \
+    const float* h_ = hr + (size_t)(P) * 4 * hstride;                           \
+    _Pragma("unroll") for (int c = 0; c < CT; ++c) {                            \
+      B[0][c] = h_[c * 32];                                                     \
+      B[1][c] = h_[2 * hstride + c * 32];                                       \
+    }                                                                           \
+  } while (0)
+#define SM_MM(A, B)                                                                              \
+  do {                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < NTC; ++t)                                              \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c)                                             \
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t].x, B[0][c], acc[t][c], 0, 0, 0);   \
+    _Pragma("unroll") for (int t = 0; t < NTC; ++t)                                              \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c)                                             \
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t].y, B[1][c], acc[t][c], 0, 0, 0);   \
+  } while (0)
+  SM_LD(ac, bc, 0);
+  SM_LD(an, bn, min(1, last));
+  int p = 0;
+  for (; p + 1 < pairs; p += 2) {
+    SM_MM(ac, bc);
+    SM_LD(ac, bc, min(p + 2, last));
+    SM_MM(an, bn);
+    SM_LD(an, bn, min(p + 3, last));
+  }
+  if (p < pairs) SM_MM(ac, bc);
+#undef SM_LD
+#undef SM_MM
+}
+
+// dispatch on the (wave-uniform) number of row tiles this wave owns
 template <int NT, int NW>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __restrict__ Wp,
-                                          int mt_total, int wave, int nt, int k2_begin,
-                                          int k2_end, const float* __restrict__ Hrows /*row 2*k2_begin*/,
+                                          int mt_total, int wave, int nt, int pair_begin,
+                                          int pair_end, const float* __restrict__ Hrows /*row 4*pair_begin*/,
                                           int lane) {
-  const int half = lane >> 5, col = lane & 31;
-  const int steps = k2_end - k2_begin;
-  if (nt <= 0 || steps <= 0) return;
-  const size_t kstride = (size_t)mt_total * 64;
-  const float* wp = Wp + ((size_t)k2_begin * mt_total + wave) * 64 + lane;
-  const float* hr = Hrows + half * SM_COLS + col;
-  // Two register sets (even / odd K-steps), each refilled right after its MFMAs issue, i.e. two
-  // steps before it is needed again: weight fragments come from L2 (~600-900 cycles), one step
-  // of this wave plus its SIMD partner is ~512 cycles of matrix-pipe time.
-  float ae[NT], ao[NT], be0, be1, bo0 = 0.f, bo1 = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    ae[t] = (t < nt) ? wp[(size_t)t * NW * 64] : 0.f;
-    ao[t] = (t < nt && steps > 1) ? wp[kstride + (size_t)t * NW * 64] : 0.f;
-  }
-  be0 = hr[0]; be1 = hr[32];
-  if (steps > 1) { bo0 = hr[2 * SM_COLS]; bo1 = hr[2 * SM_COLS + 32]; }
-  for (int s = 0; s < steps; s += 2) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t < nt) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], be0, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], be1, acc[t][1], 0, 0, 0);
-      }
-    }
-    if (s + 2 < steps) {
-      const float* w2 = wp + (size_t)(s + 2) * kstride;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) ae[t] = (t < nt) ? w2[(size_t)t * NW * 64] : 0.f;
-      const float* h2 = hr + (size_t)(s + 2) * 2 * SM_COLS;
-      be0 = h2[0]; be1 = h2[32];
-    }
-    if (s + 1 < steps) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao[t], bo0, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao[t], bo1, acc[t][1], 0, 0, 0);
-        }
-      }
-      if (s + 3 < steps) {
-        const float* w3 = wp + (size_t)(s + 3) * kstride;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) ao[t] = (t < nt) ? w3[(size_t)t * NW * 64] : 0.f;
-        const float* h3 = hr + (size_t)(s + 3) * 2 * SM_COLS;
-        bo0 = h3[0]; bo1 = h3[32];
-      }
-    }
+  const float2* wp = reinterpret_cast<const float2*>(Wp) + ((size_t)pair_begin * mt_total + wave) * 64 + lane;
+  const float* hr = Hrows + (lane >> 5) * SM_COLS + (lane & 31);
+  const size_t pstride = (size_t)mt_total * 64;
+  const int pairs = pair_end - pair_begin;
+  if (nt >= NT) mma_pairs<NT, NT, 2>(acc, wp, (size_t)NW * 64, pstride, hr, SM_COLS, pairs);
+  else if constexpr (NT > 1) {
+    if (nt == NT - 1) mma_pairs<NT - 1, NT, 2>(acc, wp, (size_t)NW * 64, pstride, hr, SM_COLS, pairs);
   }
 }
 
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
-    const int k2_total = (K + 1) >> 1;
+    const int pairs_total = (K + 3) >> 2;
     if (l == 0) {
       const int n_chunks = (K + SM_KC - 1) / SM_KC;
       float stage[LROWS];
@@ -227,9 +235,9 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
 #pragma unroll
           for (int i = 0; i < LROWS; ++i) stage[i] = load_input((ch + 1) * SM_KC + lr0 + NW * i);
         }
-        const int k2b = ch * (SM_KC / 2);
-        const int k2e = min(k2b + SM_KC / 2, k2_total);
-        mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, k2b, k2e, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
+        const int pb = ch * (SM_KC / 4);
+        const int pe = min(pb + SM_KC / 4, pairs_total);
+        mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, pb, pe, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
         if (more) {
           float* cb = chunk + (size_t)(buf ^ 1) * SM_KC * SM_COLS;
 #pragma unroll
@@ -238,13 +246,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
         __syncthreads();
       }
     } else {
-      mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, 0, k2_total, H, lane);
+      mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, 0, pairs_total, H, lane);
       __syncthreads();   // every wave has finished reading H_{l-1}
     }
     if (l + 1 < d.n_layers) {
       store_act<NT, NW>(acc, d.bias[l], wave, nt, H, lane);
-      // rows [M, roundup2(M)) of H must read as zero for the next layer's odd K
-      if ((M & 1) && tid < SM_COLS) H[M * SM_COLS + tid] = 0.f;
+      // rows [M, roundup32(M)) were written as relu(0 + 0) = 0 (zero-padded weights and bias),
+      // which covers the next layer's K rounded up to a multiple of 4
       __syncthreads();
     }
   }
@@ -360,17 +368,18 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
     }
   };
 
-  f32x16 acc[NTR];
-  auto mma = [&](const float* __restrict__ Wp, int mt_total, int k2_begin, int k2_end,
+  f32x16 acc[NTR][1];
+  auto mma = [&](const float* __restrict__ Wp, int mt_total, int pair_begin, int pair_end,
                  const float* __restrict__ rows) {
-    const float* wp = Wp + (size_t)k2_begin * mt_total * 64 + lane;
-    for (int k2 = k2_begin; k2 < k2_end; ++k2) {
-      const float b = rows[((k2 - k2_begin) * 2 + half) * 32 + col];
-#pragma unroll
-      for (int t = 0; t < NTR; ++t)
-        if (t < mt_total)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[(size_t)t * 64], b, acc[t], 0, 0, 0);
-      wp += (size_t)mt_total * 64;
+    const float2* wp = reinterpret_cast<const float2*>(Wp) + (size_t)pair_begin * mt_total * 64 + lane;
+    const float* hr = rows + half * 32 + col;
+    const size_t pstride = (size_t)mt_total * 64;
+    const int pairs = pair_end - pair_begin;
+    if (mt_total == 1) mma_pairs<1, NTR, 1>(acc, wp, 64, pstride, hr, 32, pairs);
+    if constexpr (NTR >= 2) { if (mt_total == 2) mma_pairs<2, NTR, 1>(acc, wp, 64, pstride, hr, 32, pairs); }
+    if constexpr (NTR >= 4) {
+      if (mt_total == 3) mma_pairs<3, NTR, 1>(acc, wp, 64, pstride, hr, 32, pairs);
+      if (mt_total == 4) mma_pairs<4, NTR, 1>(acc, wp, 64, pstride, hr, 32, pairs);
     }
   };
 
@@ -380,8 +389,8 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
     for (int t = 0; t < NTR; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int k2_total = (K + 1) >> 1;
+      for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
+    const int pairs_total = (K + 3) >> 2;
     if (l == 0) {
       const int n_chunks = (K + SM_KC - 1) / SM_KC;
       float stage[16];
@@ -394,11 +403,11 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
           for (int i = 0; i < 16; ++i) stage[i] = load_input((ch + 1) * SM_KC + half + 2 * i);
         }
-        const int k2b = ch * (SM_KC / 2);
-        mma(d.W[l], mt_total, k2b, min(k2b + SM_KC / 2, k2_total), chunk);
+        const int pb = ch * (SM_KC / 4);
+        mma(d.W[l], mt_total, pb, min(pb + SM_KC / 4, pairs_total), chunk);
       }
     } else {
-      mma(d.W[l], mt_total, 0, k2_total, H);
+      mma(d.W[l], mt_total, 0, pairs_total, H);
     }
     if (l + 1 < d.n_layers) {
 #pragma unroll
@@ -407,11 +416,10 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            H[row * 32 + col] = fmaxf(acc[t][r] + d.bias[l][row], 0.f);
+            H[row * 32 + col] = fmaxf(acc[t][0][r] + d.bias[l][row], 0.f);
           }
         }
       }
-      if ((M & 1) && lane < 32) H[M * 32 + lane] = 0.f;
     }
   }
 
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = fmaxf(acc[t][r] + d.bias[L][row], 0.f);
+        float v = fmaxf(acc[t][0][r] + d.bias[L][row], 0.f);
         if (IS_SA) {
           const int ns = sa.ns;   // 2..32, power of two
           for (int o = 1; o < ns; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -26,13 +26,14 @@ class PackedMLP(object):
 
 
 def _pack_weight(W):
-    """W (M,K) float32 -> [ceil(K/2)][ceil(M/32)][64]: entry (k2, mt, lane) =
-    W[mt*32 + (lane & 31)][2*k2 + (lane >> 5)], zero outside."""
+    """W (M,K) float32 -> [ceil(K/4)][ceil(M/32)][64][2]: entry (k4, mt, lane, j) =
+    W[mt*32 + (lane & 31)][4*k4 + 2*j + (lane >> 5)], zero outside (include/pvn3d_hip.h)."""
     M, K = W.shape
-    MT, K2 = (M + 31) // 32, (K + 1) // 2
-    Wp = torch.zeros((MT * 32, K2 * 2), dtype=torch.float32, device=W.device)
+    MT, K4 = (M + 31) // 32, (K + 3) // 4
+    Wp = torch.zeros((MT * 32, K4 * 4), dtype=torch.float32, device=W.device)
     Wp[:M, :K] = W
-    return Wp.view(MT, 32, K2, 2).permute(2, 0, 3, 1).contiguous().view(K2, MT, 64)
+    # (mt, r, k4, j, half) -> (k4, mt, half, r, j)
+    return Wp.view(MT, 32, K4, 2, 2).permute(2, 0, 4, 1, 3).contiguous().view(K4, MT, 64, 2)
 
 
 def _fold(layer):

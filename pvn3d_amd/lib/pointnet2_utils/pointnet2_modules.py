@@ -24,6 +24,28 @@ from ..utils import pytorch_utils as pt_utils
 FUSED_INFERENCE = True
 
 
+# Optional measurement hook: a callable ``name -> context manager`` bracketing each stage of the
+# forward ("fps", "gather", "ball_query", "sa_mlp", "three_nn", "fp_mlp"); bench.py installs an
+# event-pair timer here.  None (the default) costs one attribute read per stage.
+STAGE_HOOK = None
+
+
+class _NullStage(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_STAGE = _NullStage()
+
+
+def _stage(name):
+    hook = STAGE_HOOK
+    return hook(name) if hook is not None else _NULL_STAGE
+
+
 def _no_grad_needed(*tensors):
     if not torch.is_grad_enabled():
         return True
@@ -51,10 +73,13 @@ class _PointnetSAModuleBase(nn.Module):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum(mlp[-1]),npoint)"""
         new_xyz = None
         if self.npoint is not None:
-            sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            xyz_t = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
-            idxs = self._shared_idx(xyz, new_xyz)
+            with _stage("fps"):
+                sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            with _stage("gather"):
+                xyz_t = xyz.transpose(1, 2).contiguous()
+                new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
+            with _stage("ball_query"):
+                idxs = self._shared_idx(xyz, new_xyz)
         else:
             idxs = [None] * len(self.groupers)
 
@@ -68,8 +93,10 @@ class _PointnetSAModuleBase(nn.Module):
                 packed = _fused_mlp.pack_shared_mlp(mlp) if (ns & (ns - 1)) == 0 and ns <= 64 else None
                 if packed is not None:
                     if idx is None:
-                        idx = pointnet2_utils.ball_query(grouper.radius, ns, xyz, new_xyz)
-                    pooled.append(_ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed))
+                        with _stage("ball_query"):
+                            idx = pointnet2_utils.ball_query(grouper.radius, ns, xyz, new_xyz)
+                    with _stage("sa_mlp"):
+                        pooled.append(_ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed))
                     continue
             if idx is not None:
                 grouped = grouper(xyz, new_xyz, features, idx=idx)
@@ -121,7 +148,8 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown, known, unknow_feats, known_feats):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            with _stage("three_nn"):
+                dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
             if (FUSED_INFERENCE and not self.training and known_feats.is_cuda
@@ -130,7 +158,8 @@ class PointnetFPModule(nn.Module):
                 packed = _fused_mlp.pack_shared_mlp(self.mlp)
                 if packed is not None:
                     uf = unknow_feats.contiguous() if unknow_feats is not None else None
-                    return _ext.fp_interp_mlp(known_feats.contiguous(), uf, idx, weight.contiguous(), packed)
+                    with _stage("fp_mlp"):
+                        return _ext.fp_interp_mlp(known_feats.contiguous(), uf, idx, weight.contiguous(), packed)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
