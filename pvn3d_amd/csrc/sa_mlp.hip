@@ -31,6 +31,8 @@
 //     double-buffered LDS chunk; later layers read the full previous activation from LDS.
 // Epilogue SA: max over the nsample columns of each centre (lanes), store (B, M, npoint).
 // Epilogue FP: store (B, M, n).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -131,9 +133,49 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __r
   }
 }
 
+// max over groups of ns (power of two <= 32) consecutive lanes with DPP row operations fused
+// into v_max_f32 (a ds_bpermute butterfly costs ~5x the MFMA time of a narrow chain).
+// ns <= 16: every lane of a group ends with the group max; ns == 32: lanes 16..31 / 48..63 do.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return fmaxf(v, __int_as_float(o));
+}
+__device__ __forceinline__ float seg_max(float v, int ns) {
+  if (ns >= 2) v = dpp_max<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  if (ns >= 4) v = dpp_max<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  if (ns >= 8) v = dpp_max<0x141, 0xF>(v);    // row_half_mirror
+  if (ns >= 16) v = dpp_max<0x140, 0xF>(v);   // row_mirror
+  if (ns >= 32) v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  return v;
+}
+__device__ __forceinline__ bool seg_leader(int col, int ns) {
+  return ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
+}
+
+// accumulator tile <- bias of its rows (C/D map: reg r holds row (r&3) + 8*(r>>2) + 4*half)
+__device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb /*tile's 32 biases, LDS*/,
+                                         int half) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(sb + 8 * g + 4 * half);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+}
+
+// all biases of the chain -> LDS (layer l at offset sum_{i<l} roundup32(M_i)); caller syncs
+__device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__ sb, int tid, int nthreads) {
+  int off = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int mp = ((d.M[l] + 31) >> 5) << 5;
+    for (int i = tid; i < mp; i += nthreads) sb[off + i] = d.bias[l][i];
+    off += mp;
+  }
+}
+
 template <int NT, int NW>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], const float* __restrict__ bias,
-                                          int wave, int nt, float* __restrict__ H, int lane) {
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], int wave, int nt,
+                                          float* __restrict__ H, int lane) {
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -142,22 +184,23 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], const floa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float bv = bias[row];
-        H[row * SM_COLS + col] = fmaxf(acc[t][0][r] + bv, 0.f);
-        H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r] + bv, 0.f);
+        H[row * SM_COLS + col] = fmaxf(acc[t][0][r], 0.f);
+        H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r], 0.f);
       }
     }
   }
 }
 
-// dynamic LDS: H [hrows][64] | chunk [2][32][64]
+// dynamic LDS: H [hrows][64] | chunk [2][32][64] | bias [sum roundup32(M_l)]
 template <bool IS_SA, int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
+__global__ __launch_bounds__(NW * 64, (NT == 1 ? (NW == 8 ? (IS_SA ? 4 : 2) : 3) : 2)) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
                                                         int cols_total, float* __restrict__ out) {
   extern __shared__ float s_mem[];
   float* H = s_mem;
   float* chunk = s_mem + (size_t)hrows * SM_COLS;
+  float* s_bias = chunk + 2 * SM_KC * SM_COLS;
   const int tid = threadIdx.x, lane = tid & 63;
+  stage_bias(d, s_bias, tid, NW * 64);     // visible after the first barrier below
   // scalar wave index: keeps every "does this wave own row tile t" test a uniform branch
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bi = blockIdx.y;
@@ -169,13 +212,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
   const int gcol = col0 + lc;
   const bool cvalid = gcol < cols_total;
   int id0 = 0, id1 = 0, id2 = 0;
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f, cxv = 0.f, cyv = 0.f, czv = 0.f;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  size_t ctr = 0;      // offset of this column's centre in new_xyz
   if (IS_SA) {
     if (cvalid) {
       id0 = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
-      const int j = gcol / sa.ns;
-      const float* c = sa.new_xyz + ((size_t)bi * sa.m + j) * 3;
-      cxv = c[0]; cyv = c[1]; czv = c[2];
+      ctr = ((size_t)bi * sa.m + gcol / sa.ns) * 3;
     }
   } else {
     if (cvalid) {
@@ -188,15 +230,20 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
   // plain local copies: capturing the by-value kernel-argument structs by reference would pin
   // them in scratch memory and turn every field access of the loader into a scratch load
   const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
+  const float* const sa_nxyz = sa.new_xyz;
   const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
   const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
   const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
   auto load_input = [=](int c) -> float {   // value of input channel c for this thread's column
+#ifdef SM_EXP_NOGATHER
+    if (c >= 32) return 1.0f;
+#endif
     if (!cvalid) return 0.f;
     if (IS_SA) {
       if (c < sa_c3) {
-        const float p = sa_xyz[((size_t)bi * sa_n + id0) * 3 + c];
-        return p - (c == 0 ? cxv : (c == 1 ? cyv : czv));   // grouped_xyz -= new_xyz
+        // grouped_xyz -= new_xyz (the centre is re-read: a select chain over three registers
+        // is turned into a scratch-array lookup by the compiler)
+        return sa_xyz[((size_t)bi * sa_n + id0) * 3 + c] - sa_nxyz[ctr + c];
       }
       const int cf = c - sa_c3;
       return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
@@ -211,14 +258,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
   };
 
   f32x16 acc[NT][2];
+  int boff = 0;
   for (int l = 0; l < d.n_layers; ++l) {
     const int K = d.K[l], M = d.M[l];
     const int mt_total = (M + 31) >> 5;
     const int nt = (mt_total - wave + NW - 1) / NW;     // row tiles of this wave (<= NT)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
     const int pairs_total = (K + 3) >> 2;
     if (l == 0) {
       const int n_chunks = (K + SM_KC - 1) / SM_KC;
@@ -228,6 +272,12 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
 #pragma unroll
       for (int i = 0; i < LROWS; ++i) chunk[(lr0 + NW * i) * SM_COLS + lc] = stage[i];
       __syncthreads();
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+          acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, lane >> 5);
+          acc[t][1] = acc[t][0];
+        }
       for (int ch = 0; ch < n_chunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < n_chunks;
@@ -246,11 +296,18 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
         __syncthreads();
       }
     } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+          acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, lane >> 5);
+          acc[t][1] = acc[t][0];
+        }
       mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, 0, pairs_total, H, lane);
       __syncthreads();   // every wave has finished reading H_{l-1}
     }
+    boff += mt_total * 32;
     if (l + 1 < d.n_layers) {
-      store_act<NT, NW>(acc, d.bias[l], wave, nt, H, lane);
+      store_act<NT, NW>(acc, wave, nt, H, lane);
       // rows [M, roundup32(M)) were written as relu(0 + 0) = 0 (zero-padded weights and bias),
       // which covers the next layer's K rounded up to a multiple of 4
       __syncthreads();
@@ -270,30 +327,19 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float bv = d.bias[L][row];
-        float v0 = fmaxf(acc[t][0][r] + bv, 0.f), v1 = fmaxf(acc[t][1][r] + bv, 0.f);
+        float v0 = fmaxf(acc[t][0][r], 0.f), v1 = fmaxf(acc[t][1][r], 0.f);
         if (IS_SA) {
-          // max over the nsample consecutive columns of each centre (ns = 16 or 32 here;
-          // columns beyond cols_total hold relu(bias) of zero inputs and are never stored)
+          // max over the nsample consecutive columns of each centre (columns beyond cols_total
+          // hold relu(bias) of zero inputs and belong to centres >= m, never stored)
           const int ns = sa.ns;
-          for (int o = 1; o < ns && o < 32; o <<= 1) {
-            v0 = fmaxf(v0, __shfl_xor(v0, o, 64));
-            v1 = fmaxf(v1, __shfl_xor(v1, o, 64));
-          }
-          float v = v0;
-          int jcol = col;                               // column of tile 0
-          if (ns > 32) { v = fmaxf(v0, v1); }           // ns == 64: both tiles are one centre
-          if (row < M) {
-            if (ns >= 64) {
-              if (col == 0) {
-                const int j = col0 / ns;
-                if (j < sa.m) out[((size_t)bi * M + row) * sa.m + j] = v;
-              }
-            } else if ((col & (ns - 1)) == 0) {
-              const int j0 = (col0 + jcol) / ns, j1 = (col0 + 32 + jcol) / ns;
-              if (j0 < sa.m) out[((size_t)bi * M + row) * sa.m + j0] = v0;
-              if (j1 < sa.m) out[((size_t)bi * M + row) * sa.m + j1] = v1;
-            }
+          if (ns > 32) v0 = fmaxf(v0, v1);              // ns == 64: both tiles are one centre
+          v0 = seg_max(v0, ns);
+          if (ns <= 32) v1 = seg_max(v1, ns);
+          if (row < M && seg_leader(col, ns)) {
+            const int cb = ns >= 32 ? 0 : col;
+            const int j0 = (col0 + cb) / ns, j1 = (col0 + 32 + cb) / ns;
+            if (j0 < sa.m) out[((size_t)bi * M + row) * sa.m + j0] = v0;
+            if (ns <= 32 && j1 < sa.m) out[((size_t)bi * M + row) * sa.m + j1] = v1;
           }
         } else {
           if (row < M) {
@@ -312,32 +358,36 @@ __global__ __launch_bounds__(NW * 64) void mlp_chain_kernel(MlpDesc d, SaSrc sa,
 // tiles (<= 4), keeps its own slice of the activations in LDS and gathers its own input
 // chunk, so there is no workgroup barrier anywhere -- with M <= 64 the row-split kernel above
 // leaves 2-3 of its 4 waves without a row tile.  Workgroup = 2 waves = 64 columns.
-// dynamic LDS per wave: H [hrows][32] | chunk [32][32].
+// dynamic LDS: bias [bias_floats] | per wave: H [hrows][32] | chunk [32][32].
 // ---------------------------------------------------------------------------------------
 template <bool IS_SA, int NTR>
-__global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa, FpSrc fp,
-                                                             int hrows, int cols_total,
+__global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 2)))) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa, FpSrc fp,
+                                                             int hrows, int bias_floats,
+                                                             int cols_total,
                                                              float* __restrict__ out) {
   extern __shared__ float s_mem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* H = s_mem + (size_t)wave * (hrows + SM_KC) * 32;
+  float* s_bias = s_mem;
+  float* H = s_mem + bias_floats + (size_t)wave * (hrows + SM_KC) * 32;
   float* chunk = H + (size_t)hrows * 32;
   const int bi = blockIdx.y;
   const int col0 = blockIdx.x * 64 + wave * 32;
-  if (col0 >= cols_total) return;          // wave-uniform; no barriers in this kernel
+  stage_bias(d, s_bias, tid, 128);
+  __syncthreads();                         // the only barrier of this kernel
+  if (col0 >= cols_total) return;          // wave-uniform
   const int half = lane >> 5, col = lane & 31;
 
   // loader: lane fills column `col`, rows half + 2*i (i < 16) of every 32-row chunk
   const int gcol = col0 + col;
   const bool cvalid = gcol < cols_total;
   int id0 = 0, id1 = 0, id2 = 0;
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f, cxv = 0.f, cyv = 0.f, czv = 0.f;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+  size_t ctr = 0;      // offset of this column's centre in new_xyz
   if (IS_SA) {
     if (cvalid) {
       id0 = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
-      const float* c = sa.new_xyz + ((size_t)bi * sa.m + gcol / sa.ns) * 3;
-      cxv = c[0]; cyv = c[1]; czv = c[2];
+      ctr = ((size_t)bi * sa.m + gcol / sa.ns) * 3;
     }
   } else if (cvalid) {
     const int* ip = fp.idx + ((size_t)bi * fp.n + gcol) * 3;
@@ -346,6 +396,7 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
     w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
   }
   const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
+  const float* const sa_nxyz = sa.new_xyz;
   const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
   const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
   const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
@@ -353,8 +404,7 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
     if (!cvalid) return 0.f;
     if (IS_SA) {
       if (c < sa_c3) {
-        const float p = sa_xyz[((size_t)bi * sa_n + id0) * 3 + c];
-        return p - (c == 0 ? cxv : (c == 1 ? cyv : czv));
+        return sa_xyz[((size_t)bi * sa_n + id0) * 3 + c] - sa_nxyz[ctr + c];
       }
       const int cf = c - sa_c3;
       return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
@@ -383,13 +433,14 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
     }
   };
 
+  int boff = 0;
   for (int l = 0; l < d.n_layers; ++l) {
     const int K = d.K[l], M = d.M[l];
     const int mt_total = (M + 31) >> 5;
 #pragma unroll
     for (int t = 0; t < NTR; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
+      if (t < mt_total) acc_bias(acc[t][0], s_bias + boff + t * 32, half);
+    boff += mt_total * 32;
     const int pairs_total = (K + 3) >> 2;
     if (l == 0) {
       const int n_chunks = (K + SM_KC - 1) / SM_KC;
@@ -416,7 +467,7 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            H[row * 32 + col] = fmaxf(acc[t][0][r] + d.bias[l][row], 0.f);
+            H[row * 32 + col] = fmaxf(acc[t][0][r], 0.f);
           }
         }
       }
@@ -432,12 +483,12 @@ __global__ __launch_bounds__(128) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = fmaxf(acc[t][0][r] + d.bias[L][row], 0.f);
+        float v = fmaxf(acc[t][0][r], 0.f);
         if (IS_SA) {
           const int ns = sa.ns;   // 2..32, power of two
-          for (int o = 1; o < ns; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-          if (row < M && (col & (ns - 1)) == 0) {
-            const int j = (col0 + col) / ns;
+          v = seg_max(v, ns);
+          if (row < M && seg_leader(col, ns)) {
+            const int j = (col0 + (ns >= 32 ? 0 : col)) / ns;
             if (j < sa.m) out[((size_t)bi * M + row) * sa.m + j] = v;
           }
         } else if (row < M && gcol < cols_total) {
@@ -461,10 +512,16 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0:
   // 0.82 -> 0.36 ms and 2.66 -> 1.86 ms) and loses for M = 128 with K >= 99 (every wave
   // re-fetches all weight fragments): 1.4 -> 2.4 ms, so it is used for <= 2 row tiles only.
-  if (max_mt <= 2 && ns_ok) {   // narrow chain: barrier-free column-sliced kernel
+  static const int cols_max_mt = [] {
+    const char* e = getenv("PVN3D_MLP_COLS_MAX_MT");     // tuning override
+    return e ? atoi(e) : 2;
+  }();
+  if (max_mt <= cols_max_mt && max_mt <= 4 && ns_ok) {   // narrow chain: column-sliced kernel
     int hr = 2;
     for (int l = 0; l + 1 < d.n_layers; ++l) hr = max(hr, ((d.M[l] + 31) / 32) * 32 + 2);
-    const size_t lds2 = (size_t)2 * (hr + SM_KC) * 32 * sizeof(float);
+    int bias_floats = 0;
+    for (int l = 0; l < d.n_layers; ++l) bias_floats += ((d.M[l] + 31) / 32) * 32;
+    const size_t lds2 = ((size_t)2 * (hr + SM_KC) * 32 + bias_floats) * sizeof(float);
     const dim3 grid2(pvn3d_ceil_div(cols_total, 64), b);
 #define SM_LAUNCH_COLS(NTR)                                                                    \
   do {                                                                                         \
@@ -473,14 +530,16 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                               (int)lds2));                                     \
-    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hr, cols_total, out);      \
+    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hr, bias_floats, cols_total, out); \
   } while (0)
     if (max_mt <= 1) SM_LAUNCH_COLS(1); else if (max_mt <= 2) SM_LAUNCH_COLS(2); else SM_LAUNCH_COLS(4);
 #undef SM_LAUNCH_COLS
     PVN3D_LAUNCH_CHECK();
     return 0;
   }
-  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS) * sizeof(float);
+  int bias_all = 0;
+  for (int l = 0; l < d.n_layers; ++l) bias_all += ((d.M[l] + 31) / 32) * 32;
+  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
 #define SM_LAUNCH(NT, NW)                                                                      \
