@@ -182,7 +182,11 @@ def make_net(dev):
 def run_net(net, inp, timer):
     """(A) the fused Pointnet2MSG forward; `timer` (if enabled) brackets its stages."""
     from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    from pvn3d_amd.lib import pointnet2_msg
     pm.STAGE_HOOK = (lambda name: _HookStage(timer, name)) if timer.enabled else None
+    ahead = pointnet2_msg.GEOMETRY_STREAM
+    if timer.enabled:
+        pointnet2_msg.GEOMETRY_STREAM = False     # stage events need one serial stream
     try:
         with torch.no_grad():
             t = timer.start("pointnet2_msg_total")
@@ -190,6 +194,7 @@ def run_net(net, inp, timer):
             timer.stop(t)
     finally:
         pm.STAGE_HOOK = None
+        pointnet2_msg.GEOMETRY_STREAM = ahead
     return out
 
 
@@ -450,7 +455,8 @@ def main():
             "config": {"workload": "LineMOD 'ape' eval path: %s + vote -> MeanShift x9 -> Kabsch; N=%d pts, "
                                    "n_obj=%d, K=8" % (island, args.n_pts, args.n_obj),
                        "frames_per_gpu_per_step": args.frames, "parallelism": "frames sharded x%d, no collective" % world,
-                       "streams": "1 (serial)" if args.serial else "2 (Pointnet2MSG || vote-cluster-pose)"},
+                       "streams": "1 (serial)" if args.serial else "3 (Pointnet2MSG feature path || its xyz-only geometry (FPS, ball query, three_nn) || "
+                                  "vote-cluster-pose)" if net is not None else "2 (SA/FP ops || vote-cluster-pose)"},
             "op_chain_stage_ms_per_step": op_step if net is not None else None,
             "stage_ms_per_step": per_step,
             "dominant_stage": dominant,

@@ -2,9 +2,25 @@
 module tree (pvn3d/lib/pvn3d.py:46-154: 4 multi-scale set-abstraction levels, 4 feature
 propagation levels), built from this package's SA/FP modules.  Only this class of
 lib/pvn3d.py is on the hot path; the CNN, DenseFusion and heads are out of scope."""
+import torch
 import torch.nn as nn
 
+from .pointnet2_utils import pointnet2_modules as _pm
 from .pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPModule
+
+# Inference: FPS / ball query / three_nn of every level depend on xyz only.  They are
+# latency-bound (one workgroup per frame for FPS), so they run ahead on a second HIP stream
+# while the MFMA kernels of the previous level occupy the matrix cores; the feature path waits
+# on one event per level.  False keeps everything on the caller's stream.
+GEOMETRY_STREAM = True
+_geo_streams = {}
+
+
+def _geo_stream(dev):
+    st = _geo_streams.get(dev)
+    if st is None:
+        st = _geo_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 class Pointnet2MSG(nn.Module):
@@ -40,14 +56,56 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def _geometry_ahead(self, xyz):
+        """Run every level's xyz-only work on the geometry stream; returns per-level results and
+        the events the feature path has to wait for."""
+        cur = torch.cuda.current_stream(xyz.device)
+        geo = _geo_stream(xyz.device)
+        geo.wait_stream(cur)
+        sa_geo, fp_geo, l_xyz = [], [None] * len(self.FP_modules), [xyz]
+
+        def hand_over(tensors):
+            ev = torch.cuda.Event()
+            ev.record(geo)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(cur)      # allocated on `geo`, consumed on `cur`
+            return ev
+
+        with torch.cuda.stream(geo):
+            for sa in self.SA_modules:
+                new_xyz, idxs = sa.sample_and_query(l_xyz[-1])
+                sa_geo.append(((new_xyz, idxs), hand_over([new_xyz] + list(idxs))))
+                l_xyz.append(new_xyz)
+            for i in range(-1, -(len(self.FP_modules) + 1), -1):
+                idx, weight = PointnetFPModule.neighbours(l_xyz[i - 1], l_xyz[i])
+                fp_geo[i] = ((idx, weight), hand_over([idx, weight]))
+        return sa_geo, fp_geo
+
     def forward(self, pointcloud):
         """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N)."""
         xyz, features = self._break_up_pc(pointcloud)
+        ahead = (GEOMETRY_STREAM and _pm.FUSED_INFERENCE and not self.training and xyz.is_cuda
+                 and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]
-        for sa in self.SA_modules:
-            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+        if not ahead:
+            for sa in self.SA_modules:
+                li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+                l_xyz.append(li_xyz)
+                l_features.append(li_features)
+            for i in range(-1, -(len(self.FP_modules) + 1), -1):
+                l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+            return l_features[0]
+        cur = torch.cuda.current_stream(xyz.device)
+        sa_geo, fp_geo = self._geometry_ahead(xyz)
+        for sa, (geom, ev) in zip(self.SA_modules, sa_geo):
+            cur.wait_event(ev)
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1], geometry=geom)
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+            nbrs, ev = fp_geo[i]
+            cur.wait_event(ev)
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i],
+                                                   neighbours=nbrs)
         return l_features[0]

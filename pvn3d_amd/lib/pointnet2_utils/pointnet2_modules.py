@@ -69,19 +69,24 @@ class _PointnetSAModuleBase(nn.Module):
                                         g[1].radius, g[1].nsample)
         return [None] * len(g)
 
-    def forward(self, xyz, features=None):
+    def sample_and_query(self, xyz):
+        """The geometry half of forward(): FPS centres and the neighbour indices of every scale.
+        Depends on xyz only, so a caller may run it ahead of the feature path (another stream)
+        and hand the result back through forward(..., geometry=...)."""
+        if self.npoint is None:
+            return None, [None] * len(self.groupers)
+        with _stage("fps"):
+            sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        with _stage("gather"):
+            xyz_t = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
+        with _stage("ball_query"):
+            idxs = self._shared_idx(xyz, new_xyz)
+        return new_xyz, idxs
+
+    def forward(self, xyz, features=None, geometry=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum(mlp[-1]),npoint)"""
-        new_xyz = None
-        if self.npoint is not None:
-            with _stage("fps"):
-                sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            with _stage("gather"):
-                xyz_t = xyz.transpose(1, 2).contiguous()
-                new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
-            with _stage("ball_query"):
-                idxs = self._shared_idx(xyz, new_xyz)
-        else:
-            idxs = [None] * len(self.groupers)
+        new_xyz, idxs = geometry if geometry is not None else self.sample_and_query(xyz)
 
         pooled = []
         fuse = (FUSED_INFERENCE and not self.training and self.npoint is not None and xyz.is_cuda
@@ -145,13 +150,19 @@ class PointnetFPModule(nn.Module):
         super(PointnetFPModule, self).__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
-        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
-        if known is not None:
-            with _stage("three_nn"):
-                dist, idx = pointnet2_utils.three_nn(unknown, known)
+    @staticmethod
+    def neighbours(unknown, known):
+        """three_nn + inverse-distance weights (reference :183-186); depends on xyz only."""
+        with _stage("three_nn"):
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return idx, weight
+
+    def forward(self, unknown, known, unknow_feats, known_feats, neighbours=None):
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
+        if known is not None:
+            idx, weight = neighbours if neighbours is not None else self.neighbours(unknown, known)
             if (FUSED_INFERENCE and not self.training and known_feats.is_cuda
                     and _no_grad_needed(unknow_feats, known_feats)
                     and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters())):

@@ -320,6 +320,19 @@ def test_fused_fp_mlp_and_full_pointnet2msg(dev):
             pm.FUSED_INFERENCE = True
     assert y.shape == (1, 128, 12288)
     assert (y - y_ref).abs().max().item() < 2e-4 * max(y_ref.abs().max().item(), 1.0)
+    # geometry run ahead on its own stream (default) == everything on one stream, bit for bit
+    from pvn3d_amd.lib import pointnet2_msg
+    pointnet2_msg.GEOMETRY_STREAM = False
+    try:
+        with torch.no_grad():
+            y_one = net(pc)
+    finally:
+        pointnet2_msg.GEOMETRY_STREAM = True
+    with torch.no_grad():
+        for _ in range(3):                       # repeated: exercises cross-stream buffer reuse
+            y_two = net(pc)
+    torch.cuda.synchronize()
+    assert torch.equal(y_one, y_two) and torch.equal(y_one, y)
     # training mode / autograd keeps the unfused differentiable path
     net.train()
     out = net(pc[:, :2048].clone().requires_grad_(False))
