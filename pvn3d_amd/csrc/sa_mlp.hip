@@ -193,8 +193,8 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], int wave, 
 
 // dynamic LDS: H [hrows][64] | chunk [2][32][64] | bias [sum roundup32(M_l)]
 template <bool IS_SA, int NT, int NW>
-__global__ __launch_bounds__(NW * 64, (NT == 1 ? (NW == 8 ? (IS_SA ? 4 : 2) : 3) : 2)) void mlp_chain_kernel(MlpDesc d, SaSrc sa, FpSrc fp, int hrows,
-                                                        int cols_total, float* __restrict__ out) {
+__device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int hrows,
+                                               int cols_total, float* __restrict__ out) {
   extern __shared__ float s_mem[];
   float* H = s_mem;
   float* chunk = s_mem + (size_t)hrows * SM_COLS;
@@ -351,6 +351,19 @@ __global__ __launch_bounds__(NW * 64, (NT == 1 ? (NW == 8 ? (IS_SA ? 4 : 2) : 3)
       }
     }
   }
+}
+
+template <bool IS_SA, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : 3)) void mlp_chain_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int cols_total, float* __restrict__ out) {
+  mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, cols_total, out);
+}
+
+// Two row tiles per wave (M > 256).
+template <bool IS_SA>
+__global__ __launch_bounds__(512) void mlp_chain_wide_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int cols_total, float* __restrict__ out) {
+  mlp_chain_body<IS_SA, 2, 8>(d, sa, fp, hrows, cols_total, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -542,9 +555,9 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
-#define SM_LAUNCH(NT, NW)                                                                      \
+#define SM_LAUNCH(KERN, NW)                                                                      \
   do {                                                                                         \
-    auto kern = mlp_chain_kernel<IS_SA, NT, NW>;                                               \
+    auto kern = KERN;                                                                          \
     if (lds > 48 * 1024)                                                                       \
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
@@ -553,9 +566,9 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   } while (0)
   // wide layers: 8 waves (two per SIMD hide each other's L2 / LDS waits), <= 2 row tiles each;
   // narrow layers (<= 4 row tiles): 4 waves, one row tile each
-  if (max_mt <= 4) SM_LAUNCH(1, 4);
-  else if (max_mt <= 8) SM_LAUNCH(1, 8);
-  else SM_LAUNCH(2, 8);
+  if (max_mt <= 4) SM_LAUNCH((mlp_chain_kernel<IS_SA, 4>), 4);
+  else if (max_mt <= 8) SM_LAUNCH((mlp_chain_kernel<IS_SA, 8>), 8);
+  else SM_LAUNCH((mlp_chain_wide_kernel<IS_SA>), 8);
 #undef SM_LAUNCH
   PVN3D_LAUNCH_CHECK();
   return 0;
