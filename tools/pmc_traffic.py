@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per bench step from rocprofv3 PMC counters (MI355X_MICROARCH.md, HBM section):
-two separate passes (FETCH_SIZE, WRITE_SIZE; KB units), FETCH_SIZE doubled (gfx950 reports half
+separate passes (FETCH_SIZE, WRITE_SIZE; KB units; each once for the default fused path and
+once for `--ops-only`, the unfused op chain the HBM rooflines are quoted on), FETCH_SIZE doubled (gfx950 reports half
 of a wide coalesced read -- calibrated here on a 1 GiB hipMemcpy D2D: WRITE_SIZE = 1048576 KB
 exactly, FETCH_SIZE = 524300 KB).  Runs `bench.py --serial` under the profiler and writes
 profiles/<tag>_pmc_traffic.json (+ profiles/latest_pmc_traffic.json, read by bench.py to fill
@@ -13,18 +14,24 @@ import subprocess
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-STAGE_OF = [("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
+STAGE_OF = [("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
+            ("mlp_chain_cols_kernel<true", "sa_mlp"), ("mlp_chain_kernel<false", "fp_mlp"),
+            ("mlp_chain_wide_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
+            ("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
             ("ball_query", "ball_query"), ("grid_build", "ball_query"), ("three_nn", "three_nn"),
             ("fps_", "fps"), ("gather_points", "gather"), ("ms_", "vote_cluster_pose"),
             ("vote_compact", "vote_cluster_pose"), ("best_fit", "vote_cluster_pose")]
 WARMUP, STEPS = 3, 2
 
 
-def run_pass(counter, outdir):
+OP_STAGES = ("group", "three_interpolate", "ball_query", "three_nn", "fps", "gather")
+
+
+def run_pass(counter, outdir, extra=()):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "p", "--output-format", "csv", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--serial", "--steps", str(STEPS), "--warmup", str(WARMUP),
-           "--no-cpu-baseline", "--no-stage-events"]
+           "--no-cpu-baseline", "--no-stage-events"] + list(extra)
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
     per_kernel = collections.defaultdict(float)
     with open(os.path.join(outdir, "p_counter_collection.csv")) as f:
@@ -36,22 +43,25 @@ def run_pass(counter, outdir):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
     out = os.path.join(ROOT, "gpurun_out", "pmc_%s" % tag)
-    fetch = run_pass("FETCH_SIZE", out + "_fetch")
-    write = run_pass("WRITE_SIZE", out + "_write")
     n_steps = WARMUP + STEPS
     stages = collections.defaultdict(lambda: dict(read_bytes=0.0, write_bytes=0.0))
     kernels = {}
-    for name in set(fetch) | set(write):
-        rd = 2.0 * fetch.get(name, 0.0) / n_steps      # gfx950 FETCH_SIZE correction
-        wr = write.get(name, 0.0) / n_steps
-        kernels[name[:80]] = dict(read_bytes_per_step=rd, write_bytes_per_step=wr)
-        for key, st in STAGE_OF:
-            if key in name:
-                stages[st]["read_bytes"] += rd
-                stages[st]["write_bytes"] += wr
-                break
+    for mode, extra in (("fused", ()), ("ops_only", ("--ops-only",))):
+        fetch = run_pass("FETCH_SIZE", "%s_%s_fetch" % (out, mode), extra)
+        write = run_pass("WRITE_SIZE", "%s_%s_write" % (out, mode), extra)
+        for name in set(fetch) | set(write):
+            rd = 2.0 * fetch.get(name, 0.0) / n_steps      # gfx950 FETCH_SIZE correction
+            wr = write.get(name, 0.0) / n_steps
+            for key, st in STAGE_OF:
+                if key in name:
+                    # data-movement ops are quoted on the unfused chain, everything else on the fused path
+                    if (st in OP_STAGES) == (mode == "ops_only"):
+                        kernels["%s:%s" % (mode, name[:80])] = dict(read_bytes_per_step=rd, write_bytes_per_step=wr)
+                        stages[st]["read_bytes"] += rd
+                        stages[st]["write_bytes"] += wr
+                    break
     res = dict(tag=tag, command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --serial "
-               "--steps %d --warmup %d --no-cpu-baseline --no-stage-events" % (STEPS, WARMUP),
+               "--steps %d --warmup %d --no-cpu-baseline --no-stage-events [--ops-only]" % (STEPS, WARMUP),
                frames_per_step=64, correction="FETCH_SIZE x2 (gfx950), KB->bytes x1024, totals / %d steps" % n_steps,
                stage_bytes_per_step={k: dict(v, total_bytes=v["read_bytes"] + v["write_bytes"]) for k, v in stages.items()},
                kernels=kernels)
