@@ -125,27 +125,44 @@ int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xy
 /* Fused set abstraction for inference: gather (QueryAndGroup, pointnet2_utils.py:311-321) ->
  * SharedMLP = [1x1 conv -> BatchNorm (eval) -> ReLU] x n_layers (pytorch_utils.py:25-50) ->
  * max over nsample (pointnet2_modules.py:63-66), on fp32 MFMA; the (b, 3+c, m, nsample)
- * grouped tensor is never written.  out (b, dims[n_layers], m).
- * dims_host: HOST int[n_layers+1], dims[0] = 3*use_xyz + c.  For layer l (K = dims[l],
+ * grouped tensor is never written.
+ * Feature tensors are POINT-MAJOR at this boundary (row gathers are contiguous):
+ *   features_pm  (b, n, ld_feat) floats, channels [0,c) of each row used, or NULL (c = 0);
+ *                the reference's (b,c,n) tensor transposed (see pvn3d_transpose_bcn_to_bnc);
+ *   out_pm       (b, m, ld_out): the dims[n_layers] pooled channels of centre j are written to
+ *                out_pm[(b*m + j)*ld_out + out_coff ...] (the two scales of an MSG level share
+ *                one buffer, which replaces torch.cat, pointnet2_modules.py:71).
+ * dims_host: HOST int[n_layers+1], dims[0] = c + 3*use_xyz.  Layer-0 input channel order is
+ * [c feature channels][x,y,z relative to the centre] -- i.e. the reference's conv weight
+ * columns (xyz first, pointnet2_utils.py:319-321) rotated left by 3.  For layer l (K = dims[l],
  * M = dims[l+1]) with BatchNorm folded in (W' = W*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)):
  *   w_packed[l]   DEVICE float[ceil(K/4)][ceil(M/32)][64][2], entry (k4, mt, lane, j) =
  *                 W'[mt*32 + (lane&31)][4*k4 + 2*j + (lane>>5)]  (0 outside M x K)
  *   bias_padded[l] DEVICE float[ceil(M/32)*32], zero padded.
  * w_packed / bias_padded are HOST arrays of device pointers.  nsample: power of two <= 64;
- * every dims[l] <= 512. */
+ * every dims[l>=1] <= 512.  The 16-byte row gather is used when features_pm is 16-byte aligned
+ * and ld_feat % 4 == 0 (otherwise a scalar gather). */
 int pvn3d_sa_mlp_maxpool(int b, int n, int m, int c, int nsample, int use_xyz, const float* xyz,
-                         const float* new_xyz, const float* features, const int* idx,
-                         int n_layers, const int* dims_host, const float* const* w_packed,
-                         const float* const* bias_padded, float* out, void* stream);
+                         const float* new_xyz, const float* features_pm, int ld_feat,
+                         const int* idx, int n_layers, const int* dims_host,
+                         const float* const* w_packed, const float* const* bias_padded,
+                         float* out_pm, int ld_out, int out_coff, void* stream);
 
 /* Fused feature propagation for inference (PointnetFPModule.forward,
  * pointnet2_modules.py:183-206): three_interpolate(known_feats, idx, weight) ++ unknow_feats ->
- * SharedMLP.  known_feats (b,c2,m), unknow_feats (b,c1,n) or NULL (c1 = 0), idx/weight (b,n,3)
- * -> out (b, dims[n_layers], n); dims[0] = c2 + c1; weights as in pvn3d_sa_mlp_maxpool. */
-int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_feats,
-                        const float* unknow_feats, const int* idx, const float* weight,
-                        int n_layers, const int* dims_host, const float* const* w_packed,
-                        const float* const* bias_padded, float* out, void* stream);
+ * SharedMLP.  known_pm (b, m, ld_known) and unknown_pm (b, n, ld_unknown) (or NULL, c1 = 0) are
+ * point-major, channels [0,c2) / [0,c1) used; idx/weight (b,n,3); dims[0] = c2 + c1 in the
+ * reference's order (interpolated first, :194-197); weights as in pvn3d_sa_mlp_maxpool.
+ * out: out_point_major ? (b, n, ld_out) : (b, dims[n_layers], n)  (the module's API layout). */
+int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                        const float* unknown_pm, int ld_unknown, const int* idx,
+                        const float* weight, int n_layers, const int* dims_host,
+                        const float* const* w_packed, const float* const* bias_padded, float* out,
+                        int out_point_major, int ld_out, void* stream);
+
+/* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */
+int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out, int ld_out,
+                               void* stream);
 
 /* ========================= 3. vote -> MeanShift -> pose (post-proc) ===================== */
 

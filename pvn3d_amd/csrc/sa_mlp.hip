@@ -17,20 +17,33 @@
 // BatchNorm (eval) is folded into the weights/bias on the host: W' = W * g/sqrt(var+eps),
 // b' = beta - mean * g/sqrt(var+eps).
 //
-// Workgroup = 4 waves, 64 columns.  Layer l: D[M_l x 64] = relu(W_l[M_l x K_l] . H_{l-1}[K_l x 64] + b_l)
+// Feature tensors are POINT-MAJOR here ((B, points, channels), row stride `ld`): the gather of a
+// neighbour is then one contiguous row, read 16 bytes per lane with 8 lanes per row (8 cache
+// lines per wave instruction instead of 64 for a channel-major gather), and the pooled output
+// of a centre is one contiguous row as well.  The host glue passes the reference's (B, C, n)
+// tensors as transposed views, so nothing is copied between levels.
+//
+// Row-split kernel (mlp_chain_body): workgroup = NW waves, 64 columns.
+// Layer l: D[M_l x 64] = relu(W_l[M_l x K_l] . H_{l-1}[K_l x 64] + b_l)
 //   * A operand (weights): pre-packed on the host as [K/4][M/32][64 lanes][2] so that the
-//     fragments of two consecutive 32x32x2 steps are one coalesced 512-byte load
-//     (lane l, j: W[mt*32 + (l&31)][4*k4 + 2*j + (l>>5)]); K and M are zero padded to
-//     multiples of 4 and 32; weights are shared by every workgroup and stay L2-resident.
-//   * B operand (activations): LDS, H[k][64 cols] row-major -- a fragment read is two
-//     conflict-free 128-byte rows (lane l: H[2*k2 + (l>>5)][ct*32 + (l&31)]).
-//   * a wave owns row tiles mt = wave, wave+4, ... (<= 4) x 2 column tiles = <= 8 accumulator
-//     tiles (128 VGPRs); after a layer the tile (bias, ReLU) is written back to the same LDS
-//     buffer (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-//   * layer 0 reads its input in 32-channel chunks that the loader gathers into a
-//     double-buffered LDS chunk; later layers read the full previous activation from LDS.
-// Epilogue SA: max over the nsample columns of each centre (lanes), store (B, M, npoint).
-// Epilogue FP: store (B, M, n).
+//     fragments of two consecutive 32x32x2 steps ("a pair" = 4 input channels) are one coalesced
+//     512-byte load (lane l, j: W[mt*32 + (l&31)][4*k4 + 2*j + (l>>5)]); K and M are zero padded
+//     to multiples of 4 and 32; weights are shared by every workgroup and stay L2-resident.
+//     A ring of 8 register sets is refilled right after each pair's MFMAs issue, 8 pairs (one
+//     input chunk) ahead, and runs on across chunk boundaries: in-order vmcnt means a weight
+//     load queued behind the gathers of the next chunk completes after them, so those loads
+//     must not be needed for a whole chunk.  The steady-state loops are branch-free (exact
+//     tile count as template parameter, clamped prefetch addresses, loaders with multiplies
+//     instead of branches) so that the compiler counts outstanding loads instead of falling
+//     back to s_waitcnt vmcnt(0).
+//   * B operand (activations): LDS.  Layer 0 streams its input in 32-channel chunks, double
+//     buffered, rows rotated by 4*(row/4) columns (conflict-free for both the row-gather
+//     writer and the fragment reader); later layers read the previous activation H[k][64].
+//   * a wave owns row tiles mt = wave, wave+NW, ... (<= NT) x 2 column tiles; accumulators
+//     start from the bias; after a layer relu(acc) goes back to H
+//     (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
+// Epilogue SA: max over the nsample columns of each centre (DPP), store point-major.
+// Epilogue FP: store point-major (intermediate levels) or (B, M, n) (the module's API layout).
 #include <cstdlib>
 
 #include "common.h"
@@ -41,6 +54,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int SM_COLS = 64;
 constexpr int SM_KC = 32;            // input channels per layer-0 chunk
+constexpr int SM_CP = SM_KC / 4;     // pairs per chunk = depth of the weight prefetch ring
 constexpr int SM_MAX_LAYERS = 4;
 constexpr int SM_MAX_MT = 16;        // M <= 512
 
@@ -52,30 +66,560 @@ struct MlpDesc {
   const float* bias[SM_MAX_LAYERS];  // [ceil(M/32)*32], zero padded
 };
 
-struct SaSrc {      // loader of the set-abstraction input: column = (centre j, sample s)
+struct RowSrc {       // point-major table: row r of frame b is tab[((size_t)b * rows + r) * ld ...]
+  const float* tab;
+  int rows, ld, width;   // width = channels taken from each row
+};
+
+struct SaSrc {        // set abstraction: column = (centre j, sample s); K = [feat.width][3 xyz]
   const float* xyz;       // (B, n, 3)
   const float* new_xyz;   // (B, m, 3)
-  const float* feat;      // (B, C, n) or null
+  RowSrc feat;
   const int* idx;         // (B, m, ns)
-  int n, m, ns, C, use_xyz;
+  int n, m, ns, use_xyz;
 };
 
-struct FpSrc {      // loader of the feature-propagation input: column = unknown point j
-  const float* known_feats;   // (B, C2, m)
-  const float* unknow_feats;  // (B, C1, n) or null
-  const int* idx;             // (B, n, 3)
-  const float* weight;        // (B, n, 3)
-  int n, m, C2, C1;
+struct FpSrc {        // feature propagation: column = unknown point; K = [known.width][unknown.width]
+  RowSrc known, unknown;
+  const int* idx;         // (B, n, 3)
+  const float* weight;    // (B, n, 3)
+  int n, m;
 };
 
-// ---- one layer on the matrix cores --------------------------------------------------------
-// acc tiles [t][ct]; Hin in LDS [K][64] (layer >= 1) or streamed in chunks (layer 0).
-// K is consumed in PAIRS of 32x32x2 steps (4 input channels): one 8-byte load per lane fetches
-// the A fragments of both steps of a row tile.  The loop is branch-free (exact tile count NTC,
-// clamped prefetch addresses, odd pair peeled after the loop) so that the compiler can count
-// outstanding loads -- with conditional loads in the loop it falls back to s_waitcnt vmcnt(0)
-// at the loop head and the prefetch is lost.  Two register sets, each refilled right after its
-// MFMAs issue (two pairs = 4 steps ahead of its next use).
+struct OutDesc {
+  float* out;
+  int point_major;        // 1: (B, points, ld) at channel offset coff; 0: (B, M, points)
+  int ld, coff;
+};
+
+// ---- XCD-aware workgroup -> (frame, column block) mapping ---------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs in linear-id order, each XCD with its own
+// 4 MB L2.  With the plain (x = column block, y = frame) grid every XCD touches every frame's
+// feature rows; here XCD x works through frames x, x+8, x+16, ... one after the other.
+__device__ __forceinline__ void xcd_frame_map(int& bi, int& bx) {
+  const int nb = gridDim.x, nf = gridDim.y;
+  bx = blockIdx.x;
+  bi = blockIdx.y;
+  if ((nf & 7) == 0) {
+    const unsigned lin = blockIdx.x + (unsigned)nb * blockIdx.y;
+    const unsigned q = lin >> 3;
+    bi = (int)(lin & 7) + 8 * (int)(q / nb);
+    bx = (int)(q % nb);
+  }
+}
+
+// ---- small helpers ------------------------------------------------------------------------
+// max over groups of ns (power of two <= 32) consecutive lanes with DPP row operations fused
+// into v_max_f32 (a ds_bpermute butterfly costs ~5x the MFMA time of a narrow chain).
+// ns <= 16: every lane of a group ends with the group max; ns == 32: lanes 16..31 / 48..63 do.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return fmaxf(v, __int_as_float(o));
+}
+__device__ __forceinline__ float seg_max(float v, int ns) {
+  if (ns >= 2) v = dpp_max<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  if (ns >= 4) v = dpp_max<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  if (ns >= 8) v = dpp_max<0x141, 0xF>(v);    // row_half_mirror
+  if (ns >= 16) v = dpp_max<0x140, 0xF>(v);   // row_mirror
+  if (ns >= 32) v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  return v;
+}
+__device__ __forceinline__ bool seg_leader(int col, int ns) {
+  return ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
+}
+
+// accumulator tile <- bias of its rows (C/D map: reg r holds row (r&3) + 8*(r>>2) + 4*half)
+__device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb /*tile's 32 biases, LDS*/,
+                                         int half) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(sb + 8 * g + 4 * half);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+}
+
+// all biases of the chain -> LDS (layer l at offset sum_{i<l} roundup32(M_i)); caller syncs
+__device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__ sb, int tid, int nthreads) {
+  int off = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int mp = ((d.M[l] + 31) >> 5) << 5;
+    for (int i = tid; i < mp; i += nthreads) sb[off + i] = d.bias[l][i];
+    off += mp;
+  }
+}
+
+// ---- MFMA spans ---------------------------------------------------------------------------
+// B fragment pair q of a [rows][64] LDS buffer: rows 4q + 2j + half, column tiles col, col+32.
+// SWZ: row r is stored rotated by (r & ~3) columns.
+template <bool SWZ>
+__device__ __forceinline__ void ld_b(float (&b)[2][2], const float* __restrict__ rows_half, int col, int q) {
+  const float* r0 = rows_half + q * 4 * SM_COLS;
+  if (SWZ) {
+    const int c0 = (col + 4 * q) & 63, c1 = c0 ^ 32;
+    b[0][0] = r0[c0]; b[0][1] = r0[c1];
+    b[1][0] = r0[2 * SM_COLS + c0]; b[1][1] = r0[2 * SM_COLS + c1];
+  } else {
+    b[0][0] = r0[col]; b[0][1] = r0[col + 32];
+    b[1][0] = r0[2 * SM_COLS + col]; b[1][1] = r0[2 * SM_COLS + col + 32];
+  }
+}
+
+template <int NTC, int NT>
+__device__ __forceinline__ void mm_pair(f32x16 (&acc)[NT][2], const float2 (&a)[NTC > 0 ? NTC : 1],
+                                        const float (&b)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) {
+    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0][0], acc[t][0], 0, 0, 0);
+    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0][1], acc[t][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) {
+    acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1][0], acc[t][0], 0, 0, 0);
+    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1][1], acc[t][1], 0, 0, 0);
+  }
+}
+
+struct WPtr {           // this lane's view of a layer's packed weights
+  const float2* wp;     // + wave*64 + lane
+  size_t pstride;       // float2 per pair = mt_total * 64
+  size_t tstride;       // float2 between this wave's row tiles = NW * 64
+  int last;             // last pair index of the layer
+};
+
+template <int NTC>
+__device__ __forceinline__ void ring_load(float2 (&slot)[NTC > 0 ? NTC : 1], const WPtr& w, int p) {
+  const float2* q = w.wp + (size_t)min(p, w.last) * w.pstride;
+#pragma unroll
+  for (int t = 0; t < NTC; ++t) slot[t] = q[(size_t)t * w.tstride];
+}
+
+// 8 pairs starting at global pair p0 (ring slot u holds pair p0+u), B rows from `rows_half`
+// (local pair 0 = first row of the buffer); refills every slot with the pair 8 ahead.
+template <int NTC, int NT, bool SWZ>
+__device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
+                                      const WPtr& w, int p0, const float* __restrict__ rows_half, int col) {
+  if (NTC == 0) return;
+  float b[2][2][2];
+  ld_b<SWZ>(b[0], rows_half, col, 0);
+#pragma unroll
+  for (int u = 0; u < SM_CP; ++u) {
+    if (u + 1 < SM_CP) ld_b<SWZ>(b[(u + 1) & 1], rows_half, col, u + 1);
+    mm_pair<NTC, NT>(acc, ring[u], b[u & 1]);
+    ring_load<NTC>(ring[u], w, p0 + SM_CP + u);
+  }
+}
+
+// the last np (< 8, possibly 0) pairs of a layer: no refill
+template <int NTC, int NT, bool SWZ>
+__device__ __forceinline__ void span_tail(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
+                                          int np, const float* __restrict__ rows_half, int col) {
+  if (NTC == 0) return;
+#pragma unroll
+  for (int u = 0; u < SM_CP - 1; ++u) {
+    if (u < np) {
+      float b[2][2];
+      ld_b<SWZ>(b, rows_half, col, u);
+      mm_pair<NTC, NT>(acc, ring[u], b);
+    }
+  }
+}
+
+// ---- layer-0 input loaders ------------------------------------------------------------------
+// LDS scratch shared by the loaders of one workgroup
+struct ColInfo {
+  int* id;          // [3][64] neighbour index per column (SA: row 0 only)
+  float* w;         // [3][64] interpolation weights (SA: row 0 = 1 for valid columns, else 0)
+  float* aux;       // [3][64] SA: centre coordinates; FP: row 0 = 1 for valid columns, else 0
+};
+
+// P loader: point-major row gather, thread e -> column e>>3, channels 4*(e&7)..+3 of the chunk.
+// NB neighbours, weights from LDS.  Issue = loads only; commit = combine + rotated LDS store.
+template <int NB, int PIT>
+struct PStage {
+  float4 v[PIT][NB];
+};
+
+template <int NB, int PIT, int NTHR>
+__device__ __forceinline__ void p_issue(PStage<NB, PIT>& st, const RowSrc& s, int bi, int cbase /*channel in source*/,
+                                        const int* __restrict__ ids /*[3][64] or null = identity*/,
+                                        int col0, int id_max, int tid) {
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int e = tid + NTHR * it;
+    const int colx = e >> 3, g4 = (e & 7) * 4;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int id = ids ? ids[k * 64 + colx] : min(col0 + colx, id_max);
+      st.v[it][k] = *reinterpret_cast<const float4*>(s.tab + ((size_t)bi * s.rows + id) * s.ld + cbase + g4);
+    }
+  }
+}
+
+template <int NB, int PIT, int NTHR>
+__device__ __forceinline__ void p_commit(const PStage<NB, PIT>& st, float* __restrict__ cbuf,
+                                         const float* __restrict__ ws /*[3][64] weights, LDS*/, int tid) {
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int e = tid + NTHR * it;
+    const int colx = e >> 3, g = e & 7;
+    float4 r;
+    {
+      const float w0 = ws[colx];
+      r.x = st.v[it][0].x * w0; r.y = st.v[it][0].y * w0; r.z = st.v[it][0].z * w0; r.w = st.v[it][0].w * w0;
+    }
+#pragma unroll
+    for (int k = 1; k < NB; ++k) {       // three_interpolate's order: p0*w0 + p1*w1 + p2*w2, unfused
+      const float wk = ws[k * 64 + colx];
+      r.x = r.x + st.v[it][k].x * wk; r.y = r.y + st.v[it][k].y * wk;
+      r.z = r.z + st.v[it][k].z * wk; r.w = r.w + st.v[it][k].w * wk;
+    }
+    float* dst = cbuf + (4 * g) * SM_COLS + ((colx + 4 * g) & 63);    // rows 4g..4g+3, rotation 4g
+    dst[0] = r.x; dst[SM_COLS] = r.y; dst[2 * SM_COLS] = r.z; dst[3 * SM_COLS] = r.w;
+  }
+}
+
+// C loader (generic, any channel): thread fills column lc = tid&63, rows lr0 + NW*i.
+template <bool IS_SA>
+__device__ __forceinline__ float c_load(const SaSrc& sa, const FpSrc& fp, const ColInfo& ci, int bi, int lc,
+                                        int gcol, bool cvalid, int c) {
+  if (!cvalid) return 0.f;
+  if (IS_SA) {
+    const int id = ci.id[lc];
+    if (c < sa.feat.width) return sa.feat.tab[((size_t)bi * sa.feat.rows + id) * sa.feat.ld + c];
+    const int k = c - sa.feat.width;
+    if (sa.use_xyz && k < 3)     // grouped_xyz -= new_xyz
+      return sa.xyz[((size_t)bi * sa.n + id) * 3 + k] - ci.aux[k * 64 + lc];
+    return 0.f;
+  } else {
+    if (c < fp.known.width) {
+      const float* t = fp.known.tab + (size_t)bi * fp.known.rows * fp.known.ld + c;
+      return t[(size_t)ci.id[lc] * fp.known.ld] * ci.w[lc] + t[(size_t)ci.id[64 + lc] * fp.known.ld] * ci.w[64 + lc] +
+             t[(size_t)ci.id[128 + lc] * fp.known.ld] * ci.w[128 + lc];
+    }
+    const int cu = c - fp.known.width;
+    if (cu < fp.unknown.width) return fp.unknown.tab[((size_t)bi * fp.unknown.rows + gcol) * fp.unknown.ld + cu];
+    return 0.f;
+  }
+}
+
+__device__ __forceinline__ void c_store(float* __restrict__ cbuf, int row, int lc, float v) {
+  cbuf[row * SM_COLS + ((lc + (row & ~3)) & 63)] = v;
+}
+
+// ---- one workgroup's chain ------------------------------------------------------------------
+// dynamic LDS: H [hrows][64] | chunk [2][32][64] | bias [bias_all] | id [3][64] | w [3][64] | aux [3][64]
+template <bool IS_SA, int NT, int NW>
+struct Chain {
+  static constexpr int NTHR = NW * 64;
+  static constexpr int LROWS = SM_KC / NW;
+  static constexpr int PIT = (SM_KC * SM_COLS / 4) / NTHR;   // float4 per thread per chunk
+  static constexpr int NBA = IS_SA ? 1 : 3;                  // neighbours of the first row source
+
+  const MlpDesc& d;
+  const SaSrc& sa;
+  const FpSrc& fp;
+  float* H;
+  float* chunk;
+  float* s_bias;
+  ColInfo ci;
+  int bi, col0, cols_total, tid, lane, wave;
+
+  // chunk kinds: [0, nA) P-gather from source A; [nA, nAB) P-gather from source B (FP unknown);
+  // the rest generic
+  int nA, nAB, n_chunks;
+
+  __device__ __forceinline__ const RowSrc& srcA() const { return IS_SA ? sa.feat : fp.known; }
+
+  template <int NTC>
+  __device__ __forceinline__ void layer0(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total) {
+    float2 ring[SM_CP][NTC > 0 ? NTC : 1];
+#pragma unroll
+    for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
+    const int lc = tid & 63, lr0 = tid >> 6;
+    const int gcol = col0 + lc;
+    const bool cvalid = gcol < cols_total;
+    const int half = lane >> 5, col = lane & 31;
+    const int id_max = IS_SA ? 0 : fp.n - 1;
+
+    // ---- prologue: chunk 0
+    if (nA > 0) {
+      PStage<NBA, PIT> st;
+      p_issue<NBA, PIT, NTHR>(st, srcA(), bi, 0, ci.id, col0, id_max, tid);
+      p_commit<NBA, PIT, NTHR>(st, chunk, ci.w, tid);
+    } else if (nAB > 0) {
+      PStage<1, PIT> st;
+      p_issue<1, PIT, NTHR>(st, fp.unknown, bi, 0, nullptr, col0, id_max, tid);
+      p_commit<1, PIT, NTHR>(st, chunk, ci.aux, tid);
+    } else {
+#pragma unroll
+      for (int i = 0; i < LROWS; ++i)
+        c_store(chunk, lr0 + NW * i, lc, c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, lr0 + NW * i));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      acc_bias(acc[t][0], s_bias + (wave + NW * t) * 32, half);
+      acc[t][1] = acc[t][0];
+    }
+
+    // ---- steady state: gather chunk g while chunk g-1 is multiplied
+    int g = 1;
+    for (; g < nA; ++g) {
+      PStage<NBA, PIT> st;
+      p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
+      span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+      p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.w, tid);
+      __syncthreads();
+    }
+    if (!IS_SA) {
+      for (; g < nAB; ++g) {
+        PStage<1, PIT> st;
+        p_issue<1, PIT, NTHR>(st, fp.unknown, bi, (g - nA) * SM_KC, nullptr, col0, id_max, tid);
+        span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+        p_commit<1, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.aux, tid);
+        __syncthreads();
+      }
+    }
+    for (; g < n_chunks; ++g) {
+      float stage[LROWS];
+#pragma unroll
+      for (int i = 0; i < LROWS; ++i)
+        stage[i] = c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, g * SM_KC + lr0 + NW * i);
+      span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+#pragma unroll
+      for (int i = 0; i < LROWS; ++i) c_store(chunk + (g & 1) * SM_KC * SM_COLS, lr0 + NW * i, lc, stage[i]);
+      __syncthreads();
+    }
+    // ---- last chunk
+    const int p0 = (n_chunks - 1) * SM_CP;
+    const int np = pairs_total - p0;       // 1..8
+    const float* rows_half = chunk + ((n_chunks - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS;
+    if (np == SM_CP)
+      span8<NTC, NT, true>(acc, ring, w, p0, rows_half, col);
+    else
+      span_tail<NTC, NT, true>(acc, ring, np, rows_half, col);
+  }
+
+  template <int NTC>
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int boff) {
+    float2 ring[SM_CP][NTC > 0 ? NTC : 1];
+#pragma unroll
+    for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, half);
+      acc[t][1] = acc[t][0];
+    }
+    const float* rows_half = H + half * SM_COLS;
+    int p0 = 0;
+    for (; p0 + SM_CP <= pairs_total; p0 += SM_CP)
+      span8<NTC, NT, false>(acc, ring, w, p0, rows_half + (size_t)p0 * 4 * SM_COLS, col);
+    span_tail<NTC, NT, false>(acc, ring, pairs_total - p0, rows_half + (size_t)p0 * 4 * SM_COLS, col);
+  }
+
+  __device__ __forceinline__ void run(const OutDesc& od) {
+    f32x16 acc[NT][2];
+    int boff = 0;
+    for (int l = 0; l < d.n_layers; ++l) {
+      const int K = d.K[l], M = d.M[l];
+      const int mt_total = (M + 31) >> 5;
+      const int nt = (mt_total - wave + NW - 1) / NW;     // row tiles of this wave (<= NT)
+      const int pairs_total = (K + 3) >> 2;
+      WPtr w;
+      w.wp = reinterpret_cast<const float2*>(d.W[l]) + (size_t)wave * 64 + lane;
+      w.pstride = (size_t)mt_total * 64;
+      w.tstride = (size_t)NW * 64;
+      w.last = pairs_total - 1;
+      if (l == 0) {
+        if (nt >= NT) layer0<NT>(acc, w, pairs_total);
+        else if (NT > 1 && nt == NT - 1) layer0<(NT > 1 ? NT - 1 : 0)>(acc, w, pairs_total);
+        else layer0<0>(acc, w, pairs_total);
+      } else {
+        if (nt >= NT) layerN<NT>(acc, w, pairs_total, boff);
+        else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0)>(acc, w, pairs_total, boff);
+      }
+      __syncthreads();   // every wave has finished reading this layer's input
+      boff += mt_total * 32;
+      if (l + 1 < d.n_layers) {
+        // rows [M, roundup32(M)) come out as relu(0 + 0) = 0 (zero-padded weights and bias), which
+        // covers the next layer's K rounded up to a multiple of 4
+        const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t < nt) {
+            const int mt = wave + NW * t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              H[row * SM_COLS + col] = fmaxf(acc[t][0][r], 0.f);
+              H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r], 0.f);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+
+    // ---- epilogue on the last layer's accumulators
+    const int L = d.n_layers - 1;
+    const int M = d.M[L];
+    const int mt_total = (M + 31) >> 5;
+    const int nt = (mt_total - wave + NW - 1) / NW;
+    const int half = lane >> 5, col = lane & 31;
+    float* const out = od.out;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+        const int mt = wave + NW * t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = mt * 32 + 8 * g + 4 * half;      // regs 4g..4g+3 = rows row..row+3
+          float v0[4], v1[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v0[k] = fmaxf(acc[t][0][4 * g + k], 0.f);
+            v1[k] = fmaxf(acc[t][1][4 * g + k], 0.f);
+          }
+          if (IS_SA) {
+            // max over the nsample consecutive columns of each centre (columns beyond cols_total
+            // hold relu(bias) of zero inputs and belong to centres >= m, never stored)
+            const int ns = sa.ns;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (ns > 32) v0[k] = fmaxf(v0[k], v1[k]);          // ns == 64: both tiles are one centre
+              v0[k] = seg_max(v0[k], ns);
+              if (ns <= 32) v1[k] = seg_max(v1[k], ns);
+            }
+            if (seg_leader(col, ns)) {
+              const int cb = ns >= 32 ? 0 : col;
+              const int j0 = (col0 + cb) / ns, j1 = (col0 + 32 + cb) / ns;
+              float* o0 = out + ((size_t)bi * sa.m + j0) * od.ld + od.coff + row;
+              float* o1 = out + ((size_t)bi * sa.m + j1) * od.ld + od.coff + row;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (row + k < M) {
+                  if (j0 < sa.m) o0[k] = v0[k];
+                  if (ns <= 32 && j1 < sa.m) o1[k] = v1[k];
+                }
+              }
+            }
+          } else {
+            const int g0 = col0 + col, g1 = col0 + 32 + col;
+            if (od.point_major) {
+              float* o0 = out + ((size_t)bi * fp.n + g0) * od.ld + od.coff + row;
+              float* o1 = out + ((size_t)bi * fp.n + g1) * od.ld + od.coff + row;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (row + k < M) {
+                  if (g0 < cols_total) o0[k] = v0[k];
+                  if (g1 < cols_total) o1[k] = v1[k];
+                }
+              }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (row + k < M) {
+                  if (g0 < cols_total) out[((size_t)bi * M + row + k) * fp.n + g0] = v0[k];
+                  if (g1 < cols_total) out[((size_t)bi * M + row + k) * fp.n + g1] = v1[k];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ bool row_src_vec_ok(const RowSrc& s) {
+  return s.tab != nullptr && (s.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(s.tab) & 15) == 0;
+}
+
+template <bool IS_SA, int NT, int NW>
+__device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int hrows,
+                                               int bias_all, int cols_total, const OutDesc& od) {
+  extern __shared__ float s_mem[];
+  float* H = s_mem;
+  float* chunk = H + (size_t)hrows * SM_COLS;
+  float* s_bias = chunk + 2 * SM_KC * SM_COLS;
+  ColInfo ci;
+  ci.id = reinterpret_cast<int*>(s_bias + bias_all);
+  ci.w = reinterpret_cast<float*>(ci.id + 3 * 64);
+  ci.aux = ci.w + 3 * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // scalar wave index: keeps every "does this wave own row tile t" test a uniform branch
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bi, bx;
+  xcd_frame_map(bi, bx);
+  const int col0 = bx * SM_COLS;
+
+  stage_bias(d, s_bias, tid, NW * 64);
+  if (tid < 64) {     // per-column gather info
+    const int gcol = col0 + tid;
+    const bool cvalid = gcol < cols_total;
+    if (IS_SA) {
+      int id = 0;
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      if (cvalid) {
+        id = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
+        const float* c = sa.new_xyz + ((size_t)bi * sa.m + gcol / sa.ns) * 3;
+        cx = c[0]; cy = c[1]; cz = c[2];
+      }
+      ci.id[tid] = id;
+      ci.w[tid] = cvalid ? 1.f : 0.f;
+      ci.aux[tid] = cx; ci.aux[64 + tid] = cy; ci.aux[128 + tid] = cz;
+    } else {
+      int i0 = 0, i1 = 0, i2 = 0;
+      float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+      if (cvalid) {
+        const int* ip = fp.idx + ((size_t)bi * fp.n + gcol) * 3;
+        const float* wp = fp.weight + ((size_t)bi * fp.n + gcol) * 3;
+        i0 = ip[0]; i1 = ip[1]; i2 = ip[2];
+        w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
+      }
+      ci.id[tid] = i0; ci.id[64 + tid] = i1; ci.id[128 + tid] = i2;
+      ci.w[tid] = w0; ci.w[64 + tid] = w1; ci.w[128 + tid] = w2;
+      ci.aux[tid] = cvalid ? 1.f : 0.f;       // "weight" of the unknown-feature rows
+    }
+  }
+  __syncthreads();
+
+  Chain<IS_SA, NT, NW> ch{d, sa, fp, H, chunk, s_bias, ci, bi, col0, cols_total, tid, lane, wave, 0, 0, 0};
+  ch.n_chunks = (d.K[0] + SM_KC - 1) / SM_KC;
+  if (IS_SA) {
+    ch.nA = row_src_vec_ok(sa.feat) ? sa.feat.width / SM_KC : 0;
+    ch.nAB = ch.nA;
+  } else {
+    ch.nA = row_src_vec_ok(fp.known) ? fp.known.width / SM_KC : 0;
+    ch.nAB = ch.nA;
+    if (ch.nA * SM_KC == fp.known.width && row_src_vec_ok(fp.unknown))
+      ch.nAB = ch.nA + fp.unknown.width / SM_KC;
+  }
+  ch.run(od);
+}
+
+template <bool IS_SA, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : 3)) void mlp_chain_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
+  mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, bias_all, cols_total, od);
+}
+
+// Two row tiles per wave (M > 256).
+template <bool IS_SA>
+__global__ __launch_bounds__(512) void mlp_chain_wide_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
+  mlp_chain_body<IS_SA, 2, 8>(d, sa, fp, hrows, bias_all, cols_total, od);
+}
+
+// ---------------------------------------------------------------------------------------
+// Narrow chains (every M <= 64): column-sliced variant.  A wave owns 32 columns and ALL row
+// tiles, keeps its own slice of the activations in LDS and gathers its own input chunk, so
+// there is no workgroup barrier after the bias staging -- with M <= 64 the row-split kernel
+// above leaves 2-3 of its 4 waves without a row tile.  Workgroup = 2 waves = 64 columns.
+// dynamic LDS: bias [bias_floats] | per wave: H [hrows][32] | chunk [32][32].
+// ---------------------------------------------------------------------------------------
 template <int NTC, int NT, int CT>
 __device__ __forceinline__ void mma_pairs(f32x16 (&acc)[NT][CT], const float2* __restrict__ wp,
                                           size_t tstride, size_t pstride,
@@ -117,275 +661,18 @@ __device__ __forceinline__ void mma_pairs(f32x16 (&acc)[NT][CT], const float2* _
 #undef SM_MM
 }
 
-// dispatch on the (wave-uniform) number of row tiles this wave owns
-template <int NT, int NW>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT][2], const float* __restrict__ Wp,
-                                          int mt_total, int wave, int nt, int pair_begin,
-                                          int pair_end, const float* __restrict__ Hrows /*row 4*pair_begin*/,
-                                          int lane) {
-  const float2* wp = reinterpret_cast<const float2*>(Wp) + ((size_t)pair_begin * mt_total + wave) * 64 + lane;
-  const float* hr = Hrows + (lane >> 5) * SM_COLS + (lane & 31);
-  const size_t pstride = (size_t)mt_total * 64;
-  const int pairs = pair_end - pair_begin;
-  if (nt >= NT) mma_pairs<NT, NT, 2>(acc, wp, (size_t)NW * 64, pstride, hr, SM_COLS, pairs);
-  else if constexpr (NT > 1) {
-    if (nt == NT - 1) mma_pairs<NT - 1, NT, 2>(acc, wp, (size_t)NW * 64, pstride, hr, SM_COLS, pairs);
-  }
-}
-
-// max over groups of ns (power of two <= 32) consecutive lanes with DPP row operations fused
-// into v_max_f32 (a ds_bpermute butterfly costs ~5x the MFMA time of a narrow chain).
-// ns <= 16: every lane of a group ends with the group max; ns == 32: lanes 16..31 / 48..63 do.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max(float v) {
-  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-  return fmaxf(v, __int_as_float(o));
-}
-__device__ __forceinline__ float seg_max(float v, int ns) {
-  if (ns >= 2) v = dpp_max<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
-  if (ns >= 4) v = dpp_max<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
-  if (ns >= 8) v = dpp_max<0x141, 0xF>(v);    // row_half_mirror
-  if (ns >= 16) v = dpp_max<0x140, 0xF>(v);   // row_mirror
-  if (ns >= 32) v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  return v;
-}
-__device__ __forceinline__ bool seg_leader(int col, int ns) {
-  return ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
-}
-
-// accumulator tile <- bias of its rows (C/D map: reg r holds row (r&3) + 8*(r>>2) + 4*half)
-__device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb /*tile's 32 biases, LDS*/,
-                                         int half) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 v = *reinterpret_cast<const float4*>(sb + 8 * g + 4 * half);
-    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
-  }
-}
-
-// all biases of the chain -> LDS (layer l at offset sum_{i<l} roundup32(M_i)); caller syncs
-__device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__ sb, int tid, int nthreads) {
-  int off = 0;
-  for (int l = 0; l < d.n_layers; ++l) {
-    const int mp = ((d.M[l] + 31) >> 5) << 5;
-    for (int i = tid; i < mp; i += nthreads) sb[off + i] = d.bias[l][i];
-    off += mp;
-  }
-}
-
-template <int NT, int NW>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NT][2], int wave, int nt,
-                                          float* __restrict__ H, int lane) {
-  const int half = lane >> 5, col = lane & 31;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt) {
-      const int mt = wave + NW * t;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        H[row * SM_COLS + col] = fmaxf(acc[t][0][r], 0.f);
-        H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r], 0.f);
-      }
-    }
-  }
-}
-
-// dynamic LDS: H [hrows][64] | chunk [2][32][64] | bias [sum roundup32(M_l)]
-template <bool IS_SA, int NT, int NW>
-__device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int hrows,
-                                               int cols_total, float* __restrict__ out) {
-  extern __shared__ float s_mem[];
-  float* H = s_mem;
-  float* chunk = s_mem + (size_t)hrows * SM_COLS;
-  float* s_bias = chunk + 2 * SM_KC * SM_COLS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  stage_bias(d, s_bias, tid, NW * 64);     // visible after the first barrier below
-  // scalar wave index: keeps every "does this wave own row tile t" test a uniform branch
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bi = blockIdx.y;
-  const int col0 = blockIdx.x * SM_COLS;
-
-  // ---- per-thread loader state: this thread fills column lc, rows lr0 + 4*i of every chunk
-  constexpr int LROWS = SM_KC / NW;   // chunk rows filled per thread
-  const int lc = tid & 63, lr0 = tid >> 6;
-  const int gcol = col0 + lc;
-  const bool cvalid = gcol < cols_total;
-  int id0 = 0, id1 = 0, id2 = 0;
-  float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-  size_t ctr = 0;      // offset of this column's centre in new_xyz
-  if (IS_SA) {
-    if (cvalid) {
-      id0 = sa.idx[(size_t)bi * sa.m * sa.ns + gcol];
-      ctr = ((size_t)bi * sa.m + gcol / sa.ns) * 3;
-    }
-  } else {
-    if (cvalid) {
-      const int* ip = fp.idx + ((size_t)bi * fp.n + gcol) * 3;
-      const float* wp = fp.weight + ((size_t)bi * fp.n + gcol) * 3;
-      id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
-      w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
-    }
-  }
-  // plain local copies: capturing the by-value kernel-argument structs by reference would pin
-  // them in scratch memory and turn every field access of the loader into a scratch load
-  const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
-  const float* const sa_nxyz = sa.new_xyz;
-  const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
-  const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
-  const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
-  auto load_input = [=](int c) -> float {   // value of input channel c for this thread's column
-#ifdef SM_EXP_NOGATHER
-    if (c >= 32) return 1.0f;
-#endif
-    if (!cvalid) return 0.f;
-    if (IS_SA) {
-      if (c < sa_c3) {
-        // grouped_xyz -= new_xyz (the centre is re-read: a select chain over three registers
-        // is turned into a scratch-array lookup by the compiler)
-        return sa_xyz[((size_t)bi * sa_n + id0) * 3 + c] - sa_nxyz[ctr + c];
-      }
-      const int cf = c - sa_c3;
-      return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
-    } else {
-      if (c < fp_C2) {
-        const float* row = fp_kf + ((size_t)bi * fp_C2 + c) * fp_m;
-        return row[id0] * w0 + row[id1] * w1 + row[id2] * w2;   // three_interpolate, unfused order
-      }
-      const int cu = c - fp_C2;
-      return cu < fp_C1 ? fp_uf[((size_t)bi * fp_C1 + cu) * fp_n + gcol] : 0.f;
-    }
-  };
-
-  f32x16 acc[NT][2];
-  int boff = 0;
-  for (int l = 0; l < d.n_layers; ++l) {
-    const int K = d.K[l], M = d.M[l];
-    const int mt_total = (M + 31) >> 5;
-    const int nt = (mt_total - wave + NW - 1) / NW;     // row tiles of this wave (<= NT)
-    const int pairs_total = (K + 3) >> 2;
-    if (l == 0) {
-      const int n_chunks = (K + SM_KC - 1) / SM_KC;
-      float stage[LROWS];
-#pragma unroll
-      for (int i = 0; i < LROWS; ++i) stage[i] = load_input(lr0 + NW * i);
-#pragma unroll
-      for (int i = 0; i < LROWS; ++i) chunk[(lr0 + NW * i) * SM_COLS + lc] = stage[i];
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < nt) {
-          acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, lane >> 5);
-          acc[t][1] = acc[t][0];
-        }
-      for (int ch = 0; ch < n_chunks; ++ch) {
-        const int buf = ch & 1;
-        const bool more = ch + 1 < n_chunks;
-        if (more) {
-#pragma unroll
-          for (int i = 0; i < LROWS; ++i) stage[i] = load_input((ch + 1) * SM_KC + lr0 + NW * i);
-        }
-        const int pb = ch * (SM_KC / 4);
-        const int pe = min(pb + SM_KC / 4, pairs_total);
-        mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, pb, pe, chunk + (size_t)buf * SM_KC * SM_COLS, lane);
-        if (more) {
-          float* cb = chunk + (size_t)(buf ^ 1) * SM_KC * SM_COLS;
-#pragma unroll
-          for (int i = 0; i < LROWS; ++i) cb[(lr0 + NW * i) * SM_COLS + lc] = stage[i];
-        }
-        __syncthreads();
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t < nt) {
-          acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, lane >> 5);
-          acc[t][1] = acc[t][0];
-        }
-      mma_chunk<NT, NW>(acc, d.W[l], mt_total, wave, nt, 0, pairs_total, H, lane);
-      __syncthreads();   // every wave has finished reading H_{l-1}
-    }
-    boff += mt_total * 32;
-    if (l + 1 < d.n_layers) {
-      store_act<NT, NW>(acc, wave, nt, H, lane);
-      // rows [M, roundup32(M)) were written as relu(0 + 0) = 0 (zero-padded weights and bias),
-      // which covers the next layer's K rounded up to a multiple of 4
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue on the last layer's accumulators
-  const int L = d.n_layers - 1;
-  const int M = d.M[L];
-  const int mt_total = (M + 31) >> 5;
-  const int nt = (mt_total - wave + NW - 1) / NW;
-  const int half = lane >> 5, col = lane & 31;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt) {
-      const int mt = wave + NW * t;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v0 = fmaxf(acc[t][0][r], 0.f), v1 = fmaxf(acc[t][1][r], 0.f);
-        if (IS_SA) {
-          // max over the nsample consecutive columns of each centre (columns beyond cols_total
-          // hold relu(bias) of zero inputs and belong to centres >= m, never stored)
-          const int ns = sa.ns;
-          if (ns > 32) v0 = fmaxf(v0, v1);              // ns == 64: both tiles are one centre
-          v0 = seg_max(v0, ns);
-          if (ns <= 32) v1 = seg_max(v1, ns);
-          if (row < M && seg_leader(col, ns)) {
-            const int cb = ns >= 32 ? 0 : col;
-            const int j0 = (col0 + cb) / ns, j1 = (col0 + 32 + cb) / ns;
-            if (j0 < sa.m) out[((size_t)bi * M + row) * sa.m + j0] = v0;
-            if (ns <= 32 && j1 < sa.m) out[((size_t)bi * M + row) * sa.m + j1] = v1;
-          }
-        } else {
-          if (row < M) {
-            const int g0 = col0 + col, g1 = col0 + 32 + col;
-            if (g0 < cols_total) out[((size_t)bi * M + row) * fp.n + g0] = v0;
-            if (g1 < cols_total) out[((size_t)bi * M + row) * fp.n + g1] = v1;
-          }
-        }
-      }
-    }
-  }
-}
-
-template <bool IS_SA, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : 3)) void mlp_chain_kernel(
-    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int cols_total, float* __restrict__ out) {
-  mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, cols_total, out);
-}
-
-// Two row tiles per wave (M > 256).
-template <bool IS_SA>
-__global__ __launch_bounds__(512) void mlp_chain_wide_kernel(
-    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int cols_total, float* __restrict__ out) {
-  mlp_chain_body<IS_SA, 2, 8>(d, sa, fp, hrows, cols_total, out);
-}
-
-// ---------------------------------------------------------------------------------------
-// Narrow layers (every M <= 128): column-sliced variant.  A wave owns 32 columns and ALL row
-// tiles (<= 4), keeps its own slice of the activations in LDS and gathers its own input
-// chunk, so there is no workgroup barrier anywhere -- with M <= 64 the row-split kernel above
-// leaves 2-3 of its 4 waves without a row tile.  Workgroup = 2 waves = 64 columns.
-// dynamic LDS: bias [bias_floats] | per wave: H [hrows][32] | chunk [32][32].
-// ---------------------------------------------------------------------------------------
 template <bool IS_SA, int NTR>
-__global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 2)))) void mlp_chain_cols_kernel(MlpDesc d, SaSrc sa, FpSrc fp,
-                                                             int hrows, int bias_floats,
-                                                             int cols_total,
-                                                             float* __restrict__ out) {
+__global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 2)))) void mlp_chain_cols_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_floats, int cols_total, OutDesc od) {
   extern __shared__ float s_mem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* s_bias = s_mem;
   float* H = s_mem + bias_floats + (size_t)wave * (hrows + SM_KC) * 32;
   float* chunk = H + (size_t)hrows * 32;
-  const int bi = blockIdx.y;
-  const int col0 = blockIdx.x * 64 + wave * 32;
+  int bi, bx;
+  xcd_frame_map(bi, bx);
+  const int col0 = bx * 64 + wave * 32;
   stage_bias(d, s_bias, tid, 128);
   __syncthreads();                         // the only barrier of this kernel
   if (col0 >= cols_total) return;          // wave-uniform
@@ -408,26 +695,28 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
     id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
     w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
   }
-  const float* const sa_xyz = sa.xyz; const float* const sa_feat = sa.feat;
-  const float* const sa_nxyz = sa.new_xyz;
-  const int sa_n = sa.n, sa_C = sa.C, sa_c3 = sa.use_xyz ? 3 : 0;
-  const float* const fp_kf = fp.known_feats; const float* const fp_uf = fp.unknow_feats;
-  const int fp_n = fp.n, fp_m = fp.m, fp_C2 = fp.C2, fp_C1 = fp.C1;
+  // plain local copies: capturing the by-value kernel-argument structs by reference would pin
+  // them in scratch memory and turn every field access of the loader into a scratch load
+  const float* const sa_xyz = sa.xyz; const float* const sa_nxyz = sa.new_xyz;
+  const float* const sa_row = sa.feat.tab ? sa.feat.tab + ((size_t)bi * sa.feat.rows + id0) * sa.feat.ld : nullptr;
+  const int sa_n = sa.n, sa_C = sa.feat.width, sa_c3 = sa.use_xyz ? 3 : 0;
+  const float* const kf = fp.known.tab ? fp.known.tab + (size_t)bi * fp.known.rows * fp.known.ld : nullptr;
+  const float* const uf_row =
+      fp.unknown.tab ? fp.unknown.tab + ((size_t)bi * fp.unknown.rows + min(gcol, fp.n - 1)) * fp.unknown.ld : nullptr;
+  const int k_ld = fp.known.ld, fp_C2 = fp.known.width, fp_C1 = fp.unknown.width;
   auto load_input = [=](int c) -> float {
     if (!cvalid) return 0.f;
     if (IS_SA) {
-      if (c < sa_c3) {
-        return sa_xyz[((size_t)bi * sa_n + id0) * 3 + c] - sa_nxyz[ctr + c];
-      }
-      const int cf = c - sa_c3;
-      return cf < sa_C ? sa_feat[((size_t)bi * sa_C + cf) * sa_n + id0] : 0.f;
+      if (c < sa_C) return sa_row[c];
+      const int k = c - sa_C;
+      // grouped_xyz -= new_xyz (the centre is re-read: a select chain over three registers
+      // is turned into a scratch-array lookup by the compiler)
+      return k < sa_c3 ? sa_xyz[((size_t)bi * sa_n + id0) * 3 + k] - sa_nxyz[ctr + k] : 0.f;
     } else {
-      if (c < fp_C2) {
-        const float* row = fp_kf + ((size_t)bi * fp_C2 + c) * fp_m;
-        return row[id0] * w0 + row[id1] * w1 + row[id2] * w2;
-      }
+      if (c < fp_C2)
+        return kf[(size_t)id0 * k_ld + c] * w0 + kf[(size_t)id1 * k_ld + c] * w1 + kf[(size_t)id2 * k_ld + c] * w2;
       const int cu = c - fp_C2;
-      return cu < fp_C1 ? fp_uf[((size_t)bi * fp_C1 + cu) * fp_n + gcol] : 0.f;
+      return cu < fp_C1 ? uf_row[cu] : 0.f;
     }
   };
 
@@ -490,6 +779,7 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
   const int L = d.n_layers - 1;
   const int M = d.M[L];
   const int mt_total = (M + 31) >> 5;
+  float* const out = od.out;
 #pragma unroll
   for (int t = 0; t < NTR; ++t) {
     if (t < mt_total) {
@@ -502,10 +792,11 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
           v = seg_max(v, ns);
           if (row < M && seg_leader(col, ns)) {
             const int j = (col0 + (ns >= 32 ? 0 : col)) / ns;
-            if (j < sa.m) out[((size_t)bi * M + row) * sa.m + j] = v;
+            if (j < sa.m) out[((size_t)bi * sa.m + j) * od.ld + od.coff + row] = v;
           }
         } else if (row < M && gcol < cols_total) {
-          out[((size_t)bi * M + row) * fp.n + gcol] = v;
+          if (od.point_major) out[((size_t)bi * fp.n + gcol) * od.ld + od.coff + row] = v;
+          else out[((size_t)bi * M + row) * fp.n + gcol] = v;
         }
       }
     }
@@ -514,27 +805,24 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
 
 template <bool IS_SA>
 int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
-                 float* out, hipStream_t st) {
-  int hrows = 2, max_mt = 1;
+                 const OutDesc& od, hipStream_t st) {
+  int hrows = 4, max_mt = 1, bias_all = 0;
   for (int l = 0; l < d.n_layers; ++l) {
-    if (l + 1 < d.n_layers) hrows = max(hrows, ((d.M[l] + 31) / 32) * 32 + 2);
+    if (l + 1 < d.n_layers) hrows = max(hrows, ((d.M[l] + 31) / 32) * 32);
     max_mt = max(max_mt, (d.M[l] + 31) / 32);
+    bias_all += ((d.M[l] + 31) / 32) * 32;
   }
   if (max_mt > SM_MAX_MT) return (int)hipErrorInvalidValue;
   const bool ns_ok = !IS_SA || sa.ns <= 32;
-  // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0:
-  // 0.82 -> 0.36 ms and 2.66 -> 1.86 ms) and loses for M = 128 with K >= 99 (every wave
-  // re-fetches all weight fragments): 1.4 -> 2.4 ms, so it is used for <= 2 row tiles only.
+  // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0) and
+  // loses for M = 128 with K >= 99 (every wave re-fetches all weight fragments), so it is
+  // used for <= 2 row tiles only.
   static const int cols_max_mt = [] {
     const char* e = getenv("PVN3D_MLP_COLS_MAX_MT");     // tuning override
     return e ? atoi(e) : 2;
   }();
   if (max_mt <= cols_max_mt && max_mt <= 4 && ns_ok) {   // narrow chain: column-sliced kernel
-    int hr = 2;
-    for (int l = 0; l + 1 < d.n_layers; ++l) hr = max(hr, ((d.M[l] + 31) / 32) * 32 + 2);
-    int bias_floats = 0;
-    for (int l = 0; l < d.n_layers; ++l) bias_floats += ((d.M[l] + 31) / 32) * 32;
-    const size_t lds2 = ((size_t)2 * (hr + SM_KC) * 32 + bias_floats) * sizeof(float);
+    const size_t lds2 = ((size_t)2 * (hrows + SM_KC) * 32 + bias_all) * sizeof(float);
     const dim3 grid2(pvn3d_ceil_div(cols_total, 64), b);
 #define SM_LAUNCH_COLS(NTR)                                                                    \
   do {                                                                                         \
@@ -543,16 +831,14 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                               (int)lds2));                                     \
-    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hr, bias_floats, cols_total, out); \
+    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hrows, bias_all, cols_total, od); \
   } while (0)
     if (max_mt <= 1) SM_LAUNCH_COLS(1); else if (max_mt <= 2) SM_LAUNCH_COLS(2); else SM_LAUNCH_COLS(4);
 #undef SM_LAUNCH_COLS
     PVN3D_LAUNCH_CHECK();
     return 0;
   }
-  int bias_all = 0;
-  for (int l = 0; l < d.n_layers; ++l) bias_all += ((d.M[l] + 31) / 32) * 32;
-  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all) * sizeof(float);
+  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all + 9 * 64) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
 #define SM_LAUNCH(KERN, NW)                                                                      \
@@ -562,7 +848,7 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                               (int)lds));                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, d, sa, fp, hrows, cols_total, out); \
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, d, sa, fp, hrows, bias_all, cols_total, od); \
   } while (0)
   // wide layers: 8 waves (two per SIMD hide each other's L2 / LDS waits), <= 2 row tiles each;
   // narrow layers (<= 4 row tiles): 4 waves, one row tile each
@@ -588,38 +874,78 @@ bool fill_desc(MlpDesc* d, int n_layers, const int* dims, const float* const* W,
   return true;
 }
 
+// (B, C, n) -> (B, n, ld) tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float* __restrict__ in,
+                                                           float* __restrict__ out, int ld_out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* src = in + (size_t)b * c * n;
+  float* dst = out + (size_t)b * n * ld_out;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int cc = c0 + ty + i, nn = n0 + tx;
+    tile[ty + i][tx] = (cc < c && nn < n) ? src[(size_t)cc * n + nn] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int nn = n0 + ty + i, cc = c0 + tx;
+    if (nn < n && cc < c) dst[(size_t)nn * ld_out + cc] = tile[tx][ty + i];
+  }
+}
+
 }  // namespace
 
 extern "C" int pvn3d_sa_mlp_maxpool(int b, int n, int m, int c, int nsample, int use_xyz,
                                     const float* xyz, const float* new_xyz,
-                                    const float* features, const int* idx, int n_layers,
-                                    const int* dims_host, const float* const* w_packed,
-                                    const float* const* bias_padded, float* out, void* stream) {
+                                    const float* features_pm, int ld_feat, const int* idx,
+                                    int n_layers, const int* dims_host,
+                                    const float* const* w_packed, const float* const* bias_padded,
+                                    float* out_pm, int ld_out, int out_coff, void* stream) {
   if (b <= 0 || m <= 0) return 0;
   if (nsample <= 0 || (nsample & (nsample - 1)) || nsample > 64 || !xyz || !new_xyz || !idx ||
-      !out || !dims_host || !w_packed || !bias_padded)
+      !out_pm || !dims_host || !w_packed || !bias_padded)
     return (int)hipErrorInvalidValue;
   MlpDesc d;
   if (!fill_desc(&d, n_layers, dims_host, w_packed, bias_padded)) return (int)hipErrorInvalidValue;
-  if (dims_host[0] != (use_xyz ? 3 : 0) + (features ? c : 0)) return (int)hipErrorInvalidValue;
-  SaSrc sa = {xyz, new_xyz, features, idx, n, m, nsample, features ? c : 0, use_xyz};
+  const int cf = features_pm ? c : 0;
+  if (dims_host[0] != (use_xyz ? 3 : 0) + cf) return (int)hipErrorInvalidValue;
+  if (cf > 0 && ld_feat < cf) return (int)hipErrorInvalidValue;
+  if (out_coff < 0 || ld_out < out_coff + dims_host[n_layers]) return (int)hipErrorInvalidValue;
+  SaSrc sa = {xyz, new_xyz, {cf > 0 ? features_pm : nullptr, n, ld_feat, cf}, idx, n, m, nsample, use_xyz};
   FpSrc fp = {};
-  return launch_chain<true>(d, sa, fp, b, m * nsample, out, (hipStream_t)stream);
+  OutDesc od = {out_pm, 1, ld_out, out_coff};
+  return launch_chain<true>(d, sa, fp, b, m * nsample, od, (hipStream_t)stream);
 }
 
-extern "C" int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_feats,
-                                   const float* unknow_feats, const int* idx,
-                                   const float* weight, int n_layers, const int* dims_host,
-                                   const float* const* w_packed, const float* const* bias_padded,
-                                   float* out, void* stream) {
+extern "C" int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_pm,
+                                   int ld_known, const float* unknown_pm, int ld_unknown,
+                                   const int* idx, const float* weight, int n_layers,
+                                   const int* dims_host, const float* const* w_packed,
+                                   const float* const* bias_padded, float* out,
+                                   int out_point_major, int ld_out, void* stream) {
   if (b <= 0 || n <= 0) return 0;
-  if (!known_feats || !idx || !weight || !out || !dims_host || !w_packed || !bias_padded ||
-      (c1 > 0 && !unknow_feats))
+  if (!known_pm || !idx || !weight || !out || !dims_host || !w_packed || !bias_padded ||
+      (c1 > 0 && !unknown_pm) || ld_known < c2 || (c1 > 0 && ld_unknown < c1))
     return (int)hipErrorInvalidValue;
   MlpDesc d;
   if (!fill_desc(&d, n_layers, dims_host, w_packed, bias_padded)) return (int)hipErrorInvalidValue;
   if (dims_host[0] != c2 + c1) return (int)hipErrorInvalidValue;
+  if (out_point_major && ld_out < dims_host[n_layers]) return (int)hipErrorInvalidValue;
   SaSrc sa = {};
-  FpSrc fp = {known_feats, unknow_feats, idx, weight, n, m, c2, c1};
-  return launch_chain<false>(d, sa, fp, b, n, out, (hipStream_t)stream);
+  FpSrc fp = {{known_pm, m, ld_known, c2}, {c1 > 0 ? unknown_pm : nullptr, n, ld_unknown, c1}, idx, weight, n, m};
+  OutDesc od = {out, out_point_major ? 1 : 0, ld_out, 0};
+  return launch_chain<false>(d, sa, fp, b, n, od, (hipStream_t)stream);
+}
+
+extern "C" int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out, int ld_out,
+                                          void* stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  if (!in || !out || ld_out < c) return (int)hipErrorInvalidValue;
+  const dim3 grid(pvn3d_ceil_div(n, 32), pvn3d_ceil_div(c, 32), b);
+  hipLaunchKernelGGL(transpose_cn_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, in, out, ld_out);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
 }

@@ -2,6 +2,8 @@
 module tree (pvn3d/lib/pvn3d.py:46-154: 4 multi-scale set-abstraction levels, 4 feature
 propagation levels), built from this package's SA/FP modules.  Only this class of
 lib/pvn3d.py is on the hot path; the CNN, DenseFusion and heads are out of scope."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -12,7 +14,7 @@ from .pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPMo
 # latency-bound (one workgroup per frame for FPS), so they run ahead on a second HIP stream
 # while the MFMA kernels of the previous level occupy the matrix cores; the feature path waits
 # on one event per level.  False keeps everything on the caller's stream.
-GEOMETRY_STREAM = True
+GEOMETRY_STREAM = os.environ.get("PVN3D_GEOMETRY_STREAM", "1") != "0"
 _geo_streams = {}
 
 
@@ -50,6 +52,11 @@ class Pointnet2MSG(nn.Module):
         self.FP_modules.append(PointnetFPModule(mlp=[512 + c_out_1, 512, 512]))
         self.FP_modules.append(PointnetFPModule(mlp=[c_out_3 + c_out_2, 512, 512]))
 
+        # inference: intermediate FP levels hand point-major buffers (as transposed views) to the
+        # next level; the last one (FP_modules[0]) returns the reference's contiguous (B, 128, N)
+        for fp in list(self.FP_modules)[1:]:
+            fp._point_major_out = True
+
     @staticmethod
     def _break_up_pc(pc):
         xyz = pc[..., 0:3].contiguous()
@@ -85,6 +92,8 @@ class Pointnet2MSG(nn.Module):
     def forward(self, pointcloud):
         """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N)."""
         xyz, features = self._break_up_pc(pointcloud)
+        if features is not None and not self.training and _pm.FUSED_INFERENCE and not torch.is_grad_enabled():
+            features = pointcloud[..., 3:].transpose(1, 2)   # same values, point-major in place
         ahead = (GEOMETRY_STREAM and _pm.FUSED_INFERENCE and not self.training and xyz.is_cuda
                  and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]

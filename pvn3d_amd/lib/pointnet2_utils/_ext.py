@@ -248,51 +248,94 @@ def group_xyz_features(xyz, new_xyz, features, idx, use_xyz=True):
     return out
 
 
-def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed):
+def _point_major(t):
+    """(B, C, n) tensor -> (base tensor, ld) of a point-major (B, n, ld) table holding it.
+    Zero-copy when `t` already is a transposed view of a point-major buffer (what the fused
+    modules hand to each other, and what `pc[..., 3:].transpose(1, 2)` is); otherwise one
+    tiled transpose (csrc/sa_mlp.hip)."""
+    B, C, n = t.shape
+    if t.stride(1) == 1 and t.stride(2) >= C and t.stride(0) == n * t.stride(2):
+        return t, t.stride(2)
+    src = t if t.is_contiguous() else t.contiguous()
+    ld = (C + 3) // 4 * 4
+    out = torch.empty((B, n, ld), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.pvn3d_transpose_bcn_to_bnc(B, C, n, src.data_ptr(), out.data_ptr(), ld, _stream(t)),
+              "transpose_bcn_to_bnc")
+    return out, ld
+
+
+def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, out_coff=0):
     """Fused group -> SharedMLP (BN folded, fp32 MFMA) -> max over nsample, inference only.
-    packed: _fused_mlp.PackedMLP.  Returns (B, packed.dims[-1], npoint)."""
+    packed: _fused_mlp.PackedMLP built with n_xyz_first=3 when use_xyz.  features: (B, C, n) in
+    any layout (a transposed view of a point-major buffer is used in place).  Writes the
+    packed.dims[-1] pooled channels into the point-major buffer out_pm (B, npoint, ld) at channel
+    offset out_coff (allocated if None) and returns the (B, packed.dims[-1], npoint) VIEW of it."""
     _chk(xyz, "xyz", torch.float32)
     _chk(new_xyz, "new_xyz", torch.float32)
     _chk(idx, "idx", torch.int32)
     _same_dev(xyz, new_xyz, "new_xyz")
     _same_dev(xyz, idx, "idx")
-    C = 0
+    C, feat, ld_feat = 0, None, 0
     if features is not None:
-        _chk(features, "features", torch.float32)
+        if not features.is_cuda:
+            raise RuntimeError("CPU not supported")
+        if features.dtype != torch.float32:
+            raise RuntimeError("features must be a float tensor")
         _same_dev(xyz, features, "features")
         C = features.size(1)
+        feat, ld_feat = _point_major(features)
     B, N = xyz.size(0), xyz.size(1)
     m, nsample = idx.size(1), idx.size(2)
-    out = torch.empty((B, packed.dims[-1], m), dtype=torch.float32, device=xyz.device)
+    M = packed.dims[-1]
+    if out_pm is None:
+        out_pm = torch.empty((B, m, (M + 3) // 4 * 4), dtype=torch.float32, device=xyz.device)
+        out_coff = 0
+    ld_out = out_pm.size(2)
     with torch.cuda.device(xyz.device):
         check(lib.pvn3d_sa_mlp_maxpool(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
-                                       new_xyz.data_ptr(),
-                                       features.data_ptr() if features is not None else None,
-                                       idx.data_ptr(), packed.n_layers, packed.dims_c, packed.w_c,
-                                       packed.b_c, out.data_ptr(), _stream(xyz)), "sa_mlp_maxpool")
-    return out
+                                       new_xyz.data_ptr(), feat.data_ptr() if feat is not None else None,
+                                       ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, packed.w_c,
+                                       packed.b_c, out_pm.data_ptr(), ld_out, out_coff, _stream(xyz)),
+              "sa_mlp_maxpool")
+    return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
 
 
-def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed):
+def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_out=False):
     """Fused three_interpolate ++ unknow_feats -> SharedMLP (BN folded, fp32 MFMA), inference
-    only.  Returns (B, packed.dims[-1], n)."""
-    _chk(known_feats, "known_feats", torch.float32)
+    only.  known_feats (B, C2, m), unknow_feats (B, C1, n) in any layout (see _point_major).
+    Returns (B, packed.dims[-1], n): contiguous, or with point_major_out a transposed view of a
+    (B, n, M) buffer (what the next fused level gathers from)."""
+    if not known_feats.is_cuda:
+        raise RuntimeError("CPU not supported")
+    if known_feats.dtype != torch.float32:
+        raise RuntimeError("known_feats must be a float tensor")
     _chk(idx, "idx", torch.int32)
     _chk(weight, "weight", torch.float32)
     _same_dev(known_feats, idx, "idx")
     _same_dev(known_feats, weight, "weight")
-    C1 = 0
-    if unknow_feats is not None:
-        _chk(unknow_feats, "unknow_feats", torch.float32)
-        _same_dev(known_feats, unknow_feats, "unknow_feats")
-        C1 = unknow_feats.size(1)
     B, C2, m = known_feats.shape
     n = idx.size(1)
-    out = torch.empty((B, packed.dims[-1], n), dtype=torch.float32, device=known_feats.device)
+    kf, ld_k = _point_major(known_feats)
+    C1, uf, ld_u = 0, None, 0
+    if unknow_feats is not None:
+        if unknow_feats.dtype != torch.float32:
+            raise RuntimeError("unknow_feats must be a float tensor")
+        _same_dev(known_feats, unknow_feats, "unknow_feats")
+        C1 = unknow_feats.size(1)
+        uf, ld_u = _point_major(unknow_feats)
+    M = packed.dims[-1]
+    if point_major_out:
+        ld_out = (M + 3) // 4 * 4
+        out = torch.empty((B, n, ld_out), dtype=torch.float32, device=known_feats.device)
+    else:
+        ld_out = 0
+        out = torch.empty((B, M, n), dtype=torch.float32, device=known_feats.device)
     with torch.cuda.device(known_feats.device):
-        check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, known_feats.data_ptr(),
-                                      unknow_feats.data_ptr() if unknow_feats is not None else None,
+        check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
+                                      uf.data_ptr() if uf is not None else None, ld_u,
                                       idx.data_ptr(), weight.data_ptr(), packed.n_layers,
                                       packed.dims_c, packed.w_c, packed.b_c, out.data_ptr(),
+                                      1 if point_major_out else 0, ld_out,
                                       _stream(known_feats)), "fp_interp_mlp")
-    return out
+    return out[:, :, :M].transpose(1, 2) if point_major_out else out

@@ -63,12 +63,15 @@ def _fold(layer):
     return W, b
 
 
-def pack_shared_mlp(mlp, max_width=512):
-    """SharedMLP -> PackedMLP (cached on the module until a parameter/buffer changes), or None."""
+def pack_shared_mlp(mlp, max_width=512, n_xyz_first=0):
+    """SharedMLP -> PackedMLP (cached on the module until a parameter/buffer changes), or None.
+    n_xyz_first: the first n_xyz_first input channels of layer 0 (the reference puts the relative
+    xyz in front of the features, pointnet2_utils.py:319-321) are moved behind the features,
+    the channel order pvn3d_sa_mlp_maxpool gathers in."""
     sig = []
     for t in list(mlp.parameters()) + list(mlp.buffers()):
         sig.append((t.data_ptr(), t._version))
-    sig = (tuple(sig), mlp.training)
+    sig = (tuple(sig), mlp.training, n_xyz_first)
     cache = getattr(mlp, "_pvn3d_packed", None)
     if cache is not None and cache[0] == sig:
         return cache[1]
@@ -87,7 +90,9 @@ def pack_shared_mlp(mlp, max_width=512):
         mlp._pvn3d_packed = (sig, None)
         return None
     w_list, b_list = [], []
-    for W, b in folded:
+    for li, (W, b) in enumerate(folded):
+        if li == 0 and n_xyz_first:
+            W = torch.cat([W[:, n_xyz_first:], W[:, :n_xyz_first]], dim=1)
         w_list.append(_pack_weight(W))
         M = W.shape[0]
         bp = torch.zeros(((M + 31) // 32) * 32, dtype=torch.float32, device=W.device)

@@ -92,17 +92,13 @@ class _PointnetSAModuleBase(nn.Module):
         fuse = (FUSED_INFERENCE and not self.training and self.npoint is not None and xyz.is_cuda
                 and _no_grad_needed(xyz, features)
                 and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters()))
+        if fuse:
+            out = self._forward_fused(xyz, new_xyz, features, idxs)
+            if out is not None:
+                return new_xyz, out
+        if features is not None and not features.is_contiguous():
+            features = features.contiguous()       # a point-major view from a fused producer
         for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
-            if fuse and isinstance(grouper, pointnet2_utils.QueryAndGroup):
-                ns = grouper.nsample
-                packed = _fused_mlp.pack_shared_mlp(mlp) if (ns & (ns - 1)) == 0 and ns <= 64 else None
-                if packed is not None:
-                    if idx is None:
-                        with _stage("ball_query"):
-                            idx = pointnet2_utils.ball_query(grouper.radius, ns, xyz, new_xyz)
-                    with _stage("sa_mlp"):
-                        pooled.append(_ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed))
-                    continue
             if idx is not None:
                 grouped = grouper(xyz, new_xyz, features, idx=idx)
             else:
@@ -111,6 +107,38 @@ class _PointnetSAModuleBase(nn.Module):
             feats = F.max_pool2d(feats, kernel_size=[1, feats.size(3)]).squeeze(-1)
             pooled.append(feats)
         return new_xyz, torch.cat(pooled, dim=1)
+
+    def _forward_fused(self, xyz, new_xyz, features, idxs):
+        """Every scale as one fp32-MFMA kernel writing its slice of ONE point-major
+        (B, npoint, sum(mlp[-1])) buffer; returns its (B, C_out, npoint) transposed view (same
+        values as torch.cat(pooled, 1); the next fused level gathers rows from it in place), or
+        None when a scale cannot be fused."""
+        packs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            if not isinstance(grouper, pointnet2_utils.QueryAndGroup):
+                return None
+            ns = grouper.nsample
+            if (ns & (ns - 1)) != 0 or ns > 64:
+                return None
+            packed = _fused_mlp.pack_shared_mlp(mlp, n_xyz_first=3 if (grouper.use_xyz and features is not None) else 0)
+            if packed is None:
+                return None
+            packs.append(packed)
+        widths = [p.dims[-1] for p in packs]
+        offs = [0]
+        for w in widths:
+            offs.append(offs[-1] + (w + 3) // 4 * 4)      # 16-byte aligned slices
+        if any((w & 3) for w in widths[:-1]):
+            return None                                     # slices would not be contiguous channels
+        total = offs[-1]
+        out_pm = torch.empty((xyz.size(0), new_xyz.size(1), total), dtype=torch.float32, device=xyz.device)
+        for grouper, packed, idx, off in zip(self.groupers, packs, idxs, offs):
+            if idx is None:
+                with _stage("ball_query"):
+                    idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            with _stage("sa_mlp"):
+                _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
+        return out_pm[:, :, :sum(widths)].transpose(1, 2)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):
@@ -168,10 +196,10 @@ class PointnetFPModule(nn.Module):
                     and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters())):
                 packed = _fused_mlp.pack_shared_mlp(self.mlp)
                 if packed is not None:
-                    uf = unknow_feats.contiguous() if unknow_feats is not None else None
                     with _stage("fp_mlp"):
-                        return _ext.fp_interp_mlp(known_feats.contiguous(), uf, idx, weight.contiguous(), packed)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+                        return _ext.fp_interp_mlp(known_feats, unknow_feats, idx, weight.contiguous(), packed,
+                                                  point_major_out=getattr(self, "_point_major_out", False))
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
         if unknow_feats is not None:

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_msg
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_msg -o msg --output-format csv -- \
+PVN3D_GEOMETRY_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_msg -o msg --output-format csv -- \
   python $R/tools/bench_ops.py --ops msg --reps 2 > /tmp/prof_msg.log 2>&1
 tail -3 /tmp/prof_msg.log
 find /tmp/prof_msg -name "*.csv" | head
