@@ -131,26 +131,67 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
     const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride) {
   extern __shared__ float s_row[];  // [CPB][n]
   const int tid = threadIdx.x;
-  const int bi = blockIdx.z;
-  const int c0 = blockIdx.y * CPB;
+  // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in
+  // linear-id order; keep every workgroup of a cloud on one XCD so that the cloud's idx array,
+  // re-read once per CPB channels, is fetched from HBM once instead of once per XCD.
+  int bi = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+  if ((gridDim.z & 7) == 0) {
+    const unsigned per = gridDim.x * gridDim.y;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned q = lin >> 3, w = q % per;
+    bi = (int)(lin & 7) + 8 * (int)(q / per);
+    by = (int)(w / gridDim.x);
+    bx = (int)(w % gridDim.x);
+  }
+  const int c0 = by * CPB;
   const int nc = min(CPB, c - c0);
   const int n4 = n >> 2;
   const float4* row = reinterpret_cast<const float4*>(points + ((size_t)bi * c + c0) * n);
   float4* s4 = reinterpret_cast<float4*>(s_row);
   for (int q = tid; q < nc * n4; q += 256) s4[q] = row[q];
   __syncthreads();
-  const int p_begin = blockIdx.x * pchunk;
+  const int p_begin = bx * pchunk;
   const int p_end = min(p_begin + pchunk, P);
   const int* ip = idx + (size_t)bi * P;
   float* o = out + (size_t)bi * out_batch_stride + (size_t)c0 * P;
-  for (int p = p_begin + tid * 4; p < p_end; p += 1024) {
-    const int4 id = *reinterpret_cast<const int4*>(ip + p);
+  // idx is loaded one iteration ahead: gfx950 counts loads and stores in the same in-order
+  // vmcnt, so waiting for an idx load issued AFTER the previous iteration's stores would wait
+  // for their write acknowledgements too; issued before them it only needs vmcnt(#stores).
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  int p = p_begin + tid * 4;
+  int4 id = *reinterpret_cast<const int4*>(ip + min(p, P - 4));
+  if (nc == CPB) {
+    // Full row group: the next idx vector is requested BEFORE this iteration's stores and awaited
+    // after them with s_waitcnt vmcnt(CPB) -- loads and stores share one in-order counter on
+    // gfx950, so "CPB younger operations may be outstanding" is exactly "the idx load has
+    // landed, the CPB stores need not have".  The compiler's own bookkeeping merges the loop
+    // entry state into the loop and would wait for the stores' acknowledgements every
+    // iteration (vmcnt(1)); hence the load and the wait are issued by hand.
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i idv = {id.x, id.y, id.z, id.w};
+    while (p < p_end) {
+      const int pn = p + 1024;
+      const int* nptr = ip + min(pn, P - 4);
+      v4i idn;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(idn) : "v"(nptr) : "memory");
 #pragma unroll
-    for (int u = 0; u < CPB; ++u) {
-      if (u < nc) {
+      for (int u = 0; u < CPB; ++u) {
         const float* sr = s_row + u * n;
-        *reinterpret_cast<float4*>(o + (size_t)u * P + p) =
-            make_float4(sr[id.x], sr[id.y], sr[id.z], sr[id.w]);
+        v4f val = {sr[idv.x], sr[idv.y], sr[idv.z], sr[idv.w]};
+        // streaming output: written once, never re-read by this kernel
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (size_t)u * P + p));
+      }
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(idn) : "n"(CPB) : "memory");
+      idv = idn;
+      p = pn;
+    }
+  } else {
+    for (; p < p_end; p += 1024) {
+      id = *reinterpret_cast<const int4*>(ip + p);
+      for (int u = 0; u < nc; ++u) {
+        const float* sr = s_row + u * n;
+        v4f val = {sr[id.x], sr[id.y], sr[id.z], sr[id.w]};
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (size_t)u * P + p));
       }
     }
   }

@@ -606,6 +606,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : 3)) void mlp_
   mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, bias_all, cols_total, od);
 }
 
+// Two row tiles per wave, 4 waves (128 < M <= 256): every wave owns a tile of a 128-wide layer,
+// where the 8-wave kernel above leaves half of its waves without MFMA work.
+template <bool IS_SA>
+__global__ __launch_bounds__(256, 2) void mlp_chain_mid_kernel(
+    MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
+  mlp_chain_body<IS_SA, 2, 4>(d, sa, fp, hrows, bias_all, cols_total, od);
+}
+
 // Two row tiles per wave (M > 256).
 template <bool IS_SA>
 __global__ __launch_bounds__(512) void mlp_chain_wide_kernel(
@@ -852,7 +860,12 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   } while (0)
   // wide layers: 8 waves (two per SIMD hide each other's L2 / LDS waits), <= 2 row tiles each;
   // narrow layers (<= 4 row tiles): 4 waves, one row tile each
+  static const int mid_kernel = [] {
+    const char* e = getenv("PVN3D_MLP_MID");             // tuning override: 0 = 8-wave kernel
+    return e ? atoi(e) : 1;
+  }();
   if (max_mt <= 4) SM_LAUNCH((mlp_chain_kernel<IS_SA, 4>), 4);
+  else if (max_mt <= 8 && mid_kernel) SM_LAUNCH((mlp_chain_mid_kernel<IS_SA>), 4);
   else if (max_mt <= 8) SM_LAUNCH((mlp_chain_kernel<IS_SA, 8>), 8);
   else SM_LAUNCH((mlp_chain_wide_kernel<IS_SA>), 8);
 #undef SM_LAUNCH
