@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpvn3d_hip.so")
+# PVN3D_HIP_LIB: alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("PVN3D_HIP_LIB") or os.path.join(_HERE, "libpvn3d_hip.so")
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

@@ -45,8 +45,24 @@
 // Epilogue SA: max over the nsample columns of each centre (DPP), store point-major.
 // Epilogue FP: store point-major (intermediate levels) or (B, M, n) (the module's API layout).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
+
+#ifdef SM_PROBE
+// cycle stamps per phase of the first workgroups of a launch (tuning builds only, tools/mlp_probe.py)
+__device__ unsigned long long g_sm_probe[64 * 16];
+#define SM_STAMP(i)                                                                  \
+  do {                                                                               \
+    if (tid == 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < 64)                 \
+      g_sm_probe[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int pvn3d_debug_mlp_probe_read(unsigned long long* host64x16) {
+  return (int)hipMemcpyFromSymbol(host64x16, HIP_SYMBOL(g_sm_probe), sizeof(unsigned long long) * 64 * 16);
+}
+#else
+#define SM_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -112,21 +128,29 @@ __device__ __forceinline__ void xcd_frame_map(int& bi, int& bx) {
 // max over groups of ns (power of two <= 32) consecutive lanes with DPP row operations fused
 // into v_max_f32 (a ds_bpermute butterfly costs ~5x the MFMA time of a narrow chain).
 // ns <= 16: every lane of a group ends with the group max; ns == 32: lanes 16..31 / 48..63 do.
+// The values pooled here are post-ReLU (>= +0, never NaN), so float max == signed-integer max
+// of the bit patterns: v_max_i32 needs no NaN canonicalisation and fuses with the DPP move.
+// NS is a template parameter: with a run-time nsample every step of every call is a uniform
+// branch, and the ~640 branches of a two-tile epilogue cost more than a quarter of the whole
+// workgroup's time (measured with the SM_PROBE stamps).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max(float v) {
-  const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-  return fmaxf(v, __int_as_float(o));
+__device__ __forceinline__ int dpp_imax(int v) {
+  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+  return max(v, o);
 }
-__device__ __forceinline__ float seg_max(float v, int ns) {
-  if (ns >= 2) v = dpp_max<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
-  if (ns >= 4) v = dpp_max<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
-  if (ns >= 8) v = dpp_max<0x141, 0xF>(v);    // row_half_mirror
-  if (ns >= 16) v = dpp_max<0x140, 0xF>(v);   // row_mirror
-  if (ns >= 32) v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  return v;
+__device__ __forceinline__ float seg_max_n(float vf, int ns) {    // ns <= 32
+  int v = __float_as_int(vf);
+  if (ns >= 2) v = dpp_imax<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  if (ns >= 4) v = dpp_imax<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  if (ns >= 8) v = dpp_imax<0x141, 0xF>(v);    // row_half_mirror
+  if (ns >= 16) v = dpp_imax<0x140, 0xF>(v);   // row_mirror
+  if (ns >= 32) v = dpp_imax<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  return __int_as_float(v);
 }
-__device__ __forceinline__ bool seg_leader(int col, int ns) {
-  return ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
+// NS > 0: compile-time nsample (the shapes PVN3D uses); NS == 0: any power of two, run time
+template <int NS>
+__device__ __forceinline__ float seg_max(float vf, int ns_rt) {
+  return seg_max_n(vf, NS > 0 ? (NS > 32 ? 32 : NS) : (ns_rt > 32 ? 32 : ns_rt));
 }
 
 // accumulator tile <- bias of its rows (C/D map: reg r holds row (r&3) + 8*(r>>2) + 4*half)
@@ -204,9 +228,13 @@ __device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP
   ld_b<SWZ>(b[0], rows_half, col, 0);
 #pragma unroll
   for (int u = 0; u < SM_CP; ++u) {
+    // keep this order (fences): left alone, the scheduler sinks every LDS read to just before its
+    // MFMA (exposing the LDS latency once per pair) and bunches the refills at the chunk end
     if (u + 1 < SM_CP) ld_b<SWZ>(b[(u + 1) & 1], rows_half, col, u + 1);
+    __builtin_amdgcn_sched_barrier(0);
     mm_pair<NTC, NT>(acc, ring[u], b[u & 1]);
     ring_load<NTC>(ring[u], w, p0 + SM_CP + u);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -367,10 +395,16 @@ struct Chain {
     int g = 1;
     for (; g < nA; ++g) {
       PStage<NBA, PIT> st;
+#ifdef SM_EXP_NOGATHER
+      for (int it = 0; it < PIT; ++it) for (int k = 0; k < NBA; ++k) st.v[it][k] = make_float4(1.f, 2.f, 3.f, 4.f);
+#else
       p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
+#endif
       span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
       p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.w, tid);
+#ifndef SM_EXP_NOBARRIER
       __syncthreads();
+#endif
     }
     if (!IS_SA) {
       for (; g < nAB; ++g) {
@@ -422,6 +456,7 @@ struct Chain {
   __device__ __forceinline__ void run(const OutDesc& od) {
     f32x16 acc[NT][2];
     int boff = 0;
+    SM_STAMP(0);
     for (int l = 0; l < d.n_layers; ++l) {
       const int K = d.K[l], M = d.M[l];
       const int mt_total = (M + 31) >> 5;
@@ -441,6 +476,7 @@ struct Chain {
         else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0)>(acc, w, pairs_total, boff);
       }
       __syncthreads();   // every wave has finished reading this layer's input
+      SM_STAMP(1 + 2 * l);
       boff += mt_total * 32;
       if (l + 1 < d.n_layers) {
         // rows [M, roundup32(M)) come out as relu(0 + 0) = 0 (zero-padded weights and bias), which
@@ -459,6 +495,7 @@ struct Chain {
           }
         }
         __syncthreads();
+        SM_STAMP(2 + 2 * l);
       }
     }
 
@@ -484,15 +521,25 @@ struct Chain {
           }
           if (IS_SA) {
             // max over the nsample consecutive columns of each centre (columns beyond cols_total
-            // hold relu(bias) of zero inputs and belong to centres >= m, never stored)
+            // hold relu(bias) of zero inputs and belong to centres >= m, never stored).  One
+            // uniform branch per 8 values picks the compile-time-nsample reduction.
             const int ns = sa.ns;
+            if (ns == 32) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              if (ns > 32) v0[k] = fmaxf(v0[k], v1[k]);          // ns == 64: both tiles are one centre
-              v0[k] = seg_max(v0[k], ns);
-              if (ns <= 32) v1[k] = seg_max(v1[k], ns);
+              for (int k = 0; k < 4; ++k) { v0[k] = seg_max<32>(v0[k], 32); v1[k] = seg_max<32>(v1[k], 32); }
+            } else if (ns == 16) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { v0[k] = seg_max<16>(v0[k], 16); v1[k] = seg_max<16>(v1[k], 16); }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (ns > 32) v0[k] = fmaxf(v0[k], v1[k]);          // ns == 64: both tiles are one centre
+                v0[k] = seg_max<0>(v0[k], ns);
+                if (ns <= 32) v1[k] = seg_max<0>(v1[k], ns);
+              }
             }
-            if (seg_leader(col, ns)) {
+            const bool leader = ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
+            if (leader) {
               const int cb = ns >= 32 ? 0 : col;
               const int j0 = (col0 + cb) / ns, j1 = (col0 + 32 + cb) / ns;
               float* o0 = out + ((size_t)bi * sa.m + j0) * od.ld + od.coff + row;
@@ -530,6 +577,7 @@ struct Chain {
         }
       }
     }
+    SM_STAMP(15);
   }
 };
 
@@ -555,6 +603,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
   xcd_frame_map(bi, bx);
   const int col0 = bx * SM_COLS;
 
+  SM_STAMP(14);
   stage_bias(d, s_bias, tid, NW * 64);
   if (tid < 64) {     // per-column gather info
     const int gcol = col0 + tid;
@@ -788,26 +837,37 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
   const int M = d.M[L];
   const int mt_total = (M + 31) >> 5;
   float* const out = od.out;
+  auto epi = [&](auto ns_tag) {
+    constexpr int NS = decltype(ns_tag)::value;
 #pragma unroll
-  for (int t = 0; t < NTR; ++t) {
-    if (t < mt_total) {
+    for (int t = 0; t < NTR; ++t) {
+      if (t < mt_total) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = fmaxf(acc[t][0][r], 0.f);
-        if (IS_SA) {
-          const int ns = sa.ns;   // 2..32, power of two
-          v = seg_max(v, ns);
-          if (row < M && seg_leader(col, ns)) {
-            const int j = (col0 + (ns >= 32 ? 0 : col)) / ns;
-            if (j < sa.m) out[((size_t)bi * sa.m + j) * od.ld + od.coff + row] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = fmaxf(acc[t][0][r], 0.f);
+          if (IS_SA) {
+            const int ns = NS > 0 ? NS : sa.ns;
+            v = seg_max<NS>(v, ns);
+            const bool leader = ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
+            if (row < M && leader) {
+              const int j = (col0 + (ns >= 32 ? 0 : col)) / ns;
+              if (j < sa.m) out[((size_t)bi * sa.m + j) * od.ld + od.coff + row] = v;
+            }
+          } else if (row < M && gcol < cols_total) {
+            if (od.point_major) out[((size_t)bi * fp.n + gcol) * od.ld + od.coff + row] = v;
+            else out[((size_t)bi * M + row) * fp.n + gcol] = v;
           }
-        } else if (row < M && gcol < cols_total) {
-          if (od.point_major) out[((size_t)bi * fp.n + gcol) * od.ld + od.coff + row] = v;
-          else out[((size_t)bi * M + row) * fp.n + gcol] = v;
         }
       }
     }
+  };
+  if (IS_SA) {
+    if (sa.ns == 32) epi(std::integral_constant<int, 32>{});
+    else if (sa.ns == 16) epi(std::integral_constant<int, 16>{});
+    else epi(std::integral_constant<int, 0>{});      // 1..32, power of two
+  } else {
+    epi(std::integral_constant<int, 0>{});
   }
 }
 
