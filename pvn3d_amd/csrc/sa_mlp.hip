@@ -73,6 +73,7 @@ constexpr int SM_KC = 32;            // input channels per layer-0 chunk
 constexpr int SM_CP = SM_KC / 4;     // pairs per chunk = depth of the weight prefetch ring
 constexpr int SM_MAX_LAYERS = 4;
 constexpr int SM_MAX_MT = 16;        // M <= 512
+constexpr int SM_EPAD = 68;          // row stride of the max-pool patch (16-byte aligned, conflict-free)
 
 struct MlpDesc {
   int n_layers;
@@ -506,6 +507,70 @@ struct Chain {
     const int nt = (mt_total - wave + NW - 1) / NW;
     const int half = lane >> 5, col = lane & 31;
     float* const out = od.out;
+    if (IS_SA) {
+      // Max-pool through LDS: the wave parks relu(tile) in a private [32][SM_EPAD] patch of the
+      // (now free) activation buffer, then lane (row = lane&31, column half = lane>>5) reads
+      // its 32 columns with 8 x 16-byte loads and reduces segments of nsample in registers.
+      // Lanes 0..31 then hold 32 consecutive channels of a centre: one 128-byte store per
+      // centre into the point-major output (a DPP butterfly per accumulator register plus
+      // 4-byte scattered stores cost a quarter of a narrow chain's workgroup time).
+      float* sc = H + (size_t)wave * (32 * SM_EPAD);
+      const int ns = sa.ns;
+      const int nout = ns >= 32 ? 1 : 32 / ns;                  // centres per lane
+      const int jbase = ns >= 64 ? col0 / ns : (col0 + 32 * half) / ns;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+          const int mt = wave + NW * t;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[rr * SM_EPAD + col] = fmaxf(acc[t][0][r], 0.f);
+            sc[rr * SM_EPAD + 32 + col] = fmaxf(acc[t][1][r], 0.f);
+          }
+          __builtin_amdgcn_wave_barrier();       // same wave: LDS operations complete in order
+          int v[32];                              // post-ReLU floats compare like signed ints
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int4 q = *reinterpret_cast<const int4*>(sc + col * SM_EPAD + 32 * half + 4 * i);
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (ns >= 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 16) {
+            v[0] = max(v[0], v[1]);
+            v[1] = max(v[2], v[3]);
+          }
+          if (ns >= 32) v[0] = max(v[0], v[1]);
+          if (ns >= 64) v[0] = max(v[0], __shfl_xor(v[0], 32, 64));
+          const int row = mt * 32 + col;
+          if (row < M && (ns < 64 || half == 0)) {
+            float* o = out + ((size_t)bi * sa.m + jbase) * od.ld + od.coff + row;
+            if (nout <= 2) {
+              if (jbase < sa.m) o[0] = __int_as_float(v[0]);
+              if (nout == 2 && jbase + 1 < sa.m) o[od.ld] = __int_as_float(v[1]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 32; ++q)
+                if (q < nout && jbase + q < sa.m) o[(size_t)q * od.ld] = __int_as_float(v[q]);
+            }
+          }
+        }
+      }
+      SM_STAMP(15);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
@@ -519,40 +584,7 @@ struct Chain {
             v0[k] = fmaxf(acc[t][0][4 * g + k], 0.f);
             v1[k] = fmaxf(acc[t][1][4 * g + k], 0.f);
           }
-          if (IS_SA) {
-            // max over the nsample consecutive columns of each centre (columns beyond cols_total
-            // hold relu(bias) of zero inputs and belong to centres >= m, never stored).  One
-            // uniform branch per 8 values picks the compile-time-nsample reduction.
-            const int ns = sa.ns;
-            if (ns == 32) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) { v0[k] = seg_max<32>(v0[k], 32); v1[k] = seg_max<32>(v1[k], 32); }
-            } else if (ns == 16) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) { v0[k] = seg_max<16>(v0[k], 16); v1[k] = seg_max<16>(v1[k], 16); }
-            } else {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if (ns > 32) v0[k] = fmaxf(v0[k], v1[k]);          // ns == 64: both tiles are one centre
-                v0[k] = seg_max<0>(v0[k], ns);
-                if (ns <= 32) v1[k] = seg_max<0>(v1[k], ns);
-              }
-            }
-            const bool leader = ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
-            if (leader) {
-              const int cb = ns >= 32 ? 0 : col;
-              const int j0 = (col0 + cb) / ns, j1 = (col0 + 32 + cb) / ns;
-              float* o0 = out + ((size_t)bi * sa.m + j0) * od.ld + od.coff + row;
-              float* o1 = out + ((size_t)bi * sa.m + j1) * od.ld + od.coff + row;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if (row + k < M) {
-                  if (j0 < sa.m) o0[k] = v0[k];
-                  if (ns <= 32 && j1 < sa.m) o1[k] = v1[k];
-                }
-              }
-            }
-          } else {
+          {
             const int g0 = col0 + col, g1 = col0 + 32 + col;
             if (od.point_major) {
               float* o0 = out + ((size_t)bi * fp.n + g0) * od.ld + od.coff + row;
@@ -882,6 +914,7 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   }
   if (max_mt > SM_MAX_MT) return (int)hipErrorInvalidValue;
   const bool ns_ok = !IS_SA || sa.ns <= 32;
+  const int hrows_in = hrows;
   // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0) and
   // loses for M = 128 with K >= 99 (every wave re-fetches all weight fragments), so it is
   // used for <= 2 row tiles only.
@@ -906,12 +939,14 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
     PVN3D_LAUNCH_CHECK();
     return 0;
   }
-  const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all + 9 * 64) * sizeof(float);
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
 #define SM_LAUNCH(KERN, NW)                                                                      \
   do {                                                                                         \
     auto kern = KERN;                                                                          \
+    /* SA epilogue: NW wave-private [32][SM_EPAD] patches overlay H | chunk */                 \
+    if (IS_SA) hrows = max(hrows_in, pvn3d_ceil_div(NW * 32 * SM_EPAD - 2 * SM_KC * SM_COLS, SM_COLS)); \
+    const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all + 9 * 64) * sizeof(float); \
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                                    \
     if (lds > 48 * 1024)                                                                       \
       PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
