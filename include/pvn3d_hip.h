@@ -218,6 +218,19 @@ int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst, int v_fir
 int pvn3d_best_fit_transform(int n_sets, int npts, const float* A, const float* B,
                              const int* valid, double* T, void* stream);
 
+/* ADD / ADD-S pose distances of a batch of instances (Basic_Utils.cal_add_cuda / cal_adds_cuda,
+ * pvn3d/lib/utils/basic_utils.py:617-635; called per object by eval_metric(_lm),
+ * pvn3d_eval_utils.py:113-136, 204-221).  Instance i uses the mesh points
+ * pts[pts_off[i] .. pts_off[i+1]) (pts (total,3) float, pts_off DEVICE int[n_inst+1]), its
+ * predicted and ground-truth poses pred_RT / gt_RT (n_inst,3,4) float row-major [R|t]:
+ *   add[i]  = mean_k |pred(x_k) - gt(x_k)|,  adds[i] = mean_k min_j |pred(x_j) - gt(x_k)|.
+ * max_pts >= every instance's point count (host-known bound, sizes the grid);
+ * workspace >= pvn3d_add_adds_workspace_bytes(n_inst, max_pts) bytes.  Deterministic. */
+size_t pvn3d_add_adds_workspace_bytes(int n_inst, int max_pts);
+int pvn3d_add_adds_batch(int n_inst, int max_pts, const float* pts, const int* pts_off,
+                         const float* pred_RT, const float* gt_RT, void* workspace,
+                         size_t workspace_bytes, float* add_out, float* adds_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,31 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     poses = best_fit_transform_batch(A, B, valid)
     return dict(poses=poses.view(F, C, 3, 4), present=present0, present_new=present, cls_kps=cls_kps.view(F, C, K + 1, 3),
                 iters=iters.view(F, C, K + 1), new_mask=mask)
+
+
+def add_adds_batch(pts_list, pred_RT, gt_RT):
+    """ADD / ADD-S of a batch of instances in one launch (csrc/metrics.hip).
+    pts_list: list of (n_i,3) float32 CUDA tensors (mesh points per instance) or one (n,3) tensor
+    shared by all; pred_RT / gt_RT: (n_inst,3,4) float32 CUDA.  Returns (add, adds) (n_inst,) float32
+    CUDA tensors; no host sync."""
+    pred_RT = pred_RT.to(torch.float32).contiguous()
+    gt_RT = gt_RT.to(torch.float32).contiguous()
+    n_inst = pred_RT.size(0)
+    dev = pred_RT.device
+    if torch.is_tensor(pts_list):
+        pts_list = [pts_list] * n_inst
+    counts = [int(p.size(0)) for p in pts_list]
+    pts = torch.cat([p.to(torch.float32).reshape(-1, 3) for p in pts_list], 0).contiguous()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+    max_pts = max(counts) if counts else 0
+    add = torch.zeros(n_inst, dtype=torch.float32, device=dev)
+    adds = torch.zeros(n_inst, dtype=torch.float32, device=dev)
+    if n_inst == 0 or max_pts == 0:
+        return add, adds
+    wsb = lib.pvn3d_add_adds_workspace_bytes(n_inst, max_pts)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.pvn3d_add_adds_batch(n_inst, max_pts, pts.data_ptr(), off.data_ptr(), pred_RT.data_ptr(),
+                                       gt_RT.data_ptr(), ws.data_ptr(), wsb, add.data_ptr(), adds.data_ptr(),
+                                       _stream(dev)), "add_adds_batch")
+    return add, adds

@@ -7,11 +7,15 @@ least-squares pose.
   cal_frame_poses(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus_flter)
       -> (pred_cls_ids, pred_pose_lst)               (reference :37-110)
   cal_batch_poses_lm / cal_batch_poses               batched, sync-free forms used by bench.py
-  TorchEval.eval_pose_parallel                       pose part of reference :345-387
+  eval_metric / eval_metric_lm                       ADD / ADD-S per object (reference :113-136, :204-221)
+  eval_one_frame_pose(_lm)                           reference :140-153, :223-236 (same `item` tuples)
+  TorchEval.eval_pose_parallel / cal_auc / cal_lm_add  reference :240-387
 
 The reference launches ~12 torch kernels per mean-shift iteration per fit and synchronises
 with the host every iteration; here each call is a handful of launches covering every fit of
-every object (see _vote_engine.py).  ADD/ADD-S accumulation is out of scope.
+every object (see _vote_engine.py); ADD / ADD-S of every object of every frame of a batch are
+one more launch (csrc/metrics.hip).  Mesh points come from ``Basic_Utils.get_pointxyz_cuda``
+(dataset files, or ``set_pointxyz`` -- the datasets are not part of this repository).
 """
 import numpy as np
 import torch
@@ -76,20 +80,174 @@ def cal_frame_poses(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus
     return pred_cls_ids, [poses[c - 1] for c in pred_cls_ids]
 
 
-class TorchEval(object):
-    """Pose half of the reference's TorchEval (metrics accumulation is out of scope)."""
+YCB_SYM_CLS_IDS = [13, 16, 19, 20, 21]     # common.py:82
+LM_SYM_CLS_IDS = [10, 11]                   # common.py:93
 
-    def __init__(self, n_cls=22):
+
+def _lists(n_cls):
+    return [list() for _ in range(n_cls)], [list() for _ in range(n_cls)]
+
+
+def eval_metric(cls_ids, pred_pose_lst, pred_cls_ids, RTs, mask, label, n_cls=22, bs_utils=None):
+    """ADD / ADD-S of every ground-truth object of one YCB frame (reference :113-136): a class
+    that was not predicted scores against the all-zero pose (:124)."""
+    bs_utils = bs_utils or _bs_utils
+    cls_add_dis, cls_adds_dis = _lists(n_cls)
+    ids, preds, gts, meshes = [], [], [], []
+    dev = RTs.device
+    pred_cls_ids = np.asarray(pred_cls_ids).reshape(-1)
+    for icls, cls_id in enumerate(cls_ids):
+        cid = int(cls_id.reshape(-1)[0].item()) if torch.is_tensor(cls_id) else int(np.asarray(cls_id).reshape(-1)[0])
+        if cid == 0:
+            break
+        where = np.where(pred_cls_ids == cid)[0]
+        if len(where) == 0:
+            pred_RT = torch.zeros(3, 4, device=dev)
+        else:
+            pred_RT = torch.from_numpy(np.asarray(pred_pose_lst[where[0]]).astype(np.float32)).to(dev)
+        ids.append(cid)
+        preds.append(pred_RT)
+        gts.append(RTs[icls].to(torch.float32))
+        meshes.append(bs_utils.get_pointxyz_cuda(cid, ds_type="ycb"))
+    if ids:
+        add, adds = _eng.add_adds_batch(meshes, torch.stack(preds), torch.stack(gts))
+        add, adds = add.cpu().tolist(), adds.cpu().tolist()
+        for cid, a, s_ in zip(ids, add, adds):
+            cls_add_dis[cid].append(a)
+            cls_adds_dis[cid].append(s_)
+            cls_add_dis[0].append(a)
+            cls_adds_dis[0].append(s_)
+    return cls_add_dis, cls_adds_dis
+
+
+def eval_metric_lm(cls_ids, pred_pose_lst, RTs, mask, label, obj_id, n_cls=22, bs_utils=None):
+    """ADD / ADD-S of the single LineMOD object of a frame (reference :204-221)."""
+    bs_utils = bs_utils or _bs_utils
+    cls_add_dis, cls_adds_dis = _lists(n_cls)
+    dev = RTs.device
+    pred_RT = torch.from_numpy(np.asarray(pred_pose_lst[0]).astype(np.float32)).to(dev)
+    mesh = bs_utils.get_pointxyz_cuda(obj_id, ds_type="linemod")
+    add, adds = _eng.add_adds_batch([mesh], pred_RT[None], RTs[0].to(torch.float32)[None])
+    a, s_ = float(add[0].item()), float(adds[0].item())
+    cls_add_dis[obj_id].append(a)
+    cls_adds_dis[obj_id].append(s_)
+    cls_add_dis[0].append(a)
+    cls_adds_dis[0].append(s_)
+    return cls_add_dis, cls_adds_dis
+
+
+def eval_one_frame_pose(item):
+    """Reference :140-153; `item` as zipped by TorchEval.eval_pose_parallel."""
+    pcld, mask, ctr_of, pred_kp_of, RTs, cls_ids, use_ctr, n_cls, min_cnt, use_ctr_clus_flter, label, epoch, ibs = item
+    pred_cls_ids, pred_pose_lst = cal_frame_poses(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus_flter)
+    return eval_metric(cls_ids, pred_pose_lst, pred_cls_ids, RTs, mask, label, n_cls=n_cls)
+
+
+def eval_one_frame_pose_lm(item):
+    """Reference :223-236."""
+    (pcld, mask, ctr_of, pred_kp_of, RTs, cls_ids, use_ctr, n_cls, min_cnt, use_ctr_clus_flter, label, epoch, ibs,
+     obj_id) = item
+    pred_pose_lst = cal_frame_poses_lm(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus_flter, obj_id)
+    return eval_metric_lm(cls_ids, pred_pose_lst, RTs, mask, label, obj_id, n_cls=n_cls)
+
+
+class TorchEval(object):
+    """The reference's TorchEval (:238-392): pose estimation for a batch + ADD / ADD-S bookkeeping."""
+
+    def __init__(self, n_cls=22, bs_utils=None, log_eval_dir=None, verbose=True):
         self.n_cls = n_cls
+        self.cls_add_dis = [list() for _ in range(n_cls)]
+        self.cls_adds_dis = [list() for _ in range(n_cls)]
+        self.cls_add_s_dis = [list() for _ in range(n_cls)]
+        self.sym_cls_ids = []
+        self.bs_utils = bs_utils or _bs_utils
+        self.log_eval_dir = log_eval_dir
+        self.verbose = verbose
+        self.last_poses = None
+
+    def _say(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def cal_auc(self):
+        """Per-class and overall ADD / ADD-S / ADD(-S) AUC (reference :249-296); returns the dict the
+        reference pickles (and pickles it when log_eval_dir is set)."""
+        add_auc_lst, adds_auc_lst, add_s_auc_lst = [], [], []
+        for cls_id in range(1, self.n_cls):
+            self.cls_add_s_dis[cls_id] = self.cls_adds_dis[cls_id] if cls_id in YCB_SYM_CLS_IDS \
+                else self.cls_add_dis[cls_id]
+            self.cls_add_s_dis[0] += self.cls_add_s_dis[cls_id]
+        for i in range(self.n_cls):
+            add_auc_lst.append(self.bs_utils.cal_auc(self.cls_add_dis[i]))
+            adds_auc_lst.append(self.bs_utils.cal_auc(self.cls_adds_dis[i]))
+            add_s_auc_lst.append(self.bs_utils.cal_auc(self.cls_add_s_dis[i]))
+            if i == 0:
+                continue
+            self._say(self.bs_utils.ycb_cls_lst[i - 1] if i - 1 < len(self.bs_utils.ycb_cls_lst) else i)
+            self._say("***************add:\t", add_auc_lst[-1])
+            self._say("***************adds:\t", adds_auc_lst[-1])
+            self._say("***************add(-s):\t", add_s_auc_lst[-1])
+        self._say("Average of all object:")
+        self._say("***************add:\t", np.mean(add_auc_lst[1:]))
+        self._say("***************adds:\t", np.mean(adds_auc_lst[1:]))
+        self._say("***************add(-s):\t", np.mean(add_s_auc_lst[1:]))
+        self._say("All object (following PoseCNN):")
+        self._say("***************add:\t", add_auc_lst[0])
+        self._say("***************adds:\t", adds_auc_lst[0])
+        self._say("***************add(-s):\t", add_s_auc_lst[0])
+        sv_info = dict(add_dis_lst=self.cls_add_dis, adds_dis_lst=self.cls_adds_dis, add_auc_lst=add_auc_lst,
+                       adds_auc_lst=adds_auc_lst, add_s_auc_lst=add_s_auc_lst)
+        self._dump(sv_info, 'pvn3d_eval_cuda_{}_{}_{}.pkl'.format(adds_auc_lst[0], add_auc_lst[0], add_s_auc_lst[0]))
+        return sv_info
+
+    def cal_lm_add(self, obj_id, test_occ=False, diameter_m=None):
+        """LineMOD summary for one object (reference :298-343).  diameter_m: the object's diameter
+        in metres (`lm_r_lst[obj_id]['diameter'] / 1000` from the dataset's models_info.yml)."""
+        cls_id = obj_id
+        self.cls_add_s_dis[cls_id] = self.cls_adds_dis[cls_id] if obj_id in LM_SYM_CLS_IDS \
+            else self.cls_add_dis[cls_id]
+        self.cls_add_s_dis[0] += self.cls_add_s_dis[cls_id]
+        add_auc = self.bs_utils.cal_auc(self.cls_add_dis[cls_id])
+        adds_auc = self.bs_utils.cal_auc(self.cls_adds_dis[cls_id])
+        add_s_auc = self.bs_utils.cal_auc(self.cls_add_s_dis[cls_id])
+        sv_info = dict(add_dis_lst=self.cls_add_dis, adds_dis_lst=self.cls_adds_dis, add_auc_lst=[add_auc],
+                       adds_auc_lst=[adds_auc], add_s_auc_lst=[add_s_auc])
+        self._say("***************add auc:\t", add_auc)
+        self._say("***************adds auc:\t", adds_auc)
+        self._say("***************add(-s) auc:\t", add_s_auc)
+        if diameter_m is not None:
+            d = diameter_m * 0.1
+            sv_info["add"] = np.mean(np.array(self.cls_add_dis[cls_id]) < d) * 100
+            sv_info["adds"] = np.mean(np.array(self.cls_adds_dis[cls_id]) < d) * 100
+            self._say("***************add < 0.1 diameter:\t", sv_info["add"])
+            self._say("***************adds < 0.1 diameter:\t", sv_info["adds"])
+        self._dump(sv_info, 'pvn3d_eval_cuda_{}_{}.pkl'.format(obj_id, "occlusion" if test_occ else ""))
+        return sv_info
+
+    def _dump(self, info, name):
+        if self.log_eval_dir:
+            import os
+            import pickle as pkl
+            with open(os.path.join(self.log_eval_dir, name), "wb") as f:
+                pkl.dump(info, f)
+
+    def merge_lst(self, targ, src):
+        for i in range(len(targ)):
+            targ[i] += src[i]
+        return targ
 
     def eval_pose_parallel(self, pclds, rgbs, masks, pred_ctr_ofs, gt_ctr_ofs, labels, cnt,
                            cls_ids, RTs, pred_kp_ofs, min_cnt=20, merge_clus=False, bbox=False,
                            ds='YCB', cls_type=None, use_p2d=False, vote_type=None,
                            use_ctr_clus_flter=True, use_ctr=True, ds_type="ycb", obj_id=0):
         """Same arguments as the reference (:345-351).  The reference fans the frames of a batch
-        out to a thread pool (:373-380); here the whole batch is one device-side pipeline.
-        Returns the per-frame pose lists (and stores them in ``self.last_poses``)."""
+        out to a thread pool (:373-380); here the poses of the whole batch are one device-side
+        pipeline and, when ground-truth poses `RTs` and mesh points are available, ADD / ADD-S of
+        every object of every frame are one more launch, merged into ``cls_add_dis`` /
+        ``cls_adds_dis`` exactly as the reference does.  Returns the per-frame pose lists (also in
+        ``self.last_poses``)."""
         masks = masks.long()
+        bs = pclds.size(0)
         if ds_type == "ycb":
             res = cal_batch_poses(pclds, masks, pred_ctr_ofs, pred_kp_ofs, use_ctr, self.n_cls,
                                   use_ctr_clus_flter)
@@ -105,4 +263,19 @@ class TorchEval(object):
             poses = res["poses"].cpu().numpy()
             out = [[poses[f]] for f in range(poses.shape[0])]
         self.last_poses = out
+        if RTs is not None and cls_ids is not None:
+            try:
+                for f in range(bs):
+                    if ds_type == "ycb":
+                        add_l, adds_l = eval_metric(cls_ids[f].long(), out[f][1], out[f][0], RTs[f], masks[f],
+                                                    labels[f] if labels is not None else None, n_cls=self.n_cls,
+                                                    bs_utils=self.bs_utils)
+                    else:
+                        add_l, adds_l = eval_metric_lm(cls_ids[f].long(), out[f], RTs[f], masks[f],
+                                                       labels[f] if labels is not None else None, obj_id,
+                                                       n_cls=self.n_cls, bs_utils=self.bs_utils)
+                    self.cls_add_dis = self.merge_lst(self.cls_add_dis, add_l)
+                    self.cls_adds_dis = self.merge_lst(self.cls_adds_dis, adds_l)
+            except FileNotFoundError:
+                pass      # no mesh points available: poses only
         return out

@@ -163,6 +163,43 @@ def main():
     np.savez_compressed(os.path.join(HERE, "kabsch_ref.npz"), **kb)
     print("kabsch cases", nk)
 
+    # ------------------------------------------------------------------ ADD / ADD-S / AUC
+    # Basic_Utils.cal_add_cuda / cal_adds_cuda / cal_auc use `self` for nothing: call unbound.
+    rng_m = np.random.default_rng(20260925)      # own stream: the other fixtures stay bit-identical
+    mt = {}
+    nm = 0
+    for trial in range(8):
+        n = [64, 257, 500, 1000, 1500, 2000, 333, 1][trial]
+        pts = (rng_m.normal(size=(n, 3)) * [0.04, 0.06, 0.03]).astype(np.float32)
+        Rg = synth.random_rotation(rng_m); tg = rng_m.normal(size=3) * 0.3 + [0, 0, 0.9]
+        ang = [0.0, 0.01, 0.05, 0.2, 3.1, 0.02, 1.0, 0.3][trial]
+        ax = rng_m.normal(size=3); ax /= np.linalg.norm(ax)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        dR = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        Rp = dR @ Rg; tp = tg + rng_m.normal(size=3) * [0.0, 0.002, 0.01, 0.05, 0.1, 0.0, 0.02, 0.01][trial]
+        gt = np.concatenate([Rg, tg[:, None]], 1).astype(np.float32)
+        pr = np.concatenate([Rp, tp[:, None]], 1).astype(np.float32)
+        if trial == 5:
+            pr = np.zeros((3, 4), np.float32)           # "no prediction" pose of eval_metric (:124)
+        add = bu_mod.Basic_Utils.cal_add_cuda(None, torch.from_numpy(pr), torch.from_numpy(gt), torch.from_numpy(pts))
+        adds = bu_mod.Basic_Utils.cal_adds_cuda(None, torch.from_numpy(pr), torch.from_numpy(gt), torch.from_numpy(pts))
+        mt["pts%d" % nm] = pts; mt["gt%d" % nm] = gt; mt["pred%d" % nm] = pr
+        mt["add%d" % nm] = np.float32(add.item()); mt["adds%d" % nm] = np.float32(adds.item())
+        nm += 1
+    mt["n_cases"] = np.int64(nm)
+    na = 0
+    for trial in range(6):
+        n = [1, 5, 40, 200, 17, 3][trial]
+        dis = np.abs(rng_m.normal(size=n) * [0.01, 0.05, 0.03, 0.08, 0.5, 0.0][trial]).tolist()
+        if trial == 4:
+            dis[0] = 0.1                                  # boundary: D > max_dis is strict
+        mt["dis%d" % na] = np.asarray(dis, np.float64)
+        mt["auc%d" % na] = np.float64(bu_mod.Basic_Utils.cal_auc(None, list(dis)))
+        na += 1
+    mt["n_auc"] = np.int64(na)
+    np.savez_compressed(os.path.join(HERE, "metrics_ref.npz"), **mt)
+    print("metric cases", nm, na)
+
     # ------------------------------------------------------------------ whole frames
     def ref_fit(A, bw):
         if len(A) == 0:

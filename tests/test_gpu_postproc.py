@@ -203,3 +203,68 @@ def test_mfma_assisted_kernel_matches_valu_and_is_deterministic(dev, monkeypatch
     assert (a["cls_kps"] - base["cls_kps"]).abs().max().item() < TOL
     assert (a["iters"] - base["iters"]).abs().max().item() <= 1
     assert (a["poses"] - base["poses"]).abs().max().item() < TOL
+
+
+@pytest.mark.gpu
+def test_add_adds_vs_reference_golden_and_oracle(dev, golden):
+    """csrc/metrics.hip vs the reference's cal_add_cuda / cal_adds_cuda outputs (fixtures) and the
+    numpy oracle at a size the reference's (N,N,3) formulation would need 2.3 GB for."""
+    from oracle import metrics
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    from pvn3d_amd.lib.utils.basic_utils import Basic_Utils
+    z = golden("metrics_ref.npz")
+    n = int(z["n_cases"])
+    meshes = [torch.from_numpy(z["pts%d" % i]).to(dev) for i in range(n)]
+    pred = torch.from_numpy(np.stack([z["pred%d" % i] for i in range(n)])).to(dev)
+    gt = torch.from_numpy(np.stack([z["gt%d" % i] for i in range(n)])).to(dev)
+    add, adds = eng.add_adds_batch(meshes, pred, gt)           # ragged batch, one launch
+    add, adds = add.cpu().numpy(), adds.cpu().numpy()
+    for i in range(n):
+        assert abs(add[i] - float(z["add%d" % i])) < 1e-5 * max(1.0, float(z["add%d" % i])), i
+        assert abs(adds[i] - float(z["adds%d" % i])) < 1e-5 * max(1.0, float(z["adds%d" % i])), i
+    bu = Basic_Utils()
+    a1 = bu.cal_add_cuda(pred[2], gt[2], meshes[2]).item()       # reference call signature
+    s1 = bu.cal_adds_cuda(pred[2], gt[2], meshes[2]).item()
+    assert a1 == add[2] and s1 == adds[2]                        # batched == single, bit for bit
+    rng = np.random.default_rng(5)
+    pts = (rng.normal(size=(8192, 3)) * 0.05).astype(np.float32)
+    P = z["pred3"]; G = z["gt3"]
+    a, s = eng.add_adds_batch(torch.from_numpy(pts).to(dev), torch.from_numpy(P[None]).to(dev),
+                              torch.from_numpy(G[None]).to(dev))
+    assert abs(a.item() - metrics.cal_add(P, G, pts)) < 1e-5
+    assert abs(s.item() - metrics.cal_adds(P, G, pts)) < 1e-5
+    # identical poses: ADD = ADD-S = 0 exactly
+    a, s = eng.add_adds_batch(torch.from_numpy(pts).to(dev), gt[:1], gt[:1])
+    assert a.item() == 0.0 and s.item() == 0.0
+
+
+@pytest.mark.gpu
+def test_torcheval_accumulates_metrics_like_the_reference(dev, orc):
+    """TorchEval.eval_pose_parallel: poses + ADD/ADD-S bookkeeping for a LineMOD batch, against
+    the oracle pipeline (posecal + metrics) frame by frame."""
+    from oracle import metrics, posecal
+    from pvn3d_amd import synth
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    from pvn3d_amd.lib.utils.basic_utils import Basic_Utils
+    frames = [synth.synth_frame(frame=40 + i, n_pts=2048, n_obj=600) for i in range(3)]
+    rng = np.random.default_rng(9)
+    mesh = (rng.normal(size=(700, 3)) * [0.03, 0.04, 0.02]).astype(np.float32)
+    bu = Basic_Utils()
+    bu.set_pointxyz(1, mesh, ds_type="linemod")
+    st = lambda k: torch.from_numpy(np.stack([f[k] for f in frames])).to(dev)
+    RTs = torch.from_numpy(np.stack([np.concatenate([f["R"], f["t"][:, None]], 1)[None] for f in frames])
+                           .astype(np.float32)).to(dev)                    # (bs, 1, 3, 4)
+    cls_ids = torch.ones((3, 1, 1), dtype=torch.int64, device=dev)
+    te = ev.TorchEval(bs_utils=bu, verbose=False)
+    out = te.eval_pose_parallel(st("pcld"), None, st("mask"), st("ctr_of"), None, None, 0, cls_ids, RTs,
+                                st("pred_kp_of"), use_ctr_clus_flter=False, ds_type="linemod", obj_id=1)
+    assert len(te.cls_add_dis[1]) == 3 and len(te.cls_adds_dis[0]) == 3
+    for i, f in enumerate(frames):
+        want_pose = posecal.cal_frame_poses_lm(f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], True, 2, False,
+                                               f["mesh_kps"])[0]
+        assert np.abs(out[i][0] - want_pose).max() < 1e-4
+        gt = np.concatenate([f["R"], f["t"][:, None]], 1).astype(np.float32)
+        assert abs(te.cls_add_dis[1][i] - metrics.cal_add(out[i][0].astype(np.float32), gt, mesh)) < 1e-5
+        assert abs(te.cls_adds_dis[1][i] - metrics.cal_adds(out[i][0].astype(np.float32), gt, mesh)) < 1e-5
+    info = te.cal_lm_add(1, diameter_m=0.1)
+    assert 0.0 <= info["add_auc_lst"][0] <= 100.0 and info["add"] == 100.0

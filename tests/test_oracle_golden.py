@@ -103,3 +103,35 @@ def test_frames_native_oracle_vs_reference_driven(orc, golden):
     assert np.array_equal(new_mask, z["ycb_new_mask"])
     assert np.abs(np.stack(poses, 0) - z["ycb_poses"]).max() < 1e-4
     assert np.abs(cls_kps - z["ycb_cls_kps"]).max() < 1e-5
+
+
+def test_metric_oracle_vs_reference(golden):
+    """oracle/metrics.py (ADD, ADD-S, AUC) against the reference's own Basic_Utils.cal_add_cuda /
+    cal_adds_cuda / cal_auc outputs (torch CPU)."""
+    from oracle import metrics
+    z = golden("metrics_ref.npz")
+    for i in range(int(z["n_cases"])):
+        pts, gt, pred = z["pts%d" % i], z["gt%d" % i], z["pred%d" % i]
+        assert abs(metrics.cal_add(pred, gt, pts) - float(z["add%d" % i])) < 2e-6 * max(1.0, float(z["add%d" % i]))
+        assert abs(metrics.cal_adds(pred, gt, pts) - float(z["adds%d" % i])) < 2e-6 * max(1.0, float(z["adds%d" % i]))
+    for i in range(int(z["n_auc"])):
+        assert abs(metrics.cal_auc(list(z["dis%d" % i])) - float(z["auc%d" % i])) < 1e-9
+
+
+def test_host_auc_equals_reference(golden):
+    """Basic_Utils.cal_auc / VOCap of the package (pure numpy, no GPU needed) vs the reference."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    # basic_utils imports the ctypes library at module level; load only the pure functions
+    src = open(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "lib", "utils", "basic_utils.py")).read()
+    start = src.index("def VOCap(rec, prec):")
+    end = src.index("def best_fit_transform(A, B):")
+    ns = {}
+    exec("import numpy as np\n" + src[start:end], ns)
+    cls_src = src[src.index("    def cal_auc(self, add_dis, max_dis=0.1):"):src.index("    def cal_add_cuda(self, pred_RT, gt_RT, p3ds):")]
+    exec("import numpy as np\nclass _U(object):\n" + cls_src, ns)
+    z = golden("metrics_ref.npz")
+    for i in range(int(z["n_auc"])):
+        assert abs(ns["_U"]().cal_auc(list(z["dis%d" % i])) - float(z["auc%d" % i])) < 1e-9
