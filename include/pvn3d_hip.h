@@ -231,6 +231,18 @@ int pvn3d_add_adds_batch(int n_inst, int max_pts, const float* pts, const int* p
                          const float* pred_RT, const float* gt_RT, void* workspace,
                          size_t workspace_bytes, float* add_out, float* adds_out, void* stream);
 
+/* YCB centre-cluster re-labelling of cal_frame_poses (pvn3d_eval_utils.py:58-72), batched.
+ * pcld, ctr_of (n_frames,n_pts,3) [ctr_of = the first (only) centre offset row]; mask
+ * (n_frames,n_pts) int32; ctrs (n_frames,n_cls_m1,3) = MeanShift centre of class id c+1;
+ * present (n_frames,n_cls_m1) int32 = class occurs in mask; thr (n_cls_m1) = fp32(0.8*ycb_r_lst).
+ * new_mask (n_frames,n_pts): a labelled point takes the class of its nearest present centre
+ * (first minimum in ascending class id) when that distance < thr[class]; present_new
+ * (n_frames,n_cls_m1) int32 = classes occurring in new_mask. */
+int pvn3d_relabel_by_centre(int n_frames, int n_pts, int n_cls_m1, const float* pcld,
+                            const float* ctr_of, const int* mask, const float* ctrs,
+                            const int* present, const float* thr, int* new_mask,
+                            int* present_new, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,18 +162,22 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
     return dict(poses=poses, cls_kps=cls_kps, iters=iters.view(F, K + 1), counts=counts)
 
 
-def relabel_by_centre(mask, pred_ctr, ctrs, present, thr_lst):
-    """Centre-cluster re-labelling of cal_frame_poses (pvn3d_eval_utils.py:58-72), batched over
-    frames with every class slot kept on the device (absent classes masked by `present`).
-    mask (F,N) int32; pred_ctr (F,N,3); ctrs (F,C,3) cluster centre per class id 1..C;
-    present (F,C) bool; thr_lst (C) float32 = fp32(0.8 * ycb_r_lst).  Returns the new mask."""
-    d = torch.norm(pred_ctr.unsqueeze(2) - ctrs.unsqueeze(1), dim=3)          # (F,N,C)
-    d = torch.where(present.unsqueeze(1), d, torch.full_like(d, float("inf")))
-    min_dis, min_idx = torch.min(d, dim=2)                                     # first min
-    closest = (min_idx + 1).to(mask.dtype)
-    thr = thr_lst.to(d.dtype)[min_idx]
-    upd = (mask > 0) & (min_dis < thr) & present.any(dim=1, keepdim=True)
-    return torch.where(upd, closest, mask)
+def relabel_by_centre(pcld, ctr_of0, mask, ctrs, present, thr_lst):
+    """Centre-cluster re-labelling of cal_frame_poses (pvn3d_eval_utils.py:58-72), one launch for
+    every frame (csrc/relabel.hip); every class slot stays on the device.
+    pcld, ctr_of0 (F,N,3); mask (F,N) int32; ctrs (F,C,3) cluster centre per class id 1..C;
+    present (F,C) bool; thr_lst (C) float32 = fp32(0.8 * ycb_r_lst).
+    Returns (new mask (F,N) int32, present_new (F,C) bool)."""
+    F, N = mask.shape
+    C = ctrs.size(1)
+    new_mask = torch.empty_like(mask)
+    present_new = torch.empty((F, C), dtype=torch.int32, device=mask.device)
+    with torch.cuda.device(mask.device):
+        check(lib.pvn3d_relabel_by_centre(F, N, C, pcld.data_ptr(), ctr_of0.contiguous().data_ptr(), mask.data_ptr(),
+                                          ctrs.contiguous().data_ptr(), present.to(torch.int32).contiguous().data_ptr(),
+                                          thr_lst.contiguous().data_ptr(), new_mask.data_ptr(),
+                                          present_new.data_ptr(), _stream(mask.device)), "relabel_by_centre")
+    return new_mask, present_new != 0
 
 
 def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls, radius_lst,
@@ -206,10 +210,8 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
         c0, _, _ = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
                                        radius, max_iter, poll_every=poll_every,
                                        aligned32=(N % 32 == 0))
-        pred_ctr = pcld - ctr_of[:, 0]
         thr = torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)).to(dev)
-        mask = relabel_by_centre(mask, pred_ctr, c0.view(F, C, 3), present, thr).contiguous()
-        present = (mask.unsqueeze(1) == cls_ids).any(dim=2)
+        mask, present = relabel_by_centre(pcld, ctr_of[:, 0], mask, c0.view(F, C, 3), present, thr)
     # per-class centre fit on the (re-labelled) mask
     out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
     votes, seg_off, seg_cnt = out

@@ -268,3 +268,56 @@ def test_torcheval_accumulates_metrics_like_the_reference(dev, orc):
         assert abs(te.cls_adds_dis[1][i] - metrics.cal_adds(out[i][0].astype(np.float32), gt, mesh)) < 1e-5
     info = te.cal_lm_add(1, diameter_m=0.1)
     assert 0.0 <= info["add_auc_lst"][0] <= 100.0 and info["add"] == 100.0
+
+
+@pytest.mark.gpu
+def test_relabel_by_centre_kernel_vs_reference_formula(dev):
+    """csrc/relabel.hip vs the numpy restatement of pvn3d_eval_utils.py:58-72 on frames whose masks
+    are deliberately noisy (mislabelled points near another object's centre, background points,
+    an absent class, a class whose every point gets re-labelled)."""
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    rng = np.random.default_rng(21)
+    F, N, C = 3, 3000, 21
+    r_lst = (0.05 + 0.1 * rng.random(C)).astype(np.float64)
+    thr = (r_lst * 0.8).astype(np.float32)
+    pcld = (rng.normal(size=(F, N, 3)) * 0.2 + [0, 0, 0.9]).astype(np.float32)
+    ctr_of = np.zeros((F, N, 3), np.float32)
+    mask = np.zeros((F, N), np.int32)
+    ctrs = np.zeros((F, C, 3), np.float32)
+    present = np.zeros((F, C), bool)
+    for f in range(F):
+        ids = rng.choice(np.arange(1, C + 1), size=5, replace=False)
+        cen = (rng.normal(size=(5, 3)) * 0.15 + [0, 0, 0.9]).astype(np.float32)
+        lab = rng.integers(0, 6, size=N)                       # 0 = background
+        for k, cid in enumerate(ids):
+            sel = lab == k + 1
+            true_c = cen[k]
+            votes = true_c + rng.normal(size=(sel.sum(), 3)).astype(np.float32) * 0.01
+            ctr_of[f, sel] = pcld[f, sel] - votes               # pred_ctr = pcld - ctr_of = votes
+            mask[f, sel] = cid
+            ctrs[f, cid - 1] = true_c
+            present[f, cid - 1] = True
+        wrong = rng.random(N) < 0.15                           # mislabel 15 % of the object points
+        mask[f, wrong & (mask[f] > 0)] = rng.choice(ids, size=int((wrong & (mask[f] > 0)).sum()))
+        if f == 2:                                              # one class entirely mislabelled as another
+            mask[f, mask[f] == ids[0]] = ids[1]
+            present[f, ids[0] - 1] = False
+    T_ = lambda a, dt=None: torch.from_numpy(a).to(dev)
+    new_mask, present_new = eng.relabel_by_centre(T_(pcld), T_(ctr_of), T_(mask), T_(ctrs), T_(present), T_(thr))
+    new_mask, present_new = new_mask.cpu().numpy(), present_new.cpu().numpy()
+    for f in range(F):
+        pred_ctr = pcld[f] - ctr_of[f]
+        pred_cls_ids = np.nonzero(present[f])[0] + 1
+        c = ctrs[f, pred_cls_ids - 1]
+        d = np.linalg.norm(pred_ctr[:, None, :] - c[None, :, :], axis=2).astype(np.float32)
+        mi = np.argmin(d, axis=1)
+        md = d[np.arange(N), mi]
+        closest = pred_cls_ids[mi]
+        want = mask[f].copy()
+        for cid in pred_cls_ids:
+            upd = (mask[f] > 0) & (closest == cid) & (md < np.float32(r_lst[cid - 1] * 0.8))
+            want[upd] = closest[upd]
+        # fp32 distance rounding may flip points within 1 ulp of a threshold / tie: allow none here
+        assert np.array_equal(new_mask[f], want), int((new_mask[f] != want).sum())
+        assert np.array_equal(np.nonzero(present_new[f])[0] + 1, np.unique(want[want > 0]))
+        assert (new_mask[f] != mask[f]).sum() > 50             # the test really re-labels
