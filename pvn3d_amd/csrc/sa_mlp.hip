@@ -225,15 +225,18 @@ template <int NTC, int NT, bool SWZ>
 __device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
                                       const WPtr& w, int p0, const float* __restrict__ rows_half, int col) {
   if (NTC == 0) return;
-  float b[2][2][2];
+  // B fragments two pairs ahead (three register sets): one pair (<= 512 cycles of this wave's
+  // MFMAs) does not always cover the LDS latency when all eight waves read at once
+  float b[3][2][2];
   ld_b<SWZ>(b[0], rows_half, col, 0);
+  ld_b<SWZ>(b[1], rows_half, col, 1);
 #pragma unroll
   for (int u = 0; u < SM_CP; ++u) {
     // keep this order (fences): left alone, the scheduler sinks every LDS read to just before its
     // MFMA (exposing the LDS latency once per pair) and bunches the refills at the chunk end
-    if (u + 1 < SM_CP) ld_b<SWZ>(b[(u + 1) & 1], rows_half, col, u + 1);
+    if (u + 2 < SM_CP) ld_b<SWZ>(b[(u + 2) % 3], rows_half, col, u + 2);
     __builtin_amdgcn_sched_barrier(0);
-    mm_pair<NTC, NT>(acc, ring[u], b[u & 1]);
+    mm_pair<NTC, NT>(acc, ring[u], b[u % 3]);
     ring_load<NTC>(ring[u], w, p0 + SM_CP + u);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -396,16 +399,10 @@ struct Chain {
     int g = 1;
     for (; g < nA; ++g) {
       PStage<NBA, PIT> st;
-#ifdef SM_EXP_NOGATHER
-      for (int it = 0; it < PIT; ++it) for (int k = 0; k < NBA; ++k) st.v[it][k] = make_float4(1.f, 2.f, 3.f, 4.f);
-#else
       p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
-#endif
       span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
       p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.w, tid);
-#ifndef SM_EXP_NOBARRIER
       __syncthreads();
-#endif
     }
     if (!IS_SA) {
       for (; g < nAB; ++g) {
@@ -682,7 +679,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
 }
 
 template <bool IS_SA, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : 3)) void mlp_chain_kernel(
+#ifndef SM_NW4_WAVES
+#define SM_NW4_WAVES 3
+#endif
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : SM_NW4_WAVES)) void mlp_chain_kernel(
     MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
   mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, bias_all, cols_total, od);
 }
