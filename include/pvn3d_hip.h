@@ -243,6 +243,18 @@ int pvn3d_relabel_by_centre(int n_frames, int n_pts, int n_cls_m1, const float* 
                             const int* present, const float* thr, int* new_mask,
                             int* present_new, void* stream);
 
+/* Vote (keypoint / centre offset) L1 loss, of_l1_loss with normalize=True (pvn3d/lib/loss.py:45-73):
+ * pred_ofsts (bs,n_kpts,n_pts,3), kp_targ_ofst (bs,n_pts,n_kpts,3), labels (bs,n_pts) float
+ * (w = labels > 1e-8) -> loss (bs,n_kpts) = sum_{i,c} w|pred-targ| / (sum_i w + 1e-3), and
+ * wsum (bs,n_kpts) = sum_i w (kept for the backward).  Deterministic summation order. */
+int pvn3d_of_l1_loss(int bs, int n_kpts, int n_pts, const float* pred_ofsts,
+                     const float* kp_targ_ofst, const float* labels, float* loss, float* wsum,
+                     void* stream);
+/* grad_pred (bs,n_kpts,n_pts,3) = grad_loss[b,k] * w_i * sign(pred - targ) / (wsum[b,k] + 1e-3). */
+int pvn3d_of_l1_loss_grad(int bs, int n_kpts, int n_pts, const float* pred_ofsts,
+                          const float* kp_targ_ofst, const float* labels, const float* wsum,
+                          const float* grad_loss, float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void three_interpolate_rows_kernel(
         for (int u = 0; u < 4; ++u)
           r[u] = sr[id[u * 3 + 0]] * w[u * 3 + 0] + sr[id[u * 3 + 1]] * w[u * 3 + 1] +
                  sr[id[u * 3 + 2]] * w[u * 3 + 2];
-        *reinterpret_cast<float4*>(o + (size_t)ch * n + j0) = make_float4(r[0], r[1], r[2], r[3]);
+        // streaming output (written once, not re-read here): non-temporal 16-byte store
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f val = {r[0], r[1], r[2], r[3]};
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (size_t)ch * n + j0));
       }
     }
   }

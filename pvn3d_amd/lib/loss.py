@@ -1,0 +1,70 @@
+"""The vote loss of the reference's pvn3d/lib/loss.py: ``of_l1_loss`` (:45-73) and ``OFLoss``
+(:76-90) with the same signatures.  Forward and backward are one HIP launch each
+(csrc/vote_loss.hip) instead of ~8 elementwise torch kernels over (bs, K, N, 3) temporaries;
+summation order is fixed, so the loss is bit-reproducible.  FocalLoss (the segmentation loss) is
+not on the hot path and is not restated."""
+import torch
+from torch.nn.modules.loss import _Loss
+
+from .._lib import lib, check
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _OfL1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_ofsts, kp_targ_ofst, w_labels):
+        bs, n_kpts, n_pts, c = pred_ofsts.shape
+        pred = pred_ofsts.contiguous()
+        targ = kp_targ_ofst.contiguous()
+        loss = torch.empty((bs, n_kpts), dtype=torch.float32, device=pred.device)
+        wsum = torch.empty((bs, n_kpts), dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            check(lib.pvn3d_of_l1_loss(bs, n_kpts, n_pts, pred.data_ptr(), targ.data_ptr(), w_labels.data_ptr(),
+                                       loss.data_ptr(), wsum.data_ptr(), _stream(pred)), "of_l1_loss")
+        ctx.save_for_backward(pred, targ, w_labels, wsum)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        pred, targ, w_labels, wsum = ctx.saved_tensors
+        bs, n_kpts, n_pts, c = pred.shape
+        grad_pred = torch.empty_like(pred)
+        g = grad_loss.contiguous().float()
+        with torch.cuda.device(pred.device):
+            check(lib.pvn3d_of_l1_loss_grad(bs, n_kpts, n_pts, pred.data_ptr(), targ.data_ptr(),
+                                            w_labels.data_ptr(), wsum.data_ptr(), g.data_ptr(),
+                                            grad_pred.data_ptr(), _stream(pred)), "of_l1_loss_grad")
+        return grad_pred, None, None
+
+
+def of_l1_loss(pred_ofsts, kp_targ_ofst, labels, sigma=1.0, normalize=True, reduce=False):
+    """
+    :param pred_ofsts:      [bs, n_kpts, n_pts, c]
+    :param kp_targ_ofst:    [bs, n_pts, n_kpts, c]
+    :param labels:          [bs, n_pts, 1]
+    Returns [bs, n_kpts] (normalize=True) or the weighted |diff| [bs, n_kpts, n_pts, c].
+    `sigma` and `reduce` are accepted and ignored exactly like the reference (its
+    ``torch.mean(in_loss)`` result is discarded, :70-71).
+    """
+    if not pred_ofsts.is_cuda:
+        raise RuntimeError("CPU not supported")
+    bs, n_kpts, n_pts, c = pred_ofsts.size()
+    if c != 3 or pred_ofsts.dtype != torch.float32:
+        raise RuntimeError("pred_ofsts must be a float tensor of shape (bs, n_kpts, n_pts, 3)")
+    w_labels = (labels.reshape(bs, n_pts) > 1e-8).float().contiguous()
+    targ = kp_targ_ofst.reshape(bs, n_pts, n_kpts, 3).float()
+    if not normalize:
+        w = w_labels.view(bs, 1, n_pts, 1)
+        return w * torch.abs(pred_ofsts - targ.permute(0, 2, 1, 3))
+    return _OfL1Loss.apply(pred_ofsts, targ, w_labels)
+
+
+class OFLoss(_Loss):
+    def __init__(self):
+        super(OFLoss, self).__init__(True)
+
+    def forward(self, pred_ofsts, kp_targ_ofst, labels, normalize=True, reduce=False):
+        return of_l1_loss(pred_ofsts, kp_targ_ofst, labels, sigma=1.0, normalize=True, reduce=False)

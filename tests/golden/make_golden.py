@@ -200,6 +200,33 @@ def main():
     np.savez_compressed(os.path.join(HERE, "metrics_ref.npz"), **mt)
     print("metric cases", nm, na)
 
+    # ------------------------------------------------------------------ vote loss (lib/loss.py:45-73)
+    if "lib.utils.meanshift_pytorch" not in sys.modules:
+        _stub("lib.utils.meanshift_pytorch", MeanShiftTorch=ms_mod.MeanShiftTorch)
+    spec = importlib.util.spec_from_file_location("ref_loss", os.path.join(REF, "lib/loss.py"))
+    loss_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(loss_mod)
+    rng_l = np.random.default_rng(20260926)
+    lz = {}
+    nl = 0
+    for (bs, K, N, frac) in [(2, 8, 500, 0.3), (1, 1, 257, 1.0), (3, 8, 64, 0.0), (2, 3, 1000, 0.05)]:
+        pred = torch.from_numpy(rng_l.normal(size=(bs, K, N, 3)).astype(np.float32)).requires_grad_(True)
+        targ = torch.from_numpy(rng_l.normal(size=(bs, N, K, 3)).astype(np.float32))
+        labels = torch.from_numpy((rng_l.random((bs, N, 1)) < frac).astype(np.int64) * rng_l.integers(1, 5, (bs, N, 1)))
+        if nl == 0:
+            with torch.no_grad():
+                pred[0, 0, :7] = targ[0, :7, 0]                      # exact zeros: sign(0) = 0
+        out = loss_mod.of_l1_loss(pred, targ, labels)
+        g = torch.from_numpy(rng_l.normal(size=tuple(out.shape)).astype(np.float32))
+        out.backward(g)
+        lz["pred%d" % nl] = pred.detach().numpy(); lz["targ%d" % nl] = targ.numpy()
+        lz["labels%d" % nl] = labels.numpy(); lz["loss%d" % nl] = out.detach().numpy()
+        lz["gout%d" % nl] = g.numpy(); lz["gpred%d" % nl] = pred.grad.numpy()
+        nl += 1
+    lz["n_cases"] = np.int64(nl)
+    np.savez_compressed(os.path.join(HERE, "loss_ref.npz"), **lz)
+    print("loss cases", nl)
+
     # ------------------------------------------------------------------ whole frames
     def ref_fit(A, bw):
         if len(A) == 0:

@@ -321,3 +321,27 @@ def test_relabel_by_centre_kernel_vs_reference_formula(dev):
         assert np.array_equal(new_mask[f], want), int((new_mask[f] != want).sum())
         assert np.array_equal(np.nonzero(present_new[f])[0] + 1, np.unique(want[want > 0]))
         assert (new_mask[f] != mask[f]).sum() > 50             # the test really re-labels
+
+
+@pytest.mark.gpu
+def test_vote_loss_forward_backward_vs_reference_golden(dev, golden):
+    """csrc/vote_loss.hip through the reference's of_l1_loss / OFLoss signatures: value and
+    autograd gradient against the reference's own outputs (fixtures); run-to-run bit-stable."""
+    from pvn3d_amd.lib.loss import OFLoss, of_l1_loss
+    z = golden("loss_ref.npz")
+    for i in range(int(z["n_cases"])):
+        pred = torch.from_numpy(z["pred%d" % i]).to(dev).requires_grad_(True)
+        targ = torch.from_numpy(z["targ%d" % i]).to(dev)
+        labels = torch.from_numpy(z["labels%d" % i]).to(dev)
+        out = of_l1_loss(pred, targ, labels)
+        assert out.shape == tuple(z["loss%d" % i].shape)
+        assert np.allclose(out.detach().cpu().numpy(), z["loss%d" % i], rtol=1e-5, atol=1e-7)
+        out.backward(torch.from_numpy(z["gout%d" % i]).to(dev))
+        assert np.allclose(pred.grad.cpu().numpy(), z["gpred%d" % i], rtol=1e-5, atol=1e-9)
+        again = OFLoss()(pred.detach(), targ, labels)
+        assert torch.equal(again, out.detach())                    # deterministic summation
+    # normalize=False returns the weighted |diff| tensor like the reference
+    full = of_l1_loss(pred.detach(), targ, labels, normalize=False)
+    assert full.shape == pred.shape
+    with pytest.raises(RuntimeError):
+        of_l1_loss(pred.detach().cpu(), targ.cpu(), labels.cpu())

@@ -135,3 +135,15 @@ def test_host_auc_equals_reference(golden):
     z = golden("metrics_ref.npz")
     for i in range(int(z["n_auc"])):
         assert abs(ns["_U"]().cal_auc(list(z["dis%d" % i])) - float(z["auc%d" % i])) < 1e-9
+
+
+def test_vote_loss_oracle_vs_reference(golden):
+    """oracle/loss.py against the reference's own of_l1_loss output and autograd gradient."""
+    from oracle import loss as oloss
+    z = golden("loss_ref.npz")
+    for i in range(int(z["n_cases"])):
+        pred, targ, labels = z["pred%d" % i], z["targ%d" % i], z["labels%d" % i]
+        out = oloss.of_l1_loss(pred, targ, labels)
+        assert np.allclose(out, z["loss%d" % i], rtol=2e-6, atol=1e-7)
+        g = oloss.of_l1_loss_grad(pred, targ, labels, z["gout%d" % i])
+        assert np.allclose(g, z["gpred%d" % i], rtol=2e-6, atol=1e-9)
