@@ -337,3 +337,63 @@ def test_fused_fp_mlp_and_full_pointnet2msg(dev):
     net.train()
     out = net(pc[:, :2048].clone().requires_grad_(False))
     assert out.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,mlp,ns,npoint,n", [
+    (0, [0, 24, 40], 64, 40, 500),          # no features (K = 3), nsample 64: both column tiles one centre
+    (40, [40, 48, 100], 8, 70, 300),        # one 16-byte row-gather chunk + generic tail, nsample 8
+    (64, [64, 300, 512], 4, 33, 200),       # two-tile waves (M = 512), nsample 4, ragged column count
+    (5, [5, 20], 2, 17, 100),               # single layer, nsample 2, scalar gather (ld % 4 != 0 after transpose pad)
+    (96, [96, 130, 260, 70], 1, 50, 120),   # three layers, nsample 1 (no pooling), M not a multiple of 32
+])
+def test_fused_sa_mlp_generic_paths(dev, c_in, mlp, ns, npoint, n):
+    """Less common shapes of the fused SA kernel (run-time nsample reductions, generic loaders,
+    wide / ragged tiles) against the op-by-op torch composition."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    torch.manual_seed(3)
+    sa = pm.PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=0.08, nsample=ns).to(dev).eval()
+    _randomize_bn(sa)
+    xyz = T(clouds(11, 2, n, 0.1), dev)
+    feats = torch.randn(2, c_in, n, device=dev) if c_in > 0 else None
+    with torch.no_grad():
+        _, out_f = sa(xyz, feats)
+        pm.FUSED_INFERENCE = False
+        try:
+            _, out_u = sa(xyz, feats)
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert getattr(sa.mlps[0], "_pvn3d_packed")[1] is not None
+    assert out_f.shape == out_u.shape
+    assert (out_f - out_u).abs().max().item() < 1e-4 * max(out_u.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c2,c1,mlp,n,m", [
+    (70, 0, [70, 64], 300, 90),             # known width not a multiple of 32, no skip features
+    (64, 33, [97, 140, 30], 257, 64),       # skip features with a generic tail
+    (128, 64, [192, 512, 512], 130, 40),    # two-tile waves
+])
+def test_fused_fp_mlp_generic_paths(dev, c2, c1, mlp, n, m):
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    torch.manual_seed(4)
+    fp = pm.PointnetFPModule(mlp=list(mlp)).to(dev).eval()
+    _randomize_bn(fp)
+    unknown = T(clouds(12, 2, n, 0.1), dev)
+    known = unknown[:, :m].contiguous()
+    uf = torch.randn(2, c1, n, device=dev) if c1 > 0 else None
+    kf = torch.randn(2, c2, m, device=dev)
+    outs = []
+    with torch.no_grad():
+        for pmo in (False, True):
+            fp._point_major_out = pmo
+            outs.append(fp(unknown, known, uf, kf))
+        fp._point_major_out = False
+        pm.FUSED_INFERENCE = False
+        try:
+            ref = fp(unknown, known, uf, kf)
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert outs[0].is_contiguous() and not outs[1].is_contiguous()      # API layout vs point-major view
+    assert torch.equal(outs[0], outs[1].contiguous())
+    assert (outs[0] - ref).abs().max().item() < 1e-4 * max(ref.abs().max().item(), 1.0)
