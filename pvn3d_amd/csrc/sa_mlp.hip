@@ -177,31 +177,35 @@ __device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__
 // ---- MFMA spans ---------------------------------------------------------------------------
 // B fragment pair q of a [rows][64] LDS buffer: rows 4q + 2j + half, column tiles col, col+32.
 // SWZ: row r is stored rotated by (r & ~3) columns.
-template <bool SWZ>
-__device__ __forceinline__ void ld_b(float (&b)[2][2], const float* __restrict__ rows_half, int col, int q) {
+// CS (column split): only column tile `ct` is fetched, into b[j][0].
+template <bool SWZ, bool CS>
+__device__ __forceinline__ void ld_b(float (&b)[2][2], const float* __restrict__ rows_half, int col, int q, int ct) {
   const float* r0 = rows_half + q * 4 * SM_COLS;
   if (SWZ) {
-    const int c0 = (col + 4 * q) & 63, c1 = c0 ^ 32;
-    b[0][0] = r0[c0]; b[0][1] = r0[c1];
-    b[1][0] = r0[2 * SM_COLS + c0]; b[1][1] = r0[2 * SM_COLS + c1];
+    const int c0 = ((col + 4 * q) & 63) ^ (CS ? ct * 32 : 0), c1 = c0 ^ 32;
+    b[0][0] = r0[c0];
+    b[1][0] = r0[2 * SM_COLS + c0];
+    if (!CS) { b[0][1] = r0[c1]; b[1][1] = r0[2 * SM_COLS + c1]; }
   } else {
-    b[0][0] = r0[col]; b[0][1] = r0[col + 32];
-    b[1][0] = r0[2 * SM_COLS + col]; b[1][1] = r0[2 * SM_COLS + col + 32];
+    const int c0 = col + (CS ? ct * 32 : 0);
+    b[0][0] = r0[c0];
+    b[1][0] = r0[2 * SM_COLS + c0];
+    if (!CS) { b[0][1] = r0[c0 + 32]; b[1][1] = r0[2 * SM_COLS + c0 + 32]; }
   }
 }
 
-template <int NTC, int NT>
+template <int NTC, int NT, bool CS>
 __device__ __forceinline__ void mm_pair(f32x16 (&acc)[NT][2], const float2 (&a)[NTC > 0 ? NTC : 1],
                                         const float (&b)[2][2]) {
 #pragma unroll
   for (int t = 0; t < NTC; ++t) {
     acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0][0], acc[t][0], 0, 0, 0);
-    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0][1], acc[t][1], 0, 0, 0);
+    if (!CS) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[0][1], acc[t][1], 0, 0, 0);
   }
 #pragma unroll
   for (int t = 0; t < NTC; ++t) {
     acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1][0], acc[t][0], 0, 0, 0);
-    acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1][1], acc[t][1], 0, 0, 0);
+    if (!CS) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[1][1], acc[t][1], 0, 0, 0);
   }
 }
 
@@ -221,38 +225,39 @@ __device__ __forceinline__ void ring_load(float2 (&slot)[NTC > 0 ? NTC : 1], con
 
 // 8 pairs starting at global pair p0 (ring slot u holds pair p0+u), B rows from `rows_half`
 // (local pair 0 = first row of the buffer); refills every slot with the pair 8 ahead.
-template <int NTC, int NT, bool SWZ>
+template <int NTC, int NT, bool SWZ, bool CS>
 __device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
-                                      const WPtr& w, int p0, const float* __restrict__ rows_half, int col) {
+                                      const WPtr& w, int p0, const float* __restrict__ rows_half, int col,
+                                      int ct) {
   if (NTC == 0) return;
   // B fragments two pairs ahead (three register sets): one pair (<= 512 cycles of this wave's
   // MFMAs) does not always cover the LDS latency when all eight waves read at once
   float b[3][2][2];
-  ld_b<SWZ>(b[0], rows_half, col, 0);
-  ld_b<SWZ>(b[1], rows_half, col, 1);
+  ld_b<SWZ, CS>(b[0], rows_half, col, 0, ct);
+  ld_b<SWZ, CS>(b[1], rows_half, col, 1, ct);
 #pragma unroll
   for (int u = 0; u < SM_CP; ++u) {
     // keep this order (fences): left alone, the scheduler sinks every LDS read to just before its
     // MFMA (exposing the LDS latency once per pair) and bunches the refills at the chunk end
-    if (u + 2 < SM_CP) ld_b<SWZ>(b[(u + 2) % 3], rows_half, col, u + 2);
+    if (u + 2 < SM_CP) ld_b<SWZ, CS>(b[(u + 2) % 3], rows_half, col, u + 2, ct);
     __builtin_amdgcn_sched_barrier(0);
-    mm_pair<NTC, NT>(acc, ring[u], b[u % 3]);
+    mm_pair<NTC, NT, CS>(acc, ring[u], b[u % 3]);
     ring_load<NTC>(ring[u], w, p0 + SM_CP + u);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // the last np (< 8, possibly 0) pairs of a layer: no refill
-template <int NTC, int NT, bool SWZ>
+template <int NTC, int NT, bool SWZ, bool CS>
 __device__ __forceinline__ void span_tail(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
-                                          int np, const float* __restrict__ rows_half, int col) {
+                                          int np, const float* __restrict__ rows_half, int col, int ct) {
   if (NTC == 0) return;
 #pragma unroll
   for (int u = 0; u < SM_CP - 1; ++u) {
     if (u < np) {
       float b[2][2];
-      ld_b<SWZ>(b, rows_half, col, u);
-      mm_pair<NTC, NT>(acc, ring[u], b);
+      ld_b<SWZ, CS>(b, rows_half, col, u, ct);
+      mm_pair<NTC, NT, CS>(acc, ring[u], b);
     }
   }
 }
@@ -363,8 +368,10 @@ struct Chain {
 
   __device__ __forceinline__ const RowSrc& srcA() const { return IS_SA ? sa.feat : fp.known; }
 
-  template <int NTC>
-  __device__ __forceinline__ void layer0(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total) {
+  // tile0: first row tile of this wave (tiles tile0, tile0 + NW, ...); CS: the wave owns only
+  // column tile `ct` of row tile tile0 (layers with <= NW/2 row tiles, see run())
+  template <int NTC, bool CS>
+  __device__ __forceinline__ void layer0(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int tile0, int ct) {
     float2 ring[SM_CP][NTC > 0 ? NTC : 1];
 #pragma unroll
     for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
@@ -391,8 +398,8 @@ struct Chain {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-      acc_bias(acc[t][0], s_bias + (wave + NW * t) * 32, half);
-      acc[t][1] = acc[t][0];
+      acc_bias(acc[t][0], s_bias + (tile0 + NW * t) * 32, half);
+      if (!CS) acc[t][1] = acc[t][0];
     }
 
     // ---- steady state: gather chunk g while chunk g-1 is multiplied
@@ -400,7 +407,7 @@ struct Chain {
     for (; g < nA; ++g) {
       PStage<NBA, PIT> st;
       p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
-      span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
       p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.w, tid);
       __syncthreads();
     }
@@ -408,7 +415,7 @@ struct Chain {
       for (; g < nAB; ++g) {
         PStage<1, PIT> st;
         p_issue<1, PIT, NTHR>(st, fp.unknown, bi, (g - nA) * SM_KC, nullptr, col0, id_max, tid);
-        span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+        span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
         p_commit<1, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.aux, tid);
         __syncthreads();
       }
@@ -418,7 +425,7 @@ struct Chain {
 #pragma unroll
       for (int i = 0; i < LROWS; ++i)
         stage[i] = c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, g * SM_KC + lr0 + NW * i);
-      span8<NTC, NT, true>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col);
+      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
 #pragma unroll
       for (int i = 0; i < LROWS; ++i) c_store(chunk + (g & 1) * SM_KC * SM_COLS, lr0 + NW * i, lc, stage[i]);
       __syncthreads();
@@ -428,27 +435,28 @@ struct Chain {
     const int np = pairs_total - p0;       // 1..8
     const float* rows_half = chunk + ((n_chunks - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS;
     if (np == SM_CP)
-      span8<NTC, NT, true>(acc, ring, w, p0, rows_half, col);
+      span8<NTC, NT, true, CS>(acc, ring, w, p0, rows_half, col, ct);
     else
-      span_tail<NTC, NT, true>(acc, ring, np, rows_half, col);
+      span_tail<NTC, NT, true, CS>(acc, ring, np, rows_half, col, ct);
   }
 
-  template <int NTC>
-  __device__ __forceinline__ void layerN(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int boff) {
+  template <int NTC, bool CS>
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int boff, int tile0,
+                                         int ct) {
     float2 ring[SM_CP][NTC > 0 ? NTC : 1];
 #pragma unroll
     for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-      acc_bias(acc[t][0], s_bias + boff + (wave + NW * t) * 32, half);
-      acc[t][1] = acc[t][0];
+      acc_bias(acc[t][0], s_bias + boff + (tile0 + NW * t) * 32, half);
+      if (!CS) acc[t][1] = acc[t][0];
     }
     const float* rows_half = H + half * SM_COLS;
     int p0 = 0;
     for (; p0 + SM_CP <= pairs_total; p0 += SM_CP)
-      span8<NTC, NT, false>(acc, ring, w, p0, rows_half + (size_t)p0 * 4 * SM_COLS, col);
-    span_tail<NTC, NT, false>(acc, ring, pairs_total - p0, rows_half + (size_t)p0 * 4 * SM_COLS, col);
+      span8<NTC, NT, false, CS>(acc, ring, w, p0, rows_half + (size_t)p0 * 4 * SM_COLS, col, ct);
+    span_tail<NTC, NT, false, CS>(acc, ring, pairs_total - p0, rows_half + (size_t)p0 * 4 * SM_COLS, col, ct);
   }
 
   __device__ __forceinline__ void run(const OutDesc& od) {
@@ -458,20 +466,33 @@ struct Chain {
     for (int l = 0; l < d.n_layers; ++l) {
       const int K = d.K[l], M = d.M[l];
       const int mt_total = (M + 31) >> 5;
-      const int nt = (mt_total - wave + NW - 1) / NW;     // row tiles of this wave (<= NT)
+      // Column split: a non-final layer with <= NW/2 row tiles would leave half of the waves
+      // without MFMA work; there wave u takes (row tile u % mt_total, column tile u / mt_total).
+      // (one-tile SA kernels only: the two-tile kernels serve M > 128, and every extra
+      // instantiation of the layer code in one kernel costs registers -- the FP level-0 kernel got
+      // 7 % slower from the additional spills alone)
+      const bool cs = (NT == 1) && IS_SA && (2 * mt_total <= NW) && (l + 1 < d.n_layers);
+      const int tile0 = cs ? wave % mt_total : wave;
+      const int ct = cs ? wave / mt_total : 0;
+      const int nt = cs ? (ct < 2 ? 1 : 0) : (mt_total - wave + NW - 1) / NW;   // row tiles of this wave (<= NT)
       const int pairs_total = (K + 3) >> 2;
       WPtr w;
-      w.wp = reinterpret_cast<const float2*>(d.W[l]) + (size_t)wave * 64 + lane;
+      w.wp = reinterpret_cast<const float2*>(d.W[l]) + (size_t)tile0 * 64 + lane;
       w.pstride = (size_t)mt_total * 64;
       w.tstride = (size_t)NW * 64;
       w.last = pairs_total - 1;
       if (l == 0) {
-        if (nt >= NT) layer0<NT>(acc, w, pairs_total);
-        else if (NT > 1 && nt == NT - 1) layer0<(NT > 1 ? NT - 1 : 0)>(acc, w, pairs_total);
-        else layer0<0>(acc, w, pairs_total);
+        if (cs) {
+          if (nt) layer0<1, true>(acc, w, pairs_total, tile0, ct);
+          else layer0<0, false>(acc, w, pairs_total, tile0, ct);
+        } else if (nt >= NT) layer0<NT, false>(acc, w, pairs_total, tile0, ct);
+        else if (NT > 1 && nt == NT - 1) layer0<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, tile0, ct);
+        else layer0<0, false>(acc, w, pairs_total, tile0, ct);
       } else {
-        if (nt >= NT) layerN<NT>(acc, w, pairs_total, boff);
-        else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0)>(acc, w, pairs_total, boff);
+        if (cs) {
+          if (nt) layerN<1, true>(acc, w, pairs_total, boff, tile0, ct);
+        } else if (nt >= NT) layerN<NT, false>(acc, w, pairs_total, boff, tile0, ct);
+        else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, boff, tile0, ct);
       }
       __syncthreads();   // every wave has finished reading this layer's input
       SM_STAMP(1 + 2 * l);
@@ -480,15 +501,25 @@ struct Chain {
         // rows [M, roundup32(M)) come out as relu(0 + 0) = 0 (zero-padded weights and bias), which
         // covers the next layer's K rounded up to a multiple of 4
         const int half = lane >> 5, col = lane & 31;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
-            const int mt = wave + NW * t;
+        if (cs) {
+          if (nt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-              H[row * SM_COLS + col] = fmaxf(acc[t][0][r], 0.f);
-              H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r], 0.f);
+              const int row = tile0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              H[row * SM_COLS + ct * 32 + col] = fmaxf(acc[0][0][r], 0.f);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (t < nt) {
+              const int mt = wave + NW * t;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                H[row * SM_COLS + col] = fmaxf(acc[t][0][r], 0.f);
+                H[row * SM_COLS + 32 + col] = fmaxf(acc[t][1][r], 0.f);
+              }
             }
           }
         }
