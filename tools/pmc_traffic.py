@@ -15,8 +15,9 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 STAGE_OF = [("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
-            ("mlp_chain_cols_kernel<true", "sa_mlp"), ("mlp_chain_kernel<false", "fp_mlp"),
-            ("mlp_chain_wide_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
+            ("mlp_chain_mid_kernel<true", "sa_mlp"), ("mlp_chain_cols_kernel<true", "sa_mlp"),
+            ("mlp_chain_kernel<false", "fp_mlp"), ("mlp_chain_wide_kernel<false", "fp_mlp"),
+            ("mlp_chain_mid_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
             ("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
             ("ball_query", "ball_query"), ("grid_build", "ball_query"), ("three_nn", "three_nn"),
             ("fps_", "fps"), ("gather_points", "gather"), ("ms_", "vote_cluster_pose"),
