@@ -255,6 +255,19 @@ int pvn3d_of_l1_loss_grad(int bs, int n_kpts, int n_pts, const float* pred_ofsts
                           const float* kp_targ_ofst, const float* labels, const float* wsum,
                           const float* grad_loss, float* grad_pred, void* stream);
 
+/* Bit-reproducible forms of the backward scatters: same results as
+ * pvn3d_group_points_grad / pvn3d_gather_points_grad (nsample = 1) / pvn3d_three_interpolate_grad
+ * up to fp32 rounding, but independent of the order in which the contributions are added
+ * (64-bit fixed-point accumulation with integer atomics, csrc/scatter_det.hip).
+ * workspace >= pvn3d_scatter_det_workspace_bytes(b, c, n_targets) bytes (n_targets = n resp. m). */
+size_t pvn3d_scatter_det_workspace_bytes(int b, int c, int n_targets);
+int pvn3d_group_points_grad_det(int b, int c, int n, int npoints, int nsample,
+                                const float* grad_out, const int* idx, float* grad_points,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int pvn3d_three_interpolate_grad_det(int b, int c, int n, int m, const float* grad_out,
+                                     const int* idx, const float* weight, float* grad_points,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

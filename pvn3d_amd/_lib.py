@@ -39,6 +39,9 @@ SIGNATURES = {
     "pvn3d_meanshift_fit_batch": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p, _i, _i, _p]),
     "pvn3d_vote_compact": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p]),
     "pvn3d_best_fit_transform": (_i, [_i, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_scatter_det_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pvn3d_group_points_grad_det": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "pvn3d_three_interpolate_grad_det": (_i, [_i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pvn3d_of_l1_loss": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "pvn3d_of_l1_loss_grad": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "pvn3d_relabel_by_centre": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -71,6 +71,16 @@ def gather_points(points, idx):
     return out
 
 
+# Backward scatters: False = float atomics like the reference (result depends on the arrival order
+# in the last bits); True = 64-bit fixed-point accumulation, bit-reproducible (csrc/scatter_det.hip).
+DETERMINISTIC_GRADS = False
+
+
+def _det_ws(B, C, n, dev):
+    nbytes = int(lib.pvn3d_scatter_det_workspace_bytes(B, C, int(n)))
+    return torch.empty((nbytes,), dtype=torch.uint8, device=dev), nbytes
+
+
 def gather_points_grad(grad_out, idx, n):
     """grad_out (B,C,npoint), idx (B,npoint) -> (B,C,n).  sampling.cpp:40-64"""
     _chk(grad_out, "grad_out", torch.float32)
@@ -78,6 +88,13 @@ def gather_points_grad(grad_out, idx, n):
     _same_dev(grad_out, idx, "idx")
     B, C, m = grad_out.shape
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    if DETERMINISTIC_GRADS:
+        ws, nbytes = _det_ws(B, C, n, grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            check(lib.pvn3d_group_points_grad_det(B, C, int(n), m, 1, grad_out.data_ptr(), idx.data_ptr(),
+                                                  out.data_ptr(), ws.data_ptr(), nbytes, _stream(grad_out)),
+                  "gather_points_grad_det")
+        return out
     with torch.cuda.device(grad_out.device):
         check(lib.pvn3d_gather_points_grad(B, C, int(n), m, grad_out.data_ptr(), idx.data_ptr(),
                                            out.data_ptr(), _stream(grad_out)), "gather_points_grad")
@@ -138,6 +155,13 @@ def group_points_grad(grad_out, idx, n):
     _same_dev(grad_out, idx, "idx")
     B, C, npoint, nsample = grad_out.shape
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    if DETERMINISTIC_GRADS:
+        ws, nbytes = _det_ws(B, C, n, grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            check(lib.pvn3d_group_points_grad_det(B, C, int(n), npoint, nsample, grad_out.data_ptr(),
+                                                  idx.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes,
+                                                  _stream(grad_out)), "group_points_grad_det")
+        return out
     with torch.cuda.device(grad_out.device):
         check(lib.pvn3d_group_points_grad(B, C, int(n), npoint, nsample, grad_out.data_ptr(),
                                           idx.data_ptr(), out.data_ptr(), _stream(grad_out)),
@@ -186,6 +210,13 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _same_dev(grad_out, weight, "weight")
     B, C, n = grad_out.shape
     out = torch.empty((B, C, int(m)), dtype=torch.float32, device=grad_out.device)
+    if DETERMINISTIC_GRADS and not REFERENCE_BUG_COMPAT:
+        ws, nbytes = _det_ws(B, C, m, grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            check(lib.pvn3d_three_interpolate_grad_det(B, C, n, int(m), grad_out.data_ptr(), idx.data_ptr(),
+                                                       weight.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes,
+                                                       _stream(grad_out)), "three_interpolate_grad_det")
+        return out
     with torch.cuda.device(grad_out.device):
         check(lib.pvn3d_three_interpolate_grad(B, C, n, int(m), grad_out.data_ptr(), idx.data_ptr(),
                                                weight.data_ptr(), out.data_ptr(),

@@ -397,3 +397,50 @@ def test_fused_fp_mlp_generic_paths(dev, c2, c1, mlp, n, m):
     assert outs[0].is_contiguous() and not outs[1].is_contiguous()      # API layout vs point-major view
     assert torch.equal(outs[0], outs[1].contiguous())
     assert (outs[0] - ref).abs().max().item() < 1e-4 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+def test_deterministic_backward_scatters(ext, orc, dev):
+    """DETERMINISTIC_GRADS: fixed-point accumulation -- equal to the exact (float64) sums to fp32
+    rounding, bit-identical run to run (heavy index collisions, values over 12 orders of magnitude),
+    and the autograd path of QueryAndGroup uses it."""
+    g = np.random.default_rng(31)
+    b, c, n, m, ns = 2, 5, 300, 2048, 32
+    idx = (g.integers(0, 12, size=(b, m, ns)) ** 2 % n).astype(np.int32)      # ~12 hot targets
+    gg = (g.normal(size=(b, c, m, ns)) * 10.0 ** g.integers(-6, 6, size=(b, c, m, ns))).astype(np.float32)
+    i3 = g.integers(0, 40, size=(b, n * 20, 3)).astype(np.int32)
+    w = g.random((b, n * 20, 3)).astype(np.float32)
+    gi = g.normal(size=(b, c, n * 20)).astype(np.float32)
+    i1 = g.integers(0, 7, size=(b, m)).astype(np.int32)
+    go = g.normal(size=(b, c, m)).astype(np.float32)
+
+    def exact_group(gg, idx, n):
+        out = np.zeros((b, gg.shape[1], n), np.float64)
+        for bi in range(b):
+            for l in range(gg.shape[1]):
+                np.add.at(out[bi, l], idx[bi].reshape(-1), gg[bi, l].reshape(-1).astype(np.float64))
+        return out
+
+    def exact_interp(gi, i3, w, m_):
+        out = np.zeros((b, gi.shape[1], m_), np.float64)
+        for bi in range(b):
+            for l in range(gi.shape[1]):
+                for k in range(3):
+                    np.add.at(out[bi, l], i3[bi, :, k], (gi[bi, l] * w[bi, :, k]).astype(np.float32).astype(np.float64))
+        return out
+    try:
+        ext.DETERMINISTIC_GRADS = True
+        runs = [(ext.group_points_grad(T(gg, dev), T(idx, dev), n).cpu().numpy(),
+                 ext.three_interpolate_grad(T(gi, dev), T(i3, dev), T(w, dev), 40).cpu().numpy(),
+                 ext.gather_points_grad(T(go, dev), T(i1, dev), n).cpu().numpy()) for _ in range(3)]
+    finally:
+        ext.DETERMINISTIC_GRADS = False
+    for r in runs[1:]:
+        assert all(np.array_equal(a, b_) for a, b_ in zip(r, runs[0]))
+    # one rounding of the exact sum (the fixed-point grid is finer than fp32 at every magnitude here)
+    assert np.array_equal(runs[0][0], exact_group(gg, idx, n).astype(np.float32))
+    assert np.array_equal(runs[0][1], exact_interp(gi, i3, w, 40).astype(np.float32))
+    assert np.array_equal(runs[0][2], exact_group(go[..., None], i1[..., None], n).astype(np.float32))
+    # the float-atomic default agrees to fp32 summation error
+    fa = ext.group_points_grad(T(gg, dev), T(idx, dev), n).cpu().numpy()
+    assert np.allclose(fa, runs[0][0], rtol=1e-4, atol=1e-3 * np.abs(gg).max())
