@@ -31,3 +31,59 @@ def gather_frame_results(local, n_items, group=None):
     bufs = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Training (BASELINE config 5): data-parallel gradient averaging, one process per GPU.
+# The reference wraps the model in nn.DataParallel (train/train_linemod_pvn3d.py:480): one
+# process scatters the batch, replicates the weights every step and reduces gradients to GPU 0.
+# Here every rank owns a model replica and the gradients are all-reduced in a few large buckets.
+# xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is bound by one
+# link: buckets are large (default 64 MiB, a few hundred microseconds of wire time each) to
+# amortise the per-collective latency, and are issued asynchronously in reverse parameter order
+# (the order backward produces them) so the first buckets fly while later ones are still packed.
+# ---------------------------------------------------------------------------------------------
+
+def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=True):
+    """Average (or sum) `.grad` of `parameters` over the process group in place.
+    Returns the number of buckets used.  Parameters without a gradient are skipped on every rank
+    alike (the model is the same on all ranks)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    ws = dist.get_world_size(group)
+    params = [p for p in parameters if p.grad is not None]
+    params.reverse()
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nb = p.grad.numel() * p.grad.element_size()
+        if cur and (cur_bytes + nb > bucket_bytes or p.grad.dtype != cur[0].grad.dtype):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nb
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for bk in buckets:
+        flat = torch.cat([p.grad.reshape(-1) for p in bk])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending.append((work, flat, bk))
+    for work, flat, bk in pending:
+        work.wait()
+        if average:
+            flat.div_(ws)
+        off = 0
+        for p in bk:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    return len(buckets)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s weights and buffers (what DataParallel's per-step
+    replication guarantees implicitly)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
