@@ -30,7 +30,10 @@
 namespace {
 
 constexpr int MS_THREADS = 256;
-constexpr int MS_CHUNK = 1024;  // points staged in LDS per step (16 KiB)
+// points staged in LDS per step: 8 KiB, so that a workgroup of these VALU kernels still fits beside
+// a 151 KB fused-MLP workgroup (csrc/sa_mlp.hip) on the same CU when the two halves of the path
+// run concurrently (measured: no slowdown vs 16 KiB chunks when running alone)
+constexpr int MS_CHUNK = 512;
 
 struct MsState {        // device-side layout inside the caller's workspace
   float4* cbuf[2];      // seed positions, scaled+centred frame, double-buffered

@@ -230,18 +230,18 @@ __device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP
                                       const WPtr& w, int p0, const float* __restrict__ rows_half, int col,
                                       int ct) {
   if (NTC == 0) return;
-  // B fragments two pairs ahead (three register sets): one pair (<= 512 cycles of this wave's
-  // MFMAs) does not always cover the LDS latency when all eight waves read at once
-  float b[3][2][2];
+  // B fragments one pair ahead (two pairs ahead measured no faster and costs 4 VGPRs, which
+  // pushes the two-tile kernels over 240 -- the budget that leaves room for a 32-VGPR wave of a
+  // concurrently running VALU kernel on the same SIMD)
+  float b[2][2][2];
   ld_b<SWZ, CS>(b[0], rows_half, col, 0, ct);
-  ld_b<SWZ, CS>(b[1], rows_half, col, 1, ct);
 #pragma unroll
   for (int u = 0; u < SM_CP; ++u) {
     // keep this order (fences): left alone, the scheduler sinks every LDS read to just before its
     // MFMA (exposing the LDS latency once per pair) and bunches the refills at the chunk end
-    if (u + 2 < SM_CP) ld_b<SWZ, CS>(b[(u + 2) % 3], rows_half, col, u + 2, ct);
+    if (u + 1 < SM_CP) ld_b<SWZ, CS>(b[(u + 1) & 1], rows_half, col, u + 1, ct);
     __builtin_amdgcn_sched_barrier(0);
-    mm_pair<NTC, NT, CS>(acc, ring[u], b[u % 3]);
+    mm_pair<NTC, NT, CS>(acc, ring[u], b[u & 1]);
     ring_load<NTC>(ring[u], w, p0 + SM_CP + u);
     __builtin_amdgcn_sched_barrier(0);
   }
