@@ -44,6 +44,10 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* iters;           // [n_seg]
   unsigned long long* best;  // [n_seg]  (count << 32) | ~index
   int* active;          // [2]
+  int* counts;          // [total]  neighbour count of every point (pruned count, below)
+  int* core_idx;        // [total]  per segment: indices of "core" points, ascending
+  int* nc_idx;          // [total]  per segment: indices of the other points, ascending
+  int* n_core;          // [n_seg]
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -61,6 +65,10 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_it = take(sizeof(int) * (size_t)n_seg);
   const size_t o_best = take(sizeof(unsigned long long) * (size_t)n_seg);
   const size_t o_act = take(sizeof(int) * 2);
+  const size_t o_cnt = take(sizeof(int) * (size_t)total);
+  const size_t o_core = take(sizeof(int) * (size_t)total);
+  const size_t o_nc = take(sizeof(int) * (size_t)total);
+  const size_t o_ncore = take(sizeof(int) * (size_t)n_seg);
   if (st) {
     st->cbuf[0] = (float4*)(base + o_c0);
     st->cbuf[1] = (float4*)(base + o_c1);
@@ -71,6 +79,10 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->iters = (int*)(base + o_it);
     st->best = (unsigned long long*)(base + o_best);
     st->active = (int*)(base + o_act);
+    st->counts = (int*)(base + o_cnt);
+    st->core_idx = (int*)(base + o_core);
+    st->nc_idx = (int*)(base + o_nc);
+    st->n_core = (int*)(base + o_ncore);
   }
   (void)o_small;
   return off;
@@ -657,6 +669,168 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Pruned neighbour count (exact).  The reference counts, for every point i, the points within bw
+// (meanshift_pytorch.py:46-48): n^2 distance tests.  Votes are tightly clustered, so most pairs
+// are decided by the triangle inequality around the segment mean m: with r_i = |a_i - m|,
+//   r_i <= R and r_j <= R, R = 0.499 bw   =>   |a_i - a_j| <= 0.998 bw,
+// which is a hit under the reference's fp32 test as well (its rounding error is ~1e-7 relative,
+// the margin 2e-3).  "Core" points (r <= R) therefore all count each other without a test;
+// only pairs with a non-core partner are evaluated, with exactly the arithmetic of
+// ms_count_kernel.  counts[i] = (core_i ? n_core : hits among core columns)
+//                              + hits among non-core columns.
+// Worst case (no core points) = the full n^2 scan; typical votes: ~10 % of it.
+// ---------------------------------------------------------------------------------------
+// grid (n_seg), block 1024
+__global__ __launch_bounds__(1024) void ms_classify_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
+    float r_core, int* __restrict__ core_idx, int* __restrict__ nc_idx, int* __restrict__ n_core) {
+  __shared__ double s_sum[3][16];
+  __shared__ float s_mean[3];
+  __shared__ int s_wc[16], s_run[2];
+  const int seg = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int n = seg_cnt[seg];
+  if (n <= 0) { if (tid == 0) n_core[seg] = 0; return; }
+  const int base = seg_off[seg];
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int i = tid; i < n; i += 1024) { const float4 a = pts[base + i]; sx += a.x; sy += a.y; sz += a.z; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
+  }
+  if (lane == 0) { s_sum[0][wid] = sx; s_sum[1][wid] = sy; s_sum[2][wid] = sz; }
+  if (tid < 2) s_run[tid] = 0;
+  __syncthreads();
+  if (tid < 3) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += s_sum[tid][w];
+    s_mean[tid] = (float)(t / (double)n);
+  }
+  __syncthreads();
+  const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
+  const float r2 = r_core * r_core;
+  // order-preserving compaction of both classes (deterministic lists)
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    bool core = false, valid = i < n;
+    if (valid) {
+      const float4 a = pts[base + i];
+      const float dx = a.x - mx, dy = a.y - my, dz = a.z - mz;
+      core = (dx * dx + dy * dy) + dz * dz <= r2;
+    }
+    const unsigned long long bc = __ballot(valid && core);
+    const unsigned long long bn = __ballot(valid && !core);
+    if (lane == 0) s_wc[wid] = __popcll(bc) | (__popcll(bn) << 16);
+    __syncthreads();
+    int pre_c = 0, pre_n = 0;
+    for (int w = 0; w < wid; ++w) { pre_c += s_wc[w] & 0xffff; pre_n += s_wc[w] >> 16; }
+    const int run_c = s_run[0], run_n = s_run[1];
+    if (valid) {
+      if (core) core_idx[base + run_c + pre_c + pvn3d_mbcnt(bc)] = i;
+      else nc_idx[base + run_n + pre_n + pvn3d_mbcnt(bn)] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tc = 0, tn = 0;
+      for (int w = 0; w < 16; ++w) { tc += s_wc[w] & 0xffff; tn += s_wc[w] >> 16; }
+      s_run[0] = run_c + tc; s_run[1] = run_n + tn;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) n_core[seg] = s_run[0];
+}
+
+// ROWS_NC = false: rows = every point, columns = the non-core list; writes counts[i].
+// ROWS_NC = true : rows = the non-core list, columns = the core list; adds to counts[i].
+// grid (n_seg, ceil(max_cnt/256)), block 256
+template <bool ROWS_NC>
+__global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
+    const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
+    float d2_max, int* __restrict__ counts) {
+  __shared__ float4 s_pts[MS_CHUNK];
+  // grid (n_seg, tiles): the segment is the FAST grid dimension.  Most tiles of the non-core
+  // launch are empty (few non-core rows); with the tile as the fast dimension the surviving
+  // workgroups (tile 0/1 of every segment, linear ids 12*seg + {0,1}) all land on the same four
+  // of the eight XCDs and the launch took 5x longer than its work.
+  const int seg = blockIdx.x;
+  const int n = seg_cnt[seg];
+  const int ncore = n_core[seg], nnc = n - ncore;
+  const int n_rows = ROWS_NC ? nnc : n;
+  const int n_cols = ROWS_NC ? ncore : nnc;
+  const int tile0 = blockIdx.y * MS_THREADS;
+  if (tile0 >= n_rows) return;
+  const int base = seg_off[seg];
+  const int tid = threadIdx.x;
+  const int r = tile0 + tid;
+  int i = -1;
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < n_rows) {
+    i = ROWS_NC ? nc_idx[base + r] : r;
+    c = pts[base + i];
+  }
+  const int* cols = (ROWS_NC ? core_idx : nc_idx) + base;
+  int count = 0;
+  for (int j0 = 0; j0 < n_cols; j0 += MS_CHUNK) {
+    const int cnt = min(MS_CHUNK, n_cols - j0);
+    __syncthreads();
+    for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + cols[j0 + q]];
+    __syncthreads();
+    for (int q = 0; q < cnt; ++q) {
+      const float4 a = s_pts[q];
+      const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      count += (d2 <= d2_max) ? 1 : 0;
+    }
+  }
+  if (i < 0) return;
+  if (ROWS_NC) counts[base + i] += count;   // one thread per row, after the first launch: no race
+  else counts[base + i] = count;
+}
+
+// counts[i] += n_core for the core rows (every core point is within bw of every core point).
+// grid (ceil(max_cnt/256), n_seg), block 256
+__global__ __launch_bounds__(MS_THREADS) void ms_count_addcore_kernel(
+    const int* __restrict__ seg_off, const int* __restrict__ core_idx, const int* __restrict__ n_core,
+    int* __restrict__ counts) {
+  const int seg = blockIdx.y;
+  const int ncore = n_core[seg];
+  const int r = blockIdx.x * MS_THREADS + threadIdx.x;
+  if (r >= ncore) return;
+  const int base = seg_off[seg];
+  counts[base + core_idx[base + r]] += ncore;
+}
+
+// arg-max of the counts with the reference's first-maximum rule.  grid as above.
+__global__ __launch_bounds__(MS_THREADS) void ms_argmax_kernel(
+    const int* __restrict__ seg_off, const int* __restrict__ seg_cnt, const int* __restrict__ counts,
+    unsigned long long* __restrict__ best) {
+  __shared__ unsigned long long s_red[MS_THREADS / 64];
+  const int seg = blockIdx.y;
+  const int n = seg_cnt[seg];
+  const int tile0 = blockIdx.x * MS_THREADS;
+  if (tile0 >= n) return;
+  const int base = seg_off[seg];
+  const int tid = threadIdx.x;
+  const int i = tile0 + tid;
+  unsigned long long key = 0ULL;
+  if (i < n) key = ((unsigned long long)(unsigned)counts[base + i] << 32) | (unsigned long long)(~(unsigned)i);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)key, o, 64);
+    const unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    key = other > key ? other : key;
+  }
+  if ((tid & 63) == 0) s_red[tid >> 6] = key;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long m = s_red[0];
+    for (int w = 1; w < MS_THREADS / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
+    atomicMax(best + seg, m);
+  }
+}
+
 // labels = |A_j - A_maxidx| < bw ; ctr = C[maxidx] back in the camera frame.
 // grid: (tiles, n_seg), block 256.  Tile 0 also writes ctr / iters.
 __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
@@ -828,8 +1002,24 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     (void)hipEventDestroy(ev[1]);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(ms_count_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                     d2_max, S.best);
+  static const bool full_count = [] { const char* e = getenv("PVN3D_MS_FULL_COUNT"); return e && atoi(e) != 0; }();
+  if (full_count) {      // the plain n^2 scan (A/B and fallback)
+    hipLaunchKernelGGL(ms_count_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                       d2_max, S.best);
+  } else {
+    const float r_core = 0.499f * bandwidth;
+    hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
+                       S.core_idx, S.nc_idx, S.n_core);
+    const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
+    hipLaunchKernelGGL(ms_count_pruned_kernel<false>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+    hipLaunchKernelGGL(ms_count_pruned_kernel<true>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+    hipLaunchKernelGGL(ms_count_addcore_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, S.core_idx,
+                       S.n_core, S.counts);
+    hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts,
+                       S.best);
+  }
   PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(ms_final_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
                      S.cbuf[0], S.cbuf[1], S.best, S.iters, mfma ? S.origin : nullptr, d2_max,
