@@ -42,7 +42,8 @@
 //   * a wave owns row tiles mt = wave, wave+NW, ... (<= NT) x 2 column tiles; accumulators
 //     start from the bias; after a layer relu(acc) goes back to H
 //     (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-// Epilogue SA: max over the nsample columns of each centre (DPP), store point-major.
+// Epilogue SA: max over the nsample columns of each centre (through a wave-private LDS patch),
+// store point-major.
 // Epilogue FP: store point-major (intermediate levels) or (B, M, n) (the module's API layout).
 #include <cstdlib>
 #include <type_traits>
@@ -126,34 +127,6 @@ __device__ __forceinline__ void xcd_frame_map(int& bi, int& bx) {
 }
 
 // ---- small helpers ------------------------------------------------------------------------
-// max over groups of ns (power of two <= 32) consecutive lanes with DPP row operations fused
-// into v_max_f32 (a ds_bpermute butterfly costs ~5x the MFMA time of a narrow chain).
-// ns <= 16: every lane of a group ends with the group max; ns == 32: lanes 16..31 / 48..63 do.
-// The values pooled here are post-ReLU (>= +0, never NaN), so float max == signed-integer max
-// of the bit patterns: v_max_i32 needs no NaN canonicalisation and fuses with the DPP move.
-// NS is a template parameter: with a run-time nsample every step of every call is a uniform
-// branch, and the ~640 branches of a two-tile epilogue cost more than a quarter of the whole
-// workgroup's time (measured with the SM_PROBE stamps).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_imax(int v) {
-  const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
-  return max(v, o);
-}
-__device__ __forceinline__ float seg_max_n(float vf, int ns) {    // ns <= 32
-  int v = __float_as_int(vf);
-  if (ns >= 2) v = dpp_imax<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
-  if (ns >= 4) v = dpp_imax<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
-  if (ns >= 8) v = dpp_imax<0x141, 0xF>(v);    // row_half_mirror
-  if (ns >= 16) v = dpp_imax<0x140, 0xF>(v);   // row_mirror
-  if (ns >= 32) v = dpp_imax<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  return __int_as_float(v);
-}
-// NS > 0: compile-time nsample (the shapes PVN3D uses); NS == 0: any power of two, run time
-template <int NS>
-__device__ __forceinline__ float seg_max(float vf, int ns_rt) {
-  return seg_max_n(vf, NS > 0 ? (NS > 32 ? 32 : NS) : (ns_rt > 32 ? 32 : ns_rt));
-}
-
 // accumulator tile <- bias of its rows (C/D map: reg r holds row (r&3) + 8*(r>>2) + 4*half)
 __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb /*tile's 32 biases, LDS*/,
                                          int half) {
@@ -793,12 +766,11 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
   int bi, bx;
   xcd_frame_map(bi, bx);
   const int col0 = bx * 64 + wave * 32;
-  stage_bias(d, s_bias, tid, 128);
-  __syncthreads();                         // the only barrier of this kernel
-  if (col0 >= cols_total) return;          // wave-uniform
+  SM_STAMP(14);
   const int half = lane >> 5, col = lane & 31;
 
-  // loader: lane fills column `col`, rows half + 2*i (i < 16) of every 32-row chunk
+  // loader: lane fills column `col`, rows half + 2*i (i < 16) of every 32-row chunk.  The index /
+  // weight loads are issued BEFORE the bias staging barrier so that the two latencies overlap.
   const int gcol = col0 + col;
   const bool cvalid = gcol < cols_total;
   int id0 = 0, id1 = 0, id2 = 0;
@@ -815,6 +787,10 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
     id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
     w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
   }
+  stage_bias(d, s_bias, tid, 128);
+  __syncthreads();                         // the only barrier of this kernel
+  if (col0 >= cols_total) return;          // wave-uniform
+  SM_STAMP(0);
   // plain local copies: capturing the by-value kernel-argument structs by reference would pin
   // them in scratch memory and turn every field access of the loader into a scratch load
   const float* const sa_xyz = sa.xyz; const float* const sa_nxyz = sa.new_xyz;
@@ -872,6 +848,7 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
       for (int ch = 0; ch < n_chunks; ++ch) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) chunk[(half + 2 * i) * 32 + col] = stage[i];
+        if (ch == 0) SM_STAMP(6);
         if (ch + 1 < n_chunks) {   // gathers of the next chunk fly while this one is multiplied
 #pragma unroll
           for (int i = 0; i < 16; ++i) stage[i] = load_input((ch + 1) * SM_KC + half + 2 * i);
@@ -882,6 +859,7 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
     } else {
       mma(d.W[l], mt_total, 0, pairs_total, H);
     }
+    SM_STAMP(1 + 2 * l);
     if (l + 1 < d.n_layers) {
 #pragma unroll
       for (int t = 0; t < NTR; ++t) {
@@ -900,38 +878,70 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
   const int M = d.M[L];
   const int mt_total = (M + 31) >> 5;
   float* const out = od.out;
-  auto epi = [&](auto ns_tag) {
-    constexpr int NS = decltype(ns_tag)::value;
+  if (IS_SA) {
+    // Max-pool through the wave's own (now free) H | chunk patch, as in the row-split kernel: park
+    // relu(tile) as [32 rows][36], lane (row = lane&31, half) reads its 16 columns with four
+    // 16-byte loads, reduces segments of nsample in registers, and lanes 0..31 store 32
+    // consecutive channels of a centre (128 bytes).  The DPP butterfly + 4-byte scattered stores
+    // this replaces took 30 % of a level-0 wave's time (SM_PROBE).
+    constexpr int EP = 36;
+    float* sc = H;                               // (hrows + 32) * 32 >= 32 * 36 floats (hrows >= 4)
+    const int ns = sa.ns;                        // 1..32, power of two
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      if (t < mt_total) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+          sc[rr * EP + col] = fmaxf(acc[t][0][r], 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();         // same wave: LDS operations complete in order
+        int v[16];                               // post-ReLU floats compare like signed ints
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int4 q = *reinterpret_cast<const int4*>(sc + col * EP + 16 * half + 4 * i);
+          v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ns >= 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+        }
+        if (ns >= 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+        }
+        if (ns >= 8) { v[0] = max(v[0], v[1]); v[1] = max(v[2], v[3]); }
+        if (ns >= 16) v[0] = max(v[0], v[1]);
+        if (ns >= 32) v[0] = max(v[0], __shfl_xor(v[0], 32, 64));
+        const int nout = ns >= 16 ? 1 : 16 / ns;                 // centres per lane
+        const int jbase = ns >= 32 ? col0 / ns : (col0 + 16 * half) / ns;
+        const int row = t * 32 + col;
+        if (row < M && (ns < 32 || half == 0)) {
+          float* o = out + ((size_t)bi * sa.m + jbase) * od.ld + od.coff + row;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (q < nout && jbase + q < sa.m) o[(size_t)q * od.ld] = __int_as_float(v[q]);
+        }
+      }
+    }
+  } else {
 #pragma unroll
     for (int t = 0; t < NTR; ++t) {
       if (t < mt_total) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v = fmaxf(acc[t][0][r], 0.f);
-          if (IS_SA) {
-            const int ns = NS > 0 ? NS : sa.ns;
-            v = seg_max<NS>(v, ns);
-            const bool leader = ns >= 32 ? (col == 16) : ((col & (ns - 1)) == 0);
-            if (row < M && leader) {
-              const int j = (col0 + (ns >= 32 ? 0 : col)) / ns;
-              if (j < sa.m) out[((size_t)bi * sa.m + j) * od.ld + od.coff + row] = v;
-            }
-          } else if (row < M && gcol < cols_total) {
+          const float v = fmaxf(acc[t][0][r], 0.f);
+          if (row < M && gcol < cols_total) {
             if (od.point_major) out[((size_t)bi * fp.n + gcol) * od.ld + od.coff + row] = v;
             else out[((size_t)bi * M + row) * fp.n + gcol] = v;
           }
         }
       }
     }
-  };
-  if (IS_SA) {
-    if (sa.ns == 32) epi(std::integral_constant<int, 32>{});
-    else if (sa.ns == 16) epi(std::integral_constant<int, 16>{});
-    else epi(std::integral_constant<int, 0>{});      // 1..32, power of two
-  } else {
-    epi(std::integral_constant<int, 0>{});
   }
+  SM_STAMP(15);
 }
 
 template <bool IS_SA>

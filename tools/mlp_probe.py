@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase cycle stamps of the fused MLP kernels (needs a -DSM_PROBE build, PVN3D_HIP_LIB=...).
 Runs each SA/FP chain of Pointnet2MSG alone and prints, averaged over the first 64 workgroups,
-the cycles between stamps: 14 body start, 0 run start, 1/3/5 after layer l's MMA (+barrier),
+the cycles between stamps: 14 body start, 0 run start, 6 (column-sliced kernel) first input chunk in LDS, 1/3/5 after layer l's MMA (+barrier),
 2/4 after the activation store, 15 end."""
 import ctypes
 import os
@@ -32,7 +32,7 @@ def report(tag):
     buf = np.zeros((64, 16), dtype=np.uint64)
     lib.pvn3d_debug_mlp_probe_read(buf.ctypes.data)
     b = buf.astype(np.int64)
-    order = [14, 0, 1, 2, 3, 4, 5, 15]
+    order = [14, 0, 6, 1, 2, 3, 4, 5, 15]
     segs = []
     prev = None
     for k in order:
