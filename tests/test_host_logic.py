@@ -63,3 +63,63 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_fused_mlp_folding_and_weight_packing_on_cpu():
+    """BatchNorm folding + the packed weight layout of include/pvn3d_hip.h, checked without a GPU:
+    unpacking the packed tensors and applying relu(W'x + b') layer by layer must reproduce the
+    SharedMLP's eval forward; the xyz-first -> xyz-last column rotation must be the documented one."""
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+    from pvn3d_amd.lib.utils import pytorch_utils as pt_utils
+    torch.manual_seed(0)
+    mlp = pt_utils.SharedMLP([9, 33, 70], bn=True).eval()
+    g = torch.Generator().manual_seed(1)
+    for m in mlp.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.3)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    packed = _fused_mlp.pack_shared_mlp(mlp, n_xyz_first=3)
+    assert packed is not None and packed.dims == [9, 33, 70]
+
+    def unpack(Wp, M, K):                     # [K4][MT][64][2] -> (M, K)
+        K4, MT = Wp.shape[0], Wp.shape[1]
+        W = torch.zeros(MT * 32, K4 * 4)
+        for k4 in range(K4):
+            for mt in range(MT):
+                for lane in range(64):
+                    for j in range(2):
+                        W[mt * 32 + (lane & 31), 4 * k4 + 2 * j + (lane >> 5)] = Wp[k4, mt, lane, j]
+        assert torch.count_nonzero(W[M:]) == 0 and torch.count_nonzero(W[:, K:]) == 0   # zero padding
+        return W[:M, :K]
+    x = torch.randn(2, 9, 5, 4)               # channels: [xyz(3), features(6)] like the reference
+    with torch.no_grad():
+        want = mlp(x)
+    h = torch.cat([x[:, 3:], x[:, :3]], dim=1)                  # kernel order: features first, xyz last
+    for l, (Wp, bp) in enumerate(zip(packed.w, packed.b)):
+        W = unpack(Wp, packed.dims[l + 1], packed.dims[l])
+        assert tuple(bp.shape) == ((packed.dims[l + 1] + 31) // 32 * 32,)
+        h = torch.relu(torch.einsum("mk,bkps->bmps", W, h) + bp[:packed.dims[l + 1]].view(1, -1, 1, 1))
+    assert torch.allclose(h, want, rtol=1e-5, atol=1e-5)
+    # cache: same object until a parameter / running statistic changes, then re-packed
+    assert _fused_mlp.pack_shared_mlp(mlp, n_xyz_first=3) is packed
+    next(m for m in mlp.modules() if isinstance(m, torch.nn.BatchNorm2d)).running_mean.add_(1.0)
+    assert _fused_mlp.pack_shared_mlp(mlp, n_xyz_first=3) is not packed
+    # a training-mode BatchNorm cannot be folded
+    mlp.train()
+    assert _fused_mlp.pack_shared_mlp(mlp, n_xyz_first=3) is None
+
+
+def test_point_major_views_are_detected_without_copy():
+    """_ext._point_major: a (B, C, n) tensor that is a transposed view of a point-major buffer is
+    used in place (stride logic only, no kernel call)."""
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    buf = torch.arange(2 * 7 * 12, dtype=torch.float32).view(2, 7, 12)        # (B, n, ld)
+    view = buf[:, :, :10].transpose(1, 2)                                       # (B, C=10, n=7)
+    t, ld = _ext._point_major(view)
+    assert ld == 12 and t.data_ptr() == buf.data_ptr()
+    pc = torch.randn(3, 20, 9)
+    feats = pc[..., 3:].transpose(1, 2)                                         # Pointnet2MSG's input features
+    t, ld = _ext._point_major(feats)
+    assert ld == 9 and t.data_ptr() == pc.data_ptr() + 3 * 4
