@@ -169,6 +169,11 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
+# three_nn through a uniform grid over the known points (csrc/three_nn_grid.hip), same output
+NN_GRID = _os.environ.get("PVN3D_NN_GRID", "1") != "0"
+NN_GRID_MIN_M, NN_GRID_MAX_M, NN_GRID_MIN_N = 64, 2048, 512
+
+
 def three_nn(unknowns, knows):
     """unknowns (B,n,3), knows (B,m,3) -> [dist2 (B,n,3), idx (B,n,3)].  interpolate.cpp:14-40"""
     _chk(unknowns, "unknowns", torch.float32)
@@ -179,8 +184,16 @@ def three_nn(unknowns, knows):
     idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
     dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
     with torch.cuda.device(unknowns.device):
-        check(lib.pvn3d_three_nn(B, n, m, unknowns.data_ptr(), knows.data_ptr(), dist2.data_ptr(),
-                                 idx.data_ptr(), _stream(unknowns)), "three_nn")
+        if NN_GRID and NN_GRID_MIN_M <= m <= NN_GRID_MAX_M and n >= NN_GRID_MIN_N:
+            # identical output; ~30x fewer distance evaluations for evenly sampled surfaces
+            nbytes = int(lib.pvn3d_three_nn_grid_workspace_bytes(B, m))
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=unknowns.device)
+            check(lib.pvn3d_three_nn_grid(B, n, m, unknowns.data_ptr(), knows.data_ptr(), dist2.data_ptr(),
+                                          idx.data_ptr(), ws.data_ptr(), nbytes, _stream(unknowns)),
+                  "three_nn_grid")
+        else:
+            check(lib.pvn3d_three_nn(B, n, m, unknowns.data_ptr(), knows.data_ptr(), dist2.data_ptr(),
+                                     idx.data_ptr(), _stream(unknowns)), "three_nn")
     return [dist2, idx]
 
 

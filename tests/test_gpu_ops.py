@@ -444,3 +444,47 @@ def test_deterministic_backward_scatters(ext, orc, dev):
     # the float-atomic default agrees to fp32 summation error
     fa = ext.group_points_grad(T(gg, dev), T(idx, dev), n).cpu().numpy()
     assert np.allclose(fa, runs[0][0], rtol=1e-4, atol=1e-3 * np.abs(gg).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lattice_ties", "volumetric", "duplicates", "surface_fps", "far_queries"])
+def test_three_nn_grid_path_index_exact(ext, orc, dev, case):
+    """The uniform-grid three_nn against the C oracle and the brute-force kernel on inputs that
+    stress its exactness argument: exact distance ties (lattice), clouds where the 27 cells rarely
+    suffice (volumetric / far queries -> per-lane fallback), duplicate known points, and the real
+    use case (known = furthest-point sample of a depth surface)."""
+    g = np.random.default_rng(77)
+    if case == "lattice_ties":
+        ax = np.arange(12, dtype=np.float32) * 0.0125
+        kn = np.stack(np.meshgrid(ax, ax, ax[:8], indexing="ij"), -1).reshape(1, -1, 3)[:, g.permutation(12 * 12 * 8)]
+        unk = np.concatenate([kn[:, :800] + np.float32(0.00625), kn[:, 800:1152], kn[:, :100] + np.float32(0.0125)], 1)
+    elif case == "volumetric":
+        kn = (g.normal(size=(2, 1500, 3)) * 0.2).astype(np.float32)
+        unk = (g.normal(size=(2, 3000, 3)) * 0.25).astype(np.float32)
+    elif case == "duplicates":
+        base = (g.random((1, 300, 3)) * 0.3 - 0.15).astype(np.float32)
+        kn = np.concatenate([base, base, base[:, :150]], 1)[:, g.permutation(750)]
+        unk = np.concatenate([base[:, :200], (g.random((1, 1200, 3)) * 0.3 - 0.15).astype(np.float32)], 1)
+    elif case == "surface_fps":
+        from pvn3d_amd import synth
+        f = synth.synth_frame(frame=5, n_pts=12288, n_obj=3072)
+        unk = f["pcld"][None].astype(np.float32)
+        sel = ext.furthest_point_sampling(T(unk, dev), 2048).cpu().numpy()[0]
+        kn = np.ascontiguousarray(unk[:, sel])
+    else:
+        kn = (g.random((1, 512, 3)) * 0.1).astype(np.float32)
+        unk = np.concatenate([(g.random((1, 600, 3)) * 0.1).astype(np.float32),
+                              (g.random((1, 200, 3)) * 5.0 - 2.5).astype(np.float32)], 1)
+    kn = np.ascontiguousarray(kn, dtype=np.float32)
+    unk = np.ascontiguousarray(unk, dtype=np.float32)
+    assert ext.NN_GRID and ext.NN_GRID_MIN_M <= kn.shape[1] <= ext.NN_GRID_MAX_M and unk.shape[1] >= ext.NN_GRID_MIN_N
+    d2, idx = ext.three_nn(T(unk, dev), T(kn, dev))
+    od2, oidx = orc.three_nn(unk, kn)
+    assert np.array_equal(idx.cpu().numpy(), oidx), int((idx.cpu().numpy() != oidx).sum())
+    assert np.array_equal(d2.cpu().numpy(), od2)
+    try:
+        ext.NN_GRID = False
+        d2b, idxb = ext.three_nn(T(unk, dev), T(kn, dev))
+    finally:
+        ext.NN_GRID = True
+    assert torch.equal(idx, idxb) and torch.equal(d2, d2b)
