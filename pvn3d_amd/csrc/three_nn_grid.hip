@@ -5,7 +5,7 @@
 // known points with the smallest fp32 d = ((dx*dx + dy*dy) + dz*dz), ties to the smaller index
 // (the reference scans k in ascending order with strict '<').  The brute-force kernel evaluates
 // n*m pairs (25 M per frame at PVN3D's first feature-propagation level); here
-//   build  (one workgroup per cloud): bounding box -> cell size h = 2.2 * sqrt(A_max / m)
+//   build  (one workgroup per cloud): bounding box -> cell size h = 1.6 * sqrt(A_max / m)
 //          (A_max = largest bounding-box face: the known points are a furthest-point sample of a
 //          surface, whose spacing is ~sqrt(area / m)); 16^3 toroidal bucket table as in
 //          ball_query_grid.hip: LDS histogram -> scan -> scatter of (x, y, z, k);
@@ -17,6 +17,8 @@
 //          volumetric clouds) the lane falls back to scanning all m points.  Aliased far cells of
 //          the toroidal table only add candidates.
 // Scratch is passed in by the caller; m <= 2048 (the sorted cloud must fit in LDS).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -51,7 +53,7 @@ __device__ __forceinline__ int ng_bucket_c(int cx, int cy, int cz) {
 __device__ __forceinline__ int ng_cell(float x, float inv_h) { return (int)floorf(x * inv_h); }
 
 // one workgroup (1024 threads) per cloud
-__global__ __launch_bounds__(1024) void nn_grid_build_kernel(int m, const float* __restrict__ known,
+__global__ __launch_bounds__(1024) void nn_grid_build_kernel(int m, float h_scale, const float* __restrict__ known,
                                                              int* __restrict__ cell_start,
                                                              float4* __restrict__ sorted,
                                                              float* __restrict__ hinfo) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(1024) void nn_grid_build_kernel(int m, const float*
       e[a] = fmaxf(h - l, 0.f);
     }
     const float area = fmaxf(e[0] * e[1], fmaxf(e[1] * e[2], e[0] * e[2]));
-    float h = 2.2f * sqrtf(area / (float)m);
+    float h = h_scale * sqrtf(area / (float)m);
     const float emax = fmaxf(e[0], fmaxf(e[1], e[2]));
     if (!(h > 1e-12f)) h = fmaxf(emax * 0.125f, 1e-6f);     // collinear / coincident clouds
     if (!(h < 3.0e37f)) h = 1.0f;                           // non-finite coordinates: any cell size
@@ -260,8 +262,13 @@ extern "C" int pvn3d_three_nn_grid(int b, int n, int m, const float* unknown, co
   hipStream_t st = (hipStream_t)stream;
   NgWs ws;
   ng_layout(b, m, (char*)workspace, &ws);
-  hipLaunchKernelGGL(nn_grid_build_kernel, dim3(b), dim3(1024), 0, st, m, known, ws.cell_start, ws.sorted,
-                     ws.hinfo);
+  static const float h_scale = [] {       // cell size in units of the estimated point spacing (tuning)
+    const char* e = getenv("PVN3D_NN_H");
+    const float v = e ? (float)atof(e) : 0.f;
+    return v > 0.1f ? v : 1.6f;     // measured 1.2 / 1.5 / 1.8 / 2.2 / 2.8 -> 0.63 / 0.38 / 0.39 / 0.43 / 0.49 ms per 64-frame step
+  }();
+  hipLaunchKernelGGL(nn_grid_build_kernel, dim3(b), dim3(1024), 0, st, m, h_scale, known, ws.cell_start,
+                     ws.sorted, ws.hinfo);
   PVN3D_LAUNCH_CHECK();
   const size_t lds = (size_t)m * sizeof(float4) + (NG_T + 1) * sizeof(int);
   if (n >= 4096) {
