@@ -345,3 +345,30 @@ def test_vote_loss_forward_backward_vs_reference_golden(dev, golden):
     assert full.shape == pred.shape
     with pytest.raises(RuntimeError):
         of_l1_loss(pred.detach().cpu(), targ.cpu(), labels.cpu())
+
+
+@pytest.mark.gpu
+def test_full_size_ycb_frames_vs_oracle(dev, orc):
+    """BASELINE config 3 shape: N = 12288, 21 classes, 5 instances per frame, centre-cluster filter
+    on, two frames batched -- against the oracle pipeline (numpy restatement of cal_frame_poses on
+    the C MeanShift / Kabsch) and the ground-truth poses."""
+    from oracle import posecal
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    from pvn3d_amd.lib.utils.basic_utils import Basic_Utils
+    bu = Basic_Utils()
+    frames = [synth.synth_frame_ycb(frame=20 + i, n_pts=12288, n_obj_total=6000, n_objs=5) for i in range(2)]
+    st = lambda k: torch.stack([T(f[k], dev) for f in frames], 0)
+    res = ev.cal_batch_poses(st("pcld"), st("mask"), st("ctr_of"), st("pred_kp_of"), True, 22, True)
+    poses = res["poses"].cpu().numpy()
+    present = res["present"].cpu().numpy()
+
+    def mesh(cid):
+        return np.concatenate([bu.get_kps(int(cid), ds_type="ycb"), bu.get_ctr(int(cid), ds_type="ycb").reshape(1, 3)], 0)
+    for fi, f in enumerate(frames):
+        ids, want = posecal.cal_frame_poses(f["pcld"], f["mask"], f["ctr_of"], f["pred_kp_of"], True, 22, True,
+                                            mesh, f["radius"])
+        assert np.array_equal(np.nonzero(present[fi])[0] + 1, np.asarray(ids))
+        for cid, w in zip(ids, want):
+            assert np.abs(poses[fi, cid - 1] - w).max() < TOL, (fi, cid)
+            R, t = f["poses"][int(cid)]
+            assert np.abs(poses[fi, cid - 1][:, :3] - R).max() < 3e-2 and np.abs(poses[fi, cid - 1][:, 3] - t).max() < 3e-3
