@@ -123,3 +123,32 @@ def test_point_major_views_are_detected_without_copy():
     feats = pc[..., 3:].transpose(1, 2)                                         # Pointnet2MSG's input features
     t, ld = _ext._point_major(feats)
     assert ld == 9 and t.data_ptr() == pc.data_ptr() + 3 * 4
+
+
+def test_torcheval_auc_bookkeeping_on_cpu():
+    """TorchEval.cal_auc / cal_lm_add (pvn3d_eval_utils.py:249-343): ADD(-S) selects ADD-S for the
+    symmetric classes, class 0 aggregates everything, AUC = the reference's VOCap (checked against
+    the pinned oracle)."""
+    from oracle import metrics
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    rng = np.random.default_rng(3)
+    te = ev.TorchEval(n_cls=22, verbose=False)
+    for cid in (2, 13, 20):                       # 13 and 20 are symmetric YCB classes
+        for _ in range(15):
+            a, s = float(abs(rng.normal()) * 0.05), float(abs(rng.normal()) * 0.02)
+            te.cls_add_dis[cid].append(a); te.cls_adds_dis[cid].append(s)
+            te.cls_add_dis[0].append(a); te.cls_adds_dis[0].append(s)
+    info = te.cal_auc()
+    assert abs(info["add_auc_lst"][2] - metrics.cal_auc(te.cls_add_dis[2])) < 1e-9
+    assert abs(info["adds_auc_lst"][13] - metrics.cal_auc(te.cls_adds_dis[13])) < 1e-9
+    assert te.cls_add_s_dis[13] is te.cls_adds_dis[13] and te.cls_add_s_dis[2] is te.cls_add_dis[2]
+    assert len(te.cls_add_s_dis[0]) == 45
+    want_all = metrics.cal_auc(te.cls_add_dis[2] + te.cls_adds_dis[13] + te.cls_adds_dis[20])
+    assert abs(info["add_s_auc_lst"][0] - want_all) < 1e-9
+    assert info["add_auc_lst"][5] == 0                       # empty class: VOCap of nothing
+    lm = ev.TorchEval(n_cls=22, verbose=False)
+    lm.cls_add_dis[10] = [0.004, 0.02, 0.3]; lm.cls_adds_dis[10] = [0.002, 0.01, 0.05]
+    out = lm.cal_lm_add(10, diameter_m=0.1)                  # eggbox: symmetric -> ADD(-S) = ADD-S
+    assert lm.cls_add_s_dis[10] is lm.cls_adds_dis[10]
+    assert abs(out["add"] - 100.0 / 3) < 1e-9 and abs(out["adds"] - 200.0 / 3) < 1e-9
+    assert abs(out["adds_auc_lst"][0] - metrics.cal_auc([0.002, 0.01, 0.05])) < 1e-9
