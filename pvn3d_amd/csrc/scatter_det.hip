@@ -13,7 +13,8 @@
 //   3. grad = (float)(q_sum * 2^-e), one rounding.
 // With e chosen this way the quantisation step is 2^-45 (or finer) relative to amax for up to
 // 65536 terms per target -- far below fp32 resolution, so the result is also MORE accurate than
-// a float accumulation in any order.
+// a float accumulation in any order.  Non-finite inputs (inf / NaN anywhere in grad_out or weight)
+// make the whole output NaN (NaN bit patterns also win the uint atomicMax, so they are seen).
 #include "common.h"
 
 namespace {
@@ -78,6 +79,11 @@ __global__ __launch_bounds__(256) void fixed_to_float_kernel(size_t count, int l
                                                              float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= count) return;
+  const float a = __uint_as_float(amax[0]) * __uint_as_float(amax[1]);
+  if (!(a < 3.0e38f)) {       // an inf / NaN gradient or weight: fixed point cannot represent it --
+    out[i] = __builtin_nanf("");   // poison the whole result rather than return finite garbage
+    return;
+  }
   const int e = scale_exp(amax, log2_terms);
   out[i] = (float)ldexp((double)(long long)q[i], -e);
 }
