@@ -14,7 +14,7 @@
 // With e chosen this way the quantisation step is 2^-45 (or finer) relative to amax for up to
 // 65536 terms per target -- far below fp32 resolution, so the result is also MORE accurate than
 // a float accumulation in any order.  Non-finite inputs (inf / NaN anywhere in grad_out or weight)
-// make the whole output NaN (NaN bit patterns also win the uint atomicMax, so they are seen).
+// make the whole output NaN.
 #include "common.h"
 
 namespace {
@@ -22,8 +22,10 @@ namespace {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t count,
                                                      unsigned* __restrict__ out) {
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(x[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const float v = fabsf(x[i]);
+    if (!(v <= m)) m = (v != v) ? __builtin_inff() : v;     // a NaN counts as +inf (fmaxf would drop it)
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like uints
