@@ -41,6 +41,7 @@ struct MsState {        // device-side layout inside the caller's workspace
   uint4* feat;          // bf16 split features of the points, 64 B per point (MFMA path)
   float4* origin;       // [n_seg] frame origin of each fit (MFMA path)
   unsigned* maxshift;   // [n_seg][max_iter+2]  float bits (>= 0 so uint order == float order)
+  unsigned* cmmax;      // [n_seg][max_iter+2]  max |c'|^2 over the seeds after iteration t (float bits)
   int* iters;           // [n_seg]
   unsigned long long* best;  // [n_seg]  (count << 32) | ~index
   int* active;          // [2]
@@ -62,6 +63,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_org = take(sizeof(float4) * (size_t)n_seg);
   const size_t o_small = off;  // everything from here is zero-filled per call
   const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
+  const size_t o_cm = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_it = take(sizeof(int) * (size_t)n_seg);
   const size_t o_best = take(sizeof(unsigned long long) * (size_t)n_seg);
   const size_t o_act = take(sizeof(int) * 2);
@@ -76,6 +78,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->feat = (uint4*)(base + o_ft);
     st->origin = (float4*)(base + o_org);
     st->maxshift = (unsigned*)(base + o_ms);
+    st->cmmax = (unsigned*)(base + o_cm);
     st->iters = (int*)(base + o_it);
     st->best = (unsigned long long*)(base + o_best);
     st->active = (int*)(base + o_act);
@@ -174,10 +177,10 @@ template <int S>
 __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
-    unsigned* __restrict__ maxshift, int* __restrict__ iters, int t, int max_iter,
-    float thresh, float kappa, float inv_kappa) {
+    unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
+    int max_iter, float thresh, float kappa, float inv_kappa) {
   __shared__ float4 s_pts[MS_CHUNK];
-  __shared__ float s_red[MS_THREADS / 64];
+  __shared__ float s_red[2][MS_THREADS / 64];
   const int seg = blockIdx.y;
   const int n = seg_cnt[seg];
   const int tile0 = blockIdx.x * (MS_THREADS * S);
@@ -190,6 +193,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   const int base = seg_off[seg];
   const float4 org = pts[base];  // frame origin: the fit's first point
   const int tid = threadIdx.x;
+  // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
+  // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
+  // |c'|^2 <= 64 (no overflow: the largest weight is exp2(|c'|^2)) the per-pair subtraction of
+  // |c'|^2 is dropped -- one VALU instruction of nine.  The bound comes from the previous
+  // iteration's output; iteration 1 always takes the exact form.
+  unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
+  const bool fast = t > 1 && __uint_as_float(cmx[t - 1]) <= 64.f;
 
   float cx[S], cy[S], cz[S], c2x[S], c2y[S], c2z[S], cm[S], sw[S], sx[S], sy[S], sz[S];
 #pragma unroll
@@ -227,24 +237,40 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     }
     __syncthreads();
     const int cnt4 = (cnt + 3) & ~3;
+    if (fast) {
 #pragma unroll 4
-    for (int q = 0; q < cnt4; ++q) {
-      const float4 a = s_pts[q];
+      for (int q = 0; q < cnt4; ++q) {
+        const float4 a = s_pts[q];
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : one subtract + three FMAs instead of
-        // three subtracts + mul + two FMAs (the frame is centred, so magnitudes stay ~1)
-        const float e = fmaf(c2z[s], a.z, fmaf(c2y[s], a.y, fmaf(c2x[s], a.x, a.w - cm[s])));
-        const float w = __builtin_amdgcn_exp2f(e);
-        sw[s] += w;
-        sx[s] = fmaf(w, a.x, sx[s]);
-        sy[s] = fmaf(w, a.y, sy[s]);
-        sz[s] = fmaf(w, a.z, sz[s]);
+        for (int s = 0; s < S; ++s) {
+          const float e = fmaf(c2z[s], a.z, fmaf(c2y[s], a.y, fmaf(c2x[s], a.x, a.w)));
+          const float w = __builtin_amdgcn_exp2f(e);
+          sw[s] += w;
+          sx[s] = fmaf(w, a.x, sx[s]);
+          sy[s] = fmaf(w, a.y, sy[s]);
+          sz[s] = fmaf(w, a.z, sz[s]);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int q = 0; q < cnt4; ++q) {
+        const float4 a = s_pts[q];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : one subtract + three FMAs instead of
+          // three subtracts + mul + two FMAs (the frame is centred, so magnitudes stay ~1)
+          const float e = fmaf(c2z[s], a.z, fmaf(c2y[s], a.y, fmaf(c2x[s], a.x, a.w - cm[s])));
+          const float w = __builtin_amdgcn_exp2f(e);
+          sw[s] += w;
+          sx[s] = fmaf(w, a.x, sx[s]);
+          sy[s] = fmaf(w, a.y, sy[s]);
+          sz[s] = fmaf(w, a.z, sz[s]);
+        }
       }
     }
   }
 
-  float mshift = 0.f;
+  float mshift = 0.f, mcm = 0.f;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int i = tile0 + s * MS_THREADS + tid;
@@ -254,17 +280,23 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
       const float ex = nx - cx[s], ey = ny - cy[s], ez = nz - cz[s];
       const float sh = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_kappa;
       mshift = fmaxf(mshift, sh);
+      const float ncm = fmaf(nz, nz, fmaf(ny, ny, nx * nx));
+      mcm = (ncm <= mcm) ? mcm : ((ncm != ncm) ? __builtin_inff() : ncm);   // NaN counts as +inf
       cout[base + i] = make_float4(nx, ny, nz, 0.f);
     }
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
-  if ((tid & 63) == 0) s_red[tid >> 6] = mshift;
+  for (int o = 32; o >= 1; o >>= 1) {
+    mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
+    mcm = fmaxf(mcm, __shfl_xor(mcm, o, 64));
+  }
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = mshift; s_red[1][tid >> 6] = mcm; }
   __syncthreads();
   if (tid == 0) {
-    float m = s_red[0];
-    for (int i = 1; i < MS_THREADS / 64; ++i) m = fmaxf(m, s_red[i]);
+    float m = s_red[0][0], c = s_red[1][0];
+    for (int i = 1; i < MS_THREADS / 64; ++i) { m = fmaxf(m, s_red[0][i]); c = fmaxf(c, s_red[1][i]); }
     atomicMax(ms + t, __float_as_uint(m));
+    atomicMax(cmx + t, __float_as_uint(c));
     atomicMax(iters + seg, t);
   }
 }
@@ -970,15 +1002,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
                          seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, inv_kappa);
     else if (S_sel == 4)
       hipLaunchKernelGGL(ms_iter_kernel<4>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, kappa,
+                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
                          inv_kappa);
     else if (S_sel == 2)
       hipLaunchKernelGGL(ms_iter_kernel<2>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, kappa,
+                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
                          inv_kappa);
     else
       hipLaunchKernelGGL(ms_iter_kernel<1>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, kappa,
+                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
                          inv_kappa);
     if ((rc = (int)hipGetLastError()) != 0) break;
     if (poll && (t % poll_every) == 0 && t <= max_iter) {
