@@ -1,8 +1,9 @@
 """The vote loss of the reference's pvn3d/lib/loss.py: ``of_l1_loss`` (:45-73) and ``OFLoss``
 (:76-90) with the same signatures.  Forward and backward are one HIP launch each
 (csrc/vote_loss.hip) instead of ~8 elementwise torch kernels over (bs, K, N, 3) temporaries;
-summation order is fixed, so the loss is bit-reproducible.  FocalLoss (the segmentation loss) is
-not on the hot path and is not restated."""
+summation order is fixed, so the loss is bit-reproducible.  ``FocalLoss`` (:13-42, the
+segmentation loss, not on the hot path) is provided in plain torch so that
+``from lib.loss import OFLoss, FocalLoss`` keeps working when this module is substituted."""
 import torch
 from torch.nn.modules.loss import _Loss
 
@@ -60,6 +61,36 @@ def of_l1_loss(pred_ofsts, kp_targ_ofst, labels, sigma=1.0, normalize=True, redu
         w = w_labels.view(bs, 1, n_pts, 1)
         return w * torch.abs(pred_ofsts - targ.permute(0, 2, 1, 3))
     return _OfL1Loss.apply(pred_ofsts, targ, w_labels)
+
+
+class FocalLoss(_Loss):
+    """Focal loss -(1 - p_t)^gamma * alpha_t * log p_t over class logits (reference :13-42):
+    `input` (N, C) or (N, C, ...) logits, `target` integer class ids; `alpha` a float (binary:
+    [alpha, 1 - alpha]) or a per-class list; p_t is treated as a constant in the backward pass,
+    as the reference does."""
+
+    def __init__(self, gamma=0, alpha=None, size_average=True):
+        super(FocalLoss, self).__init__()
+        self.gamma = gamma
+        if isinstance(alpha, (float, int)):
+            alpha = torch.tensor([alpha, 1 - alpha], dtype=torch.float32)
+        elif isinstance(alpha, list):
+            alpha = torch.tensor(alpha, dtype=torch.float32)
+        self.alpha = alpha
+        self.size_average = size_average
+
+    def forward(self, input, target):
+        if input.dim() > 2:
+            input = input.reshape(input.size(0), input.size(1), -1).transpose(1, 2)
+            input = input.reshape(-1, input.size(2))
+        target = target.reshape(-1, 1)
+        logpt = torch.log_softmax(input, dim=1).gather(1, target).reshape(-1)
+        pt = logpt.detach().exp()
+        if self.alpha is not None:
+            self.alpha = self.alpha.to(device=input.device, dtype=input.dtype)
+            logpt = logpt * self.alpha.gather(0, target.reshape(-1))
+        loss = -1 * (1 - pt) ** self.gamma * logpt
+        return loss.mean() if self.size_average else loss.sum()
 
 
 class OFLoss(_Loss):

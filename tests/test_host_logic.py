@@ -152,3 +152,22 @@ def test_torcheval_auc_bookkeeping_on_cpu():
     assert lm.cls_add_s_dis[10] is lm.cls_adds_dis[10]
     assert abs(out["add"] - 100.0 / 3) < 1e-9 and abs(out["adds"] - 200.0 / 3) < 1e-9
     assert abs(out["adds_auc_lst"][0] - metrics.cal_auc([0.002, 0.01, 0.05])) < 1e-9
+
+
+def test_focal_loss_matches_reference_formula():
+    """lib.loss.FocalLoss (plain torch, not on the hot path) against the closed form the reference
+    evaluates (pvn3d/lib/loss.py:23-42), incl. the (N, C, H, W) reshape and per-class alpha."""
+    from pvn3d_amd.lib.loss import FocalLoss
+    torch.manual_seed(5)
+    logits = torch.randn(2, 4, 3, 5, requires_grad=True)
+    target = torch.randint(0, 4, (2, 3, 5))
+    alpha = [0.1, 0.2, 0.3, 0.4]
+    out = FocalLoss(gamma=2, alpha=alpha)(logits, target)
+    flat = logits.permute(0, 2, 3, 1).reshape(-1, 4)
+    lp = torch.log_softmax(flat, 1).gather(1, target.reshape(-1, 1)).reshape(-1)
+    want = (-(1 - lp.exp()) ** 2 * lp * torch.tensor(alpha)[target.reshape(-1)]).mean()
+    assert torch.allclose(out, want, rtol=1e-6, atol=1e-7)
+    out.backward()
+    assert logits.grad is not None and torch.isfinite(logits.grad).all()
+    s = FocalLoss(gamma=0, size_average=False)(flat.detach(), target.reshape(-1))
+    assert torch.allclose(s, torch.nn.functional.cross_entropy(flat.detach(), target.reshape(-1), reduction="sum"))

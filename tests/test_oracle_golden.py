@@ -147,3 +147,15 @@ def test_vote_loss_oracle_vs_reference(golden):
         assert np.allclose(out, z["loss%d" % i], rtol=2e-6, atol=1e-7)
         g = oloss.of_l1_loss_grad(pred, targ, labels, z["gout%d" % i])
         assert np.allclose(g, z["gpred%d" % i], rtol=2e-6, atol=1e-9)
+
+
+def test_focal_loss_vs_reference(golden):
+    """pvn3d_amd.lib.loss.FocalLoss (plain torch) against outputs of the reference's FocalLoss."""
+    from pvn3d_amd.lib.loss import FocalLoss
+    z = golden("loss_ref.npz")
+    for i in range(int(z["n_focal"])):
+        alpha = z["f_alpha%d" % i]
+        alpha = None if alpha.size == 0 else [float(a) for a in alpha]
+        fl = FocalLoss(gamma=float(z["f_gamma%d" % i]), alpha=alpha, size_average=bool(z["f_avg%d" % i]))
+        out = fl(torch.from_numpy(z["f_logits%d" % i]), torch.from_numpy(z["f_target%d" % i]))
+        assert abs(out.item() - float(z["f_out%d" % i])) < 1e-5 * max(1.0, abs(float(z["f_out%d" % i]))), i
