@@ -120,10 +120,7 @@ def test_metric_oracle_vs_reference(golden):
 
 def test_host_auc_equals_reference(golden):
     """Basic_Utils.cal_auc / VOCap of the package (pure numpy, no GPU needed) vs the reference."""
-    import importlib.util
     import os
-    import sys
-    import types
     # basic_utils imports the ctypes library at module level; load only the pure functions
     src = open(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "lib", "utils", "basic_utils.py")).read()
     start = src.index("def VOCap(rec, prec):")

@@ -4,7 +4,6 @@ usage: python tools/bench_ops.py [--frames 64] [--ops group,interp,bq,nn,fps,ms]
 import argparse
 import os
 import sys
-import time
 
 import numpy as np
 import torch

@@ -60,5 +60,4 @@ with torch.no_grad():
     net(pc)
     torch.cuda.synchronize()
     _ext.sa_mlp_maxpool, _ext.fp_interp_mlp = sa, fp
-    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
     net(pc)
