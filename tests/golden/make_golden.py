@@ -11,6 +11,10 @@ so that tests never read /root/reference.  What is pinned by real reference outp
                       cv2 / plyfile / ip_basic stubbed).
   frames_ref.npz    : cal_frame_poses_lm / cal_frame_poses restated (oracle/posecal.py) but
                       DRIVEN BY the reference's MeanShiftTorch.fit and best_fit_transform.
+  metrics_ref.npz   : Basic_Utils.cal_add_cuda / cal_adds_cuda / cal_auc (+ VOCap) of
+                      pvn3d/lib/utils/basic_utils.py on CPU tensors (unbound calls).
+  loss_ref.npz      : of_l1_loss value and autograd gradient, FocalLoss value, of pvn3d/lib/loss.py
+                      (file-level load, lib.utils.meanshift_pytorch stubbed with the loaded module).
 What cannot be pinned by the reference (CUDA-only native ops, no nvcc / NVIDIA GPU here):
   native_oracle.npz : outputs of the C oracle for the pointnet2 ops on seeded inputs --
                       regression vectors, labelled "oracle-generated".
