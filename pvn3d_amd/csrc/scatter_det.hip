@@ -12,8 +12,9 @@
 //      (integer addition is associative: any order gives the same bits);
 //   3. grad = (float)(q_sum * 2^-e), one rounding.
 // With e chosen this way the quantisation step is 2^-45 (or finer) relative to amax for up to
-// 65536 terms per target -- far below fp32 resolution, so the result is also MORE accurate than
-// a float accumulation in any order.  Non-finite inputs (inf / NaN anywhere in grad_out or weight)
+// 65536 terms per target: the absolute error of a sum is <= #terms * 2^-46 * amax, far below the
+// fp32 rounding of any sum containing a term of that size (a target fed only by terms more than
+// 2^20 times smaller than amax keeps this absolute -- not relative -- accuracy).  Non-finite inputs (inf / NaN anywhere in grad_out or weight)
 // make the whole output NaN.
 #include "common.h"
 
