@@ -15,9 +15,14 @@ Contents
 ``metrics``     numpy restatement of ADD / ADD-S / VOCap / cal_auc (basic_utils.py:32-44, 597-635).
 ``loss``        numpy restatement of of_l1_loss and its gradient (lib/loss.py:45-73).
 
-Pinning: every restatement is checked against outputs of the reference's own Python
-(tests/golden/*_ref.npz, generated by tests/golden/make_golden.py in the build container) except
-the native SA/FP ops, which the reference ships as CUDA-only code without test vectors -- those
-are "parity unpinned"  and are cross-checked against independent
-brute-force formulations instead.
+``ref``         ctypes binding of ``oracle/_ref/libpvn3d_ref_{nofma,fma}.so``: the REFERENCE'S OWN
+                kernels (pvn3d/_ext-src/src/*_gpu.cu) compiled for the CPU from where they lie under
+                /root/reference by ``ref_shim/build_ref.py`` (CUDA execution model supplied by
+                ``ref_shim/``: threads as fibers, real block barriers).  Built in the development
+                container, shipped to the GPU box as prebuilt files, never committed.
+
+Pinning: every restatement is checked against outputs of the reference itself --
+the Python pieces against tests/golden/*_ref.npz (tests/golden/make_golden.py), the nine native ops
+bit-for-bit against ``ref`` (tests/test_oracle_vs_ref.py) and against the fixture the reference's
+kernels produced at the BASELINE shapes (tests/golden/native_ref.npz, make_golden_native.py).
 """

@@ -488,3 +488,34 @@ def test_three_nn_grid_path_index_exact(ext, orc, dev, case):
     finally:
         ext.NN_GRID = True
     assert torch.equal(idx, idxb) and torch.equal(d2, d2b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Against the REFERENCE'S OWN kernels: tests/golden/native_ref.npz holds what pvn3d/_ext-src/src/*_gpu.cu
+# (compiled for the CPU, oracle/ref_shim/build_ref.py) returned on two 12 288-point clouds for every
+# set-abstraction / feature-propagation level of the backbone (tests/golden/make_golden_native.py).
+REF_NPOINT = [2048, 1024, 512, 128]
+REF_RADII = [(0.0175, 0.025), (0.025, 0.05), (0.05, 0.1), (0.1, 0.2)]
+
+
+@pytest.mark.parametrize("c", [0, 1])
+def test_all_levels_equal_reference_kernels_fixture(ext, golden, dev, c):
+    z = golden("native_ref.npz")
+    cur = T(z["c%d_xyz" % c][None], dev)
+    levels = [cur]
+    for l in range(4):
+        fps = ext.furthest_point_sampling(cur, REF_NPOINT[l])
+        assert np.array_equal(fps[0].cpu().numpy(), z["c%d_fps%d" % (c, l)].astype(np.int32)), "fps level %d" % l
+        new = torch.gather(cur, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        for s, ns in enumerate((16, 32)):
+            bq = ext.ball_query(new, cur, REF_RADII[l][s], ns)
+            assert np.array_equal(bq[0].cpu().numpy(), z["c%d_bq%d_%d" % (c, l, s)].astype(np.int32)), (l, s)
+        i16, i32 = ext.ball_query_pair(new, cur, REF_RADII[l][0], 16, REF_RADII[l][1], 32)
+        assert np.array_equal(i16[0].cpu().numpy(), z["c%d_bq%d_0" % (c, l)].astype(np.int32))
+        assert np.array_equal(i32[0].cpu().numpy(), z["c%d_bq%d_1" % (c, l)].astype(np.int32))
+        cur = new
+        levels.append(cur)
+    for l in range(4):
+        d2, idx = ext.three_nn(levels[l], levels[l + 1])
+        assert np.array_equal(idx[0].cpu().numpy(), z["c%d_nn%d_idx" % (c, l)].astype(np.int32)), "three_nn idx %d" % l
+        assert np.array_equal(d2[0].cpu().numpy(), z["c%d_nn%d_d2" % (c, l)]), "three_nn dist2 %d" % l
