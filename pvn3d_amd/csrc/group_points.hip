@@ -12,18 +12,7 @@
 // The reference's thread writes with stride nsample and loops k serially.
 #include "common.h"
 
-#include <cstdlib>
-
 namespace {
-
-constexpr int GP_LDS_MAX_N = 4096;  // rows up to 16 KiB are staged through LDS
-
-// A/B switch for kernel tuning (tools/bench_ops.py): PVN3D_GROUP_DIRECT=1 forces the
-// direct-gather kernel.  Read per call, no cached state (the C ABI stays re-entrant).
-inline bool gp_force_direct() {
-  const char* e = getenv("PVN3D_GROUP_DIRECT");
-  return e && e[0] == '1';
-}
 
 // grid: (ceil(P/1024), n_chunks, b); P = npoints*nsample, P % 4 == 0
 __global__ __launch_bounds__(256) void group_points_vec4_kernel(
@@ -53,69 +42,6 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(
   for (; l < c1; ++l) {
     *reinterpret_cast<float4*>(o) = make_float4(row[id.x], row[id.y], row[id.z], row[id.w]);
     row += n;
-    o += P;
-  }
-}
-
-// LDS-staged variant for rows that fit the LDS (n <= GP_LDS_MAX_N): the scattered 4-byte
-// global gathers of the kernel above keep the texture-address path busy (~64 tag lookups per
-// wave instruction); here a workgroup copies channel row l (n floats, coalesced 16-byte loads)
-// into LDS, double-buffered against the gather of row l-1, and the random reads become
-// ds_read_b32.  A thread owns 2 x 4 consecutive positions (1024 apart) so every store
-// instruction of a wave still covers one contiguous KiB.
-// grid: (ceil(P/2048), n_chunks, b); dynamic LDS = 2*n floats; n % 4 == 0, P % 4 == 0.
-__global__ __launch_bounds__(256) void group_points_lds_kernel(
-    int c, int n, int P, int cch, const float* __restrict__ points,
-    const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride) {
-  extern __shared__ float s_row[];  // [2][n]
-  const int tid = threadIdx.x;
-  const int bi = blockIdx.z;
-  const int c0 = blockIdx.y * cch;
-  const int c1 = min(c0 + cch, c);
-  const int tile0 = blockIdx.x * 2048;
-  const int pa = tile0 + tid * 4, pb = tile0 + 1024 + tid * 4;
-  const bool va = pa < P, vb = pb < P;
-  int4 ia = make_int4(0, 0, 0, 0), ib = make_int4(0, 0, 0, 0);
-  if (va) ia = *reinterpret_cast<const int4*>(idx + (size_t)bi * P + pa);
-  if (vb) ib = *reinterpret_cast<const int4*>(idx + (size_t)bi * P + pb);
-  const int n4 = n >> 2;
-  const float4* row = reinterpret_cast<const float4*>(points + ((size_t)bi * c + c0) * n);
-  float* o = out + (size_t)bi * out_batch_stride + (size_t)c0 * P;
-  float4* s4 = reinterpret_cast<float4*>(s_row);
-  for (int q = tid; q < n4; q += 256) s4[q] = row[q];
-  __syncthreads();
-  int cur = 0;
-  for (int l = c0; l < c1; ++l) {
-    const float* sr = s_row + cur * n;
-    const bool more = l + 1 < c1;
-    // issue the next row's loads before the LDS gathers so HBM/L2 latency hides behind them
-    float4 pre[3];
-    const float4* nrow = row + (size_t)n4;
-    int npre = 0;
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int q = tid + u * 256;
-        if (q < n4) pre[u] = nrow[q];
-      }
-      npre = 3;
-    }
-    if (va)
-      *reinterpret_cast<float4*>(o + pa) = make_float4(sr[ia.x], sr[ia.y], sr[ia.z], sr[ia.w]);
-    if (vb)
-      *reinterpret_cast<float4*>(o + pb) = make_float4(sr[ib.x], sr[ib.y], sr[ib.z], sr[ib.w]);
-    if (more) {
-      float4* d4 = s4 + (size_t)(cur ^ 1) * n4;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int q = tid + u * 256;
-        if (q < n4) d4[q] = pre[u];
-      }
-      for (int q = tid + npre * 256; q < n4; q += 256) d4[q] = nrow[q];
-    }
-    __syncthreads();
-    cur ^= 1;
-    row = nrow;
     o += P;
   }
 }
@@ -243,18 +169,13 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
   if (b <= 0 || c <= 0 || P <= 0) return 0;
   const bool aligned = (P % 4 == 0) && (out_batch_stride % 4 == 0) &&
                        (((uintptr_t)out & 15) == 0) && (((uintptr_t)idx & 15) == 0);
-  const bool lds_ok = aligned && (n % 4 == 0) && n <= GP_LDS_MAX_N && P >= 2048 &&
-                      (((uintptr_t)points & 15) == 0) && !gp_force_direct();
-  const char* mode = getenv("PVN3D_GROUP_MODE");  // tuning A/B: "rows" | "tile" | unset
-  const bool rows_ok = aligned && (n % 4 == 0) && (size_t)n * 4 <= 128 * 1024 &&
-                       (((uintptr_t)points & 15) == 0) && !gp_force_direct() &&
-                       !(mode && mode[0] == 't');
+  const bool rows_ok = aligned && (n % 4 == 0) && (size_t)n * 4 <= 128 * 1024 && (((uintptr_t)points & 15) == 0);
   if (rows_ok) {
     // rows per workgroup: measured best (MI355X, 64 clouds) with ~16 KiB of LDS per workgroup,
-    // at most 4 rows: n=2048 -> 2 (4.2 TB/s), n=1024 -> 4 (4.6 TB/s), n=512 -> 4 (4.3 TB/s)
+    // at most 4 rows: n=2048 -> 2 (4.2 TB/s), n=1024 -> 4 (4.6 TB/s), n=512 -> 4 (4.3 TB/s);
+    // tile-owner and direct-gather variants measured 1.8-3.0 TB/s and were removed
     int cpb = 4;
     while (cpb > 1 && (size_t)cpb * n * 4 > 16 * 1024) cpb >>= 1;
-    if (const char* e = getenv("PVN3D_GROUP_CPB")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)v * n * 4 <= 128 * 1024) cpb = v; }
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb);
     // split the position range until there are a few thousand workgroups
@@ -264,34 +185,23 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     if (pchunk < 4096) pchunk = 4096;
     pch = pvn3d_ceil_div(P, pchunk);
     const size_t lds = (size_t)cpb * n * sizeof(float);
-#define GP_ROWS_LAUNCH(CPB)                                                                   \
-  do {                                                                                        \
-    auto kern = group_points_rows_kernel<CPB>;                                                \
-    if (lds > 48 * 1024)                                                                      \
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                              (int)lds));                                     \
-    hipLaunchKernelGGL(kern, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk, points, \
-                       idx, out, out_batch_stride);                                           \
-  } while (0)
     switch (cpb) {
-      case 8: GP_ROWS_LAUNCH(8); break;
-      case 4: GP_ROWS_LAUNCH(4); break;
-      case 2: GP_ROWS_LAUNCH(2); break;
-      default: GP_ROWS_LAUNCH(1); break;
+      case 4:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<4>));
+        hipLaunchKernelGGL(group_points_rows_kernel<4>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
+                           points, idx, out, out_batch_stride);
+        break;
+      case 2:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<2>));
+        hipLaunchKernelGGL(group_points_rows_kernel<2>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
+                           points, idx, out, out_batch_stride);
+        break;
+      default:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<1>));
+        hipLaunchKernelGGL(group_points_rows_kernel<1>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
+                           points, idx, out, out_batch_stride);
+        break;
     }
-#undef GP_ROWS_LAUNCH
-  } else if (lds_ok) {
-    const int gx = pvn3d_ceil_div(P, 2048);
-    int chunks = pvn3d_ceil_div(2048, gx * b);
-    if (chunks < 1) chunks = 1;
-    if (chunks > c) chunks = c;
-    int cch = pvn3d_ceil_div(c, chunks);
-    if (cch < 4 && c >= 4) cch = 4;  // amortise the first (un-overlapped) row load
-    chunks = pvn3d_ceil_div(c, cch);
-    hipLaunchKernelGGL(group_points_lds_kernel, dim3(gx, chunks, b), dim3(256),
-                       (size_t)2 * n * sizeof(float), st, c, n, P, cch, points, idx, out,
-                       out_batch_stride);
   } else if (aligned) {
     const int gx = pvn3d_ceil_div(P, 1024);
     // split channels until there are a few thousand workgroups (256 CUs x 8)

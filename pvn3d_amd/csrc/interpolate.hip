@@ -13,14 +13,13 @@
 // points, keeps their 12 indices/weights in registers and loops over channels with one
 // 16-byte store per channel.
 // Arithmetic: -ffp-contract=off; d = ((dx*dx + dy*dy) + dz*dz), out = ((p1*w1 + p2*w2) + p3*w3).
-#include <cstdlib>
 
 #include "common.h"
 
 namespace {
 
 constexpr int NN_CHUNK = 1024;
-constexpr int TI_LDS_MAX_M = 4096;  // rows up to 16 KiB are staged through LDS
+constexpr int TI_LDS_MAX_M = 4096;  // known-point rows up to 16 KiB are staged through LDS (row-owner kernel)
 
 // grid: (ceil(n/256), b)
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
@@ -112,78 +111,6 @@ __global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(
              row[id[u * 3 + 2]] * w[u * 3 + 2];
     *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
     row += m;
-    o += n;
-  }
-}
-
-// LDS-staged variant (m <= TI_LDS_MAX_M): channel row l of `points` (m floats) is copied to
-// LDS with coalesced 16-byte loads, double-buffered, and the 12 random reads per thread become
-// ds_read_b32 (see group_points_lds_kernel).  grid: (ceil(n/1024), n_chunks, b);
-// dynamic LDS = 2*m floats; n % 4 == 0, m % 4 == 0.
-__global__ __launch_bounds__(256) void three_interpolate_lds_kernel(
-    int c, int m, int n, int cch, const float* __restrict__ points,
-    const int* __restrict__ idx, const float* __restrict__ weight, float* __restrict__ out) {
-  extern __shared__ float s_row[];  // [2][m]
-  const int tid = threadIdx.x;
-  const int j0 = (blockIdx.x * 256 + tid) * 4;
-  const bool valid = j0 < n;
-  const int bi = blockIdx.z;
-  const int c0 = blockIdx.y * cch;
-  const int c1 = min(c0 + cch, c);
-  int id[12];
-  float w[12];
-#pragma unroll
-  for (int u = 0; u < 12; ++u) { id[u] = 0; w[u] = 0.f; }
-  if (valid) {
-    const int4* ip = reinterpret_cast<const int4*>(idx + ((size_t)bi * n + j0) * 3);
-    const float4* wp = reinterpret_cast<const float4*>(weight + ((size_t)bi * n + j0) * 3);
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int4 a = ip[u];
-      const float4 f = wp[u];
-      id[u * 4 + 0] = a.x; id[u * 4 + 1] = a.y; id[u * 4 + 2] = a.z; id[u * 4 + 3] = a.w;
-      w[u * 4 + 0] = f.x; w[u * 4 + 1] = f.y; w[u * 4 + 2] = f.z; w[u * 4 + 3] = f.w;
-    }
-  }
-  const int m4 = m >> 2;
-  const float4* row = reinterpret_cast<const float4*>(points + ((size_t)bi * c + c0) * m);
-  float* o = out + ((size_t)bi * c + c0) * n + j0;
-  float4* s4 = reinterpret_cast<float4*>(s_row);
-  for (int q = tid; q < m4; q += 256) s4[q] = row[q];
-  __syncthreads();
-  int cur = 0;
-  for (int l = c0; l < c1; ++l) {
-    const float* sr = s_row + cur * m;
-    const bool more = l + 1 < c1;
-    const float4* nrow = row + (size_t)m4;
-    float4 pre[2];
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int q = tid + u * 256;
-        if (q < m4) pre[u] = nrow[q];
-      }
-    }
-    if (valid) {
-      float r[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        r[u] = sr[id[u * 3 + 0]] * w[u * 3 + 0] + sr[id[u * 3 + 1]] * w[u * 3 + 1] +
-               sr[id[u * 3 + 2]] * w[u * 3 + 2];
-      *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
-    }
-    if (more) {
-      float4* d4 = s4 + (size_t)(cur ^ 1) * m4;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int q = tid + u * 256;
-        if (q < m4) d4[q] = pre[u];
-      }
-      for (int q = tid + 2 * 256; q < m4; q += 256) d4[q] = nrow[q];
-    }
-    __syncthreads();
-    cur ^= 1;
-    row = nrow;
     o += n;
   }
 }
@@ -288,16 +215,12 @@ extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* 
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = (n % 4 == 0) && (((uintptr_t)out & 15) == 0) &&
                        (((uintptr_t)idx & 15) == 0) && (((uintptr_t)weight & 15) == 0);
-  const char* env = getenv("PVN3D_INTERP_DIRECT");
-  const bool lds_ok = aligned && (m % 4 == 0) && m <= TI_LDS_MAX_M && m > 0 &&
-                      (((uintptr_t)points & 15) == 0) && !(env && env[0] == '1');
-  const char* mode = getenv("PVN3D_INTERP_MODE");  // tuning A/B: "rows" | "tile" | unset
-  const bool rows_ok = lds_ok && !(mode && mode[0] == 't');
+  const bool rows_ok = aligned && (m % 4 == 0) && m <= TI_LDS_MAX_M && m > 0 && (((uintptr_t)points & 15) == 0);
   if (rows_ok) {
-    // 4 rows per workgroup measured best (idx/weight are 24 B per point, read once per 4 rows)
+    // 4 rows per workgroup measured best (idx/weight are 24 B per point, read once per 4 rows);
+    // tile-owner and direct-gather variants measured slower and were removed
     int cpb = 4;
     while (cpb > 1 && (size_t)cpb * m * 4 > 64 * 1024) cpb >>= 1;
-    if (const char* e = getenv("PVN3D_INTERP_CPB")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4 || v == 8) && (size_t)v * m * 4 <= 128 * 1024) cpb = v; }
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb);
     int jch = pvn3d_ceil_div(4096, rows * b);
@@ -306,33 +229,23 @@ extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* 
     if (jchunk < 2048) jchunk = 2048;
     jch = pvn3d_ceil_div(n, jchunk);
     const size_t lds = (size_t)cpb * m * sizeof(float);
-#define TI_ROWS_LAUNCH(CPB)                                                                    \
-  do {                                                                                         \
-    auto kern = three_interpolate_rows_kernel<CPB>;                                            \
-    if (lds > 48 * 1024)                                                                       \
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                              (int)lds));                                      \
-    hipLaunchKernelGGL(kern, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk, points,  \
-                       idx, weight, out);                                                      \
-  } while (0)
     switch (cpb) {
-      case 8: TI_ROWS_LAUNCH(8); break;
-      case 4: TI_ROWS_LAUNCH(4); break;
-      case 2: TI_ROWS_LAUNCH(2); break;
-      default: TI_ROWS_LAUNCH(1); break;
+      case 4:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_rows_kernel<4>));
+        hipLaunchKernelGGL(three_interpolate_rows_kernel<4>, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk,
+                           points, idx, weight, out);
+        break;
+      case 2:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_rows_kernel<2>));
+        hipLaunchKernelGGL(three_interpolate_rows_kernel<2>, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk,
+                           points, idx, weight, out);
+        break;
+      default:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_rows_kernel<1>));
+        hipLaunchKernelGGL(three_interpolate_rows_kernel<1>, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk,
+                           points, idx, weight, out);
+        break;
     }
-#undef TI_ROWS_LAUNCH
-  } else if (lds_ok) {
-    const int gx = pvn3d_ceil_div(n, 1024);
-    int chunks = pvn3d_ceil_div(2048, gx * b);
-    if (chunks < 1) chunks = 1;
-    if (chunks > c) chunks = c;
-    int cch = pvn3d_ceil_div(c, chunks);
-    if (cch < 4 && c >= 4) cch = 4;
-    chunks = pvn3d_ceil_div(c, cch);
-    hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(gx, chunks, b), dim3(256),
-                       (size_t)2 * m * sizeof(float), st, c, m, n, cch, points, idx, weight, out);
   } else if (aligned) {
     const int gx = pvn3d_ceil_div(n, 1024);
     int chunks = pvn3d_ceil_div(2048, gx * b);

@@ -23,8 +23,6 @@
 // accumulators.  The neighbour count / labels pass uses the ORIGINAL coordinates and the
 // oracle's exact unfused fp32 distance so labels are bit-identical to it.
 // This TU is compiled with -ffp-contract=off; FMAs in the hot loop are explicit fmaf().
-#include <cstdlib>
-
 #include "common.h"
 
 namespace {
@@ -37,9 +35,6 @@ constexpr int MS_CHUNK = 512;
 
 struct MsState {        // device-side layout inside the caller's workspace
   float4* cbuf[2];      // seed positions, scaled+centred frame, double-buffered
-  float4* pts4s;        // points in the scaled+centred frame (MFMA path)
-  uint4* feat;          // bf16 split features of the points, 64 B per point (MFMA path)
-  float4* origin;       // [n_seg] frame origin of each fit (MFMA path)
   unsigned* maxshift;   // [n_seg][max_iter+2]  float bits (>= 0 so uint order == float order)
   unsigned* cmmax;      // [n_seg][max_iter+2]  max |c'|^2 over the seeds after iteration t (float bits)
   int* iters;           // [n_seg]
@@ -58,9 +53,6 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_c0 = take(sizeof(float4) * (size_t)total);
   const size_t o_c1 = take(sizeof(float4) * (size_t)total);
-  const size_t o_p4 = take(sizeof(float4) * (size_t)total);
-  const size_t o_ft = take((size_t)64 * (size_t)total);
-  const size_t o_org = take(sizeof(float4) * (size_t)n_seg);
   const size_t o_small = off;  // everything from here is zero-filled per call
   const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_cm = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
@@ -74,9 +66,6 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   if (st) {
     st->cbuf[0] = (float4*)(base + o_c0);
     st->cbuf[1] = (float4*)(base + o_c1);
-    st->pts4s = (float4*)(base + o_p4);
-    st->feat = (uint4*)(base + o_ft);
-    st->origin = (float4*)(base + o_org);
     st->maxshift = (unsigned*)(base + o_ms);
     st->cmmax = (unsigned*)(base + o_cm);
     st->iters = (int*)(base + o_it);
@@ -171,14 +160,25 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 
 // ---------------------------------------------------------------------------------------
 // one mean-shift iteration for every still-running fit.  grid: (tiles, n_seg), block 256.
-// S seeds per thread (tile = 256*S seeds).
+// PK = false: one seed per lane, 8 (fast form) or 9 VALU instructions per (seed, point) pair.
+// PK = true : two seeds per lane held as float2; the exponent and the four accumulations are packed
+//             fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 with the point operand broadcast through
+//             op_sel), 3.5 packed + 1 v_exp_f32 per pair instead of 7 + 1.  tile = 512 seeds.
+// Both evaluate, per seed, exactly the same sequence of fp32 operations (fmaf chains in the same
+// order), so the two kernels give bit-identical results.
 // ---------------------------------------------------------------------------------------
-template <int S>
+typedef float ms_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ ms_f2 ms_fma2(ms_f2 a, ms_f2 b, ms_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ ms_f2 ms_splat(float x) { return ms_f2{x, x}; }
+
+template <bool PK>
 __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
     unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
     int max_iter, float thresh, float kappa, float inv_kappa) {
+  constexpr int S = PK ? 2 : 1;
   __shared__ float4 s_pts[MS_CHUNK];
   __shared__ float s_red[2][MS_THREADS / 64];
   const int seg = blockIdx.y;
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
   // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
   // |c'|^2 <= 64 (no overflow: the largest weight is exp2(|c'|^2)) the per-pair subtraction of
-  // |c'|^2 is dropped -- one VALU instruction of nine.  The bound comes from the previous
-  // iteration's output; iteration 1 always takes the exact form.
+  // |c'|^2 is dropped.  The bound comes from the previous iteration's output; iteration 1 always
+  // takes the exact form.
   unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
   const bool fast = t > 1 && __uint_as_float(cmx[t - 1]) <= 64.f;
 
@@ -219,6 +219,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     cm[s] = fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x));
     sw[s] = sx[s] = sy[s] = sz[s] = 0.f;
   }
+  // packed views of the per-seed state (PK only; element s = seed s of this lane)
+  ms_f2 p2x, p2y, p2z, pcm, psw, psx, psy, psz;
+  if (PK) {
+    p2x = ms_f2{c2x[0], c2x[S - 1]}; p2y = ms_f2{c2y[0], c2y[S - 1]}; p2z = ms_f2{c2z[0], c2z[S - 1]};
+    pcm = ms_f2{cm[0], cm[S - 1]};
+    psw = psx = psy = psz = ms_splat(0.f);
+  }
 
   for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
     const int cnt = min(MS_CHUNK, n - j0);
@@ -237,37 +244,59 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     }
     __syncthreads();
     const int cnt4 = (cnt + 3) & ~3;
-    if (fast) {
+    if (PK) {
+      if (fast) {
+#pragma unroll 4
+        for (int q = 0; q < cnt4; ++q) {
+          const float4 a = s_pts[q];
+          const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), ms_splat(a.w))));
+          const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          psw += w;
+          psx = ms_fma2(w, ms_splat(a.x), psx);
+          psy = ms_fma2(w, ms_splat(a.y), psy);
+          psz = ms_fma2(w, ms_splat(a.z), psz);
+        }
+      } else {
+#pragma unroll 4
+        for (int q = 0; q < cnt4; ++q) {
+          const float4 a = s_pts[q];
+          const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), ms_splat(a.w) - pcm)));
+          const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          psw += w;
+          psx = ms_fma2(w, ms_splat(a.x), psx);
+          psy = ms_fma2(w, ms_splat(a.y), psy);
+          psz = ms_fma2(w, ms_splat(a.z), psz);
+        }
+      }
+    } else if (fast) {
 #pragma unroll 4
       for (int q = 0; q < cnt4; ++q) {
         const float4 a = s_pts[q];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const float e = fmaf(c2z[s], a.z, fmaf(c2y[s], a.y, fmaf(c2x[s], a.x, a.w)));
-          const float w = __builtin_amdgcn_exp2f(e);
-          sw[s] += w;
-          sx[s] = fmaf(w, a.x, sx[s]);
-          sy[s] = fmaf(w, a.y, sy[s]);
-          sz[s] = fmaf(w, a.z, sz[s]);
-        }
+        const float e = fmaf(c2z[0], a.z, fmaf(c2y[0], a.y, fmaf(c2x[0], a.x, a.w)));
+        const float w = __builtin_amdgcn_exp2f(e);
+        sw[0] += w;
+        sx[0] = fmaf(w, a.x, sx[0]);
+        sy[0] = fmaf(w, a.y, sy[0]);
+        sz[0] = fmaf(w, a.z, sz[0]);
       }
     } else {
 #pragma unroll 4
       for (int q = 0; q < cnt4; ++q) {
         const float4 a = s_pts[q];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : one subtract + three FMAs instead of
-          // three subtracts + mul + two FMAs (the frame is centred, so magnitudes stay ~1)
-          const float e = fmaf(c2z[s], a.z, fmaf(c2y[s], a.y, fmaf(c2x[s], a.x, a.w - cm[s])));
-          const float w = __builtin_amdgcn_exp2f(e);
-          sw[s] += w;
-          sx[s] = fmaf(w, a.x, sx[s]);
-          sy[s] = fmaf(w, a.y, sy[s]);
-          sz[s] = fmaf(w, a.z, sz[s]);
-        }
+        // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : one subtract + three FMAs instead of
+        // three subtracts + mul + two FMAs (the frame is centred, so magnitudes stay ~1)
+        const float e = fmaf(c2z[0], a.z, fmaf(c2y[0], a.y, fmaf(c2x[0], a.x, a.w - cm[0])));
+        const float w = __builtin_amdgcn_exp2f(e);
+        sw[0] += w;
+        sx[0] = fmaf(w, a.x, sx[0]);
+        sy[0] = fmaf(w, a.y, sy[0]);
+        sz[0] = fmaf(w, a.z, sz[0]);
       }
     }
+  }
+  if (PK) {
+    sw[0] = psw.x; sx[0] = psx.x; sy[0] = psy.x; sz[0] = psz.x;
+    sw[S - 1] = psw.y; sx[S - 1] = psx.y; sy[S - 1] = psy.y; sz[S - 1] = psz.y;
   }
 
   float mshift = 0.f, mcm = 0.f;
@@ -301,339 +330,6 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   }
 }
 
-// =======================================================================================
-// MFMA-assisted iteration.  The exponent of the Gaussian weight,
-//   t_ij = -|c_i - a_j|^2 = 2 c_i.a_j - |a_j|^2 - |c_i|^2          (scaled+centred frame),
-// is a rank-5 bilinear form, i.e. a tiny GEMM (seeds x points x K).  Each fp32 operand is split
-// into three bf16 pieces (x = x_h + x_m + x_l, 24 significant bits); the six largest cross
-// terms per coordinate plus the split norms fill 24 of the 32 K-slots of two
-// v_mfma_f32_32x32x16_bf16 per 32x32 tile.  Every bf16 x bf16 product is exact in the fp32
-// accumulator, so t carries fp32-level error (~1e-7 * (|c|^2 + |a|^2), kept small by centring
-// each fit on the mean of its points).  The VALU is left with exp2 + the four accumulations:
-// 5 instructions per pair instead of 11, while the matrix pipe does the distance part.
-// STATUS (round 1): opt-in (PVN3D_MS_USE_MFMA).  It is parity-green but on MI355X it only ties
-// the pure-VALU kernel (about 1.65 vs 1.9 ms per iteration at 576 fits x 3072 points): hipcc's
-// SLP packing of the accumulate step into v_pk_add/v_pk_fma_f32 next to in-flight MFMAs gave
-// run-to-run different sums (tools/det_check2.py), so this TU is built with
-// -fno-slp-vectorize, and without packed math the VALU side costs as much as before.
-// Layout: rows (M) = 32 seeds of the wave, columns (N) = 32 points of the tile; a lane owns one
-// point column and 16 seed rows (C/D map: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
-// so the per-seed sums are finished by one cross-lane reduction per iteration.
-// =======================================================================================
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-__device__ __forceinline__ unsigned bf16_rn(float x) {  // round-to-nearest-even, as 16 bits
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-
-struct Split3 { unsigned h, m, l; };
-
-__device__ __forceinline__ Split3 split3(float x) {
-  Split3 s;
-  s.h = bf16_rn(x);
-  const float r1 = x - __uint_as_float(s.h << 16);
-  s.m = bf16_rn(r1);
-  const float r2 = r1 - __uint_as_float(s.m << 16);
-  s.l = bf16_rn(r2);
-  return s;
-}
-
-constexpr unsigned BF16_ONE = 0x3f80u;
-
-// 32 K-slots of the point (B) side.  See ms_seed_slots for the matching seed (A) side.
-__device__ __forceinline__ void ms_point_slots(float ax, float ay, float az, float na,
-                                               unsigned short* k) {
-  const Split3 x = split3(ax), y = split3(ay), z = split3(az), q = split3(na);
-  const Split3 c[3] = {x, y, z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    k[d * 6 + 0] = c[d].h; k[d * 6 + 1] = c[d].m; k[d * 6 + 2] = c[d].h;
-    k[d * 6 + 3] = c[d].m; k[d * 6 + 4] = c[d].l; k[d * 6 + 5] = c[d].h;
-  }
-  k[18] = q.h; k[19] = q.m; k[20] = q.l;
-  k[21] = BF16_ONE; k[22] = BF16_ONE; k[23] = BF16_ONE;
-#pragma unroll
-  for (int i = 24; i < 32; ++i) k[i] = 0;
-}
-
-__device__ __forceinline__ void ms_seed_slots(float cx, float cy, float cz, unsigned short* k) {
-  const float nc = -(cx * cx + cy * cy + cz * cz);
-  const Split3 x = split3(2.f * cx), y = split3(2.f * cy), z = split3(2.f * cz), q = split3(nc);
-  const Split3 c[3] = {x, y, z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    k[d * 6 + 0] = c[d].h; k[d * 6 + 1] = c[d].h; k[d * 6 + 2] = c[d].m;
-    k[d * 6 + 3] = c[d].m; k[d * 6 + 4] = c[d].h; k[d * 6 + 5] = c[d].l;
-  }
-  k[18] = BF16_ONE; k[19] = BF16_ONE; k[20] = BF16_ONE;
-  k[21] = q.h; k[22] = q.m; k[23] = q.l;
-#pragma unroll
-  for (int i = 24; i < 32; ++i) k[i] = 0;
-}
-
-// per-fit preparation (once per call): origin = mean of the fit's points; points in the
-// scaled+centred frame; their bf16 feature chunks laid out [tile][chunk 0..3][32 points][16 B].
-// Requires seg_off % 32 == 0 and room for roundup32(cnt) rows per segment.
-// grid: (n_seg), block 256.
-__global__ __launch_bounds__(256) void ms_prep_kernel(const float4* __restrict__ pts,
-                                                      const int* __restrict__ seg_off,
-                                                      const int* __restrict__ seg_cnt,
-                                                      float kappa, float4* __restrict__ origin,
-                                                      float4* __restrict__ pts4s,
-                                                      uint4* __restrict__ feat) {
-  __shared__ float s_sum[3][4];
-  const int seg = blockIdx.x;
-  const int n = seg_cnt[seg];
-  const int base = seg_off[seg];
-  const int tid = threadIdx.x;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int j = tid; j < n; j += 256) {
-    const float4 a = pts[base + j];
-    sx += a.x; sy += a.y; sz += a.z;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); sz += __shfl_xor(sz, o, 64);
-  }
-  if ((tid & 63) == 0) { s_sum[0][tid >> 6] = sx; s_sum[1][tid >> 6] = sy; s_sum[2][tid >> 6] = sz; }
-  __syncthreads();
-  const float inv = n > 0 ? 1.0f / (float)n : 0.f;
-  const float ox = (s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3]) * inv;
-  const float oy = (s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3]) * inv;
-  const float oz = (s_sum[2][0] + s_sum[2][1] + s_sum[2][2] + s_sum[2][3]) * inv;
-  if (tid == 0) origin[seg] = make_float4(ox, oy, oz, 0.f);
-  const int n32 = (n + 31) & ~31;
-  for (int j = tid; j < n32; j += 256) {
-    float ax = 0.f, ay = 0.f, az = 0.f, na = -1e30f;  // padded rows: weight exp2(-1e30) = 0
-    if (j < n) {
-      const float4 a = pts[base + j];
-      ax = (a.x - ox) * kappa; ay = (a.y - oy) * kappa; az = (a.z - oz) * kappa;
-      na = -(ax * ax + ay * ay + az * az);
-    }
-    pts4s[base + j] = make_float4(ax, ay, az, 0.f);
-    unsigned short k[32];
-    ms_point_slots(ax, ay, az, na, k);
-    const int row = base + j;
-    const size_t tile = (size_t)(row >> 5);
-    const int col = row & 31;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint4 v;
-      v.x = k[c * 8 + 0] | ((unsigned)k[c * 8 + 1] << 16);
-      v.y = k[c * 8 + 2] | ((unsigned)k[c * 8 + 3] << 16);
-      v.z = k[c * 8 + 4] | ((unsigned)k[c * 8 + 5] << 16);
-      v.w = k[c * 8 + 6] | ((unsigned)k[c * 8 + 7] << 16);
-      feat[(tile * 4 + c) * 32 + col] = v;
-    }
-  }
-}
-
-__device__ __forceinline__ float dpp_sum32(float v) {
-  // Sum over the 32 lanes of a half-wave; the result is valid in lanes 31 and 63.
-  // Hand-written with explicit wait states so the chain stays one v_add_f32_dpp per stage.
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v));
-  return v;
-}
-
-constexpr int MS_CT = 4;                          // point tiles (of 32) per LDS chunk
-constexpr int MS_CHUNK_FEAT = MS_CT * 4 * 32;     // uint4 entries of features per chunk (16 KiB)
-constexpr int MS_CHUNK_PTS = MS_CT * 32;          // float4 entries of coordinates (4 KiB)
-constexpr int MS_CHUNK_V4 = MS_CHUNK_FEAT + MS_CHUNK_PTS;  // 640 x 16 B = 10 KiB per buffer
-constexpr int MS_STAGE = (MS_CHUNK_V4 + 255) / 256;        // uint4 per thread per chunk
-
-#define MS_MFMA_PAIR(ACC, B0, B1)                                                              \
-  do {                                                                                         \
-    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) ACC[r_] = 0.f;                           \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8_t, B0), ACC, 0, 0, 0); \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8_t, B1), ACC, 0, 0, 0); \
-  } while (0)
-
-#define MS_CONSUME(ACC, P)                                                                     \
-  do {                                                                                         \
-    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                        \
-      const float w_ = __builtin_amdgcn_exp2f(ACC[r_]);                                        \
-      sw[r_] += w_;                                                                            \
-      sx[r_] = fmaf(w_, P.x, sx[r_]);                                                          \
-      sy[r_] = fmaf(w_, P.y, sy[r_]);                                                          \
-      sz[r_] = fmaf(w_, P.z, sz[r_]);                                                          \
-    }                                                                                          \
-  } while (0)
-
-// grid: (ceil(max_cnt / 128), n_seg), block 256 = 4 waves x 32 seeds.
-// The 4 waves share the point stream: chunks of MS_CT tiles go through a double-buffered LDS
-// ring (register-staged, one barrier per chunk); inside a chunk the MFMA pair of tile T+1 is
-// issued before the VALU consumes tile T, so the matrix pipe's latency hides behind
-// exp2 + accumulate.
-__global__ __launch_bounds__(256) void ms_iter_mfma_kernel(
-    const float4* __restrict__ pts4s, const uint4* __restrict__ feat,
-    const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
-    const float4* __restrict__ cin, float4* __restrict__ cout, unsigned* __restrict__ maxshift,
-    int* __restrict__ iters, int t, int max_iter, float thresh, float inv_kappa) {
-  __shared__ uint4 s_buf[2][MS_CHUNK_V4];   // [feat 16 KiB | coords 4 KiB] x 2
-  __shared__ float s_red[4];
-  const int seg = blockIdx.y;
-  const int n = seg_cnt[seg];
-  const int tile0 = blockIdx.x * 128;
-  if (tile0 >= n) return;
-  unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
-  if (t > 1) {
-    const float prev = __uint_as_float(ms[t - 1]);
-    if (!(prev >= thresh) || (t - 1) > max_iter) return;
-  }
-  const int base = seg_off[seg];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, col = lane & 31;
-  const int s0 = tile0 + wave * 32;
-  const bool active = s0 < n;   // wave-uniform; inactive waves still help with the copies
-
-  // ---- A operand: this lane's seed row is s0 + col
-  bf16x8_t a0, a1;
-  {
-    const int i = s0 + col;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) c = (t == 1) ? pts4s[base + i] : cin[base + i];
-    unsigned short k[32];
-    ms_seed_slots(c.x, c.y, c.z, k);
-    unsigned short e0[8], e1[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      e0[q] = half ? k[8 + q] : k[q];
-      e1[q] = half ? k[24 + q] : k[16 + q];
-    }
-    uint4 u0, u1;
-    u0.x = e0[0] | ((unsigned)e0[1] << 16); u0.y = e0[2] | ((unsigned)e0[3] << 16);
-    u0.z = e0[4] | ((unsigned)e0[5] << 16); u0.w = e0[6] | ((unsigned)e0[7] << 16);
-    u1.x = e1[0] | ((unsigned)e1[1] << 16); u1.y = e1[2] | ((unsigned)e1[3] << 16);
-    u1.z = e1[4] | ((unsigned)e1[5] << 16); u1.w = e1[6] | ((unsigned)e1[7] << 16);
-    a0 = __builtin_bit_cast(bf16x8_t, u0);
-    a1 = __builtin_bit_cast(bf16x8_t, u1);
-  }
-  float sw[16], sx[16], sy[16], sz[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sw[r] = sx[r] = sy[r] = sz[r] = 0.f;
-
-  const int n_tiles = (n + 31) >> 5;
-  const int n_chunks = (n_tiles + MS_CT - 1) / MS_CT;
-  const uint4* gfeat = feat + (size_t)(base >> 5) * 128;             // 128 uint4 per tile
-  const uint4* gpts = reinterpret_cast<const uint4*>(pts4s + base);  // 32 uint4 per tile
-
-  // Chunk staging: MS_CHUNK_V4 x 16 B per chunk, MS_STAGE per thread.  The global loads of chunk ch+1 are
-  // issued before chunk ch is consumed and parked in registers; they are written to the other
-  // LDS buffer after the compute, then one barrier publishes them.
-  uint4 stage[MS_STAGE];
-  auto load_chunk = [&](int ch) {
-    const int tl = min(MS_CT, n_tiles - ch * MS_CT);   // tiles present in this chunk
-#pragma unroll
-    for (int u = 0; u < MS_STAGE; ++u) {
-      const int el = min(u * 256 + tid, MS_CHUNK_V4 - 1);
-      const uint4* src;
-      if (el < MS_CHUNK_FEAT) {
-        const int lim = tl * 128 - 1;
-        src = gfeat + (size_t)ch * MS_CHUNK_FEAT + (el <= lim ? el : lim);
-      } else {
-        const int q = el - MS_CHUNK_FEAT;
-        const int lim = tl * 32 - 1;
-        src = gpts + (size_t)ch * MS_CHUNK_PTS + (q <= lim ? q : lim);
-      }
-      stage[u] = *src;
-    }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < MS_STAGE; ++u)
-      if (u * 256 + tid < MS_CHUNK_V4) s_buf[buf][u * 256 + tid] = stage[u];
-  };
-
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const int buf = ch & 1;
-    const bool more = ch + 1 < n_chunks;
-    if (more) load_chunk(ch + 1);
-    if (active) {
-      const uint4* lf = &s_buf[buf][0];
-      const float4* lp = reinterpret_cast<const float4*>(&s_buf[buf][MS_CHUNK_FEAT]);
-      const int tl = min(MS_CT, n_tiles - ch * MS_CT);
-      f32x16_t accA, accB;
-      uint4 b0 = lf[half * 32 + col], b1 = lf[(2 + half) * 32 + col];
-      MS_MFMA_PAIR(accA, b0, b1);
-      int T = 0;
-      for (; T + 2 <= tl; T += 2) {
-        {   // tile T+1 in flight while tile T is consumed
-          const uint4 c0 = lf[((T + 1) * 4 + half) * 32 + col];
-          const uint4 c1 = lf[((T + 1) * 4 + 2 + half) * 32 + col];
-          MS_MFMA_PAIR(accB, c0, c1);
-          const float4 p = lp[T * 32 + col];
-          MS_CONSUME(accA, p);
-        }
-        if (T + 2 < tl) {
-          const uint4 c0 = lf[((T + 2) * 4 + half) * 32 + col];
-          const uint4 c1 = lf[((T + 2) * 4 + 2 + half) * 32 + col];
-          MS_MFMA_PAIR(accA, c0, c1);
-        }
-        const float4 p = lp[(T + 1) * 32 + col];
-        MS_CONSUME(accB, p);
-      }
-      if (T < tl) {   // odd tile count: the last tile's MFMA pair is already in accA
-        const float4 p = lp[T * 32 + col];
-        MS_CONSUME(accA, p);
-      }
-    }
-    if (more) store_chunk(buf ^ 1);   // buf^1 was last read during chunk ch-1: free since the
-    __syncthreads();                  // barrier that ended that chunk
-  }
-
-  float mshift = 0.f;
-  if (active) {
-    // ---- finish the per-seed sums across the 32 point columns of each half-wave
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sw[r] = dpp_sum32(sw[r]); sx[r] = dpp_sum32(sx[r]);
-      sy[r] = dpp_sum32(sy[r]); sz[r] = dpp_sum32(sz[r]);
-    }
-    if (col == 31) {   // lanes 31 and 63 hold the sums of their 16 rows
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int i = s0 + row;
-        if (i < n) {
-          const float4 c = (t == 1) ? pts4s[base + i] : cin[base + i];
-          const float inv = 1.0f / sw[r];
-          const float nx = sx[r] * inv, ny = sy[r] * inv, nz = sz[r] * inv;
-          const float ex = nx - c.x, ey = ny - c.y, ez = nz - c.z;
-          mshift = fmaxf(mshift, sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_kappa);
-          cout[base + i] = make_float4(nx, ny, nz, 0.f);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
-  if (lane == 0) s_red[wave] = mshift;
-  __syncthreads();
-  if (tid == 0) {
-    const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    atomicMax(ms + t, __float_as_uint(m));
-    atomicMax(iters + seg, t);
-  }
-}
-
 // number of fits that would still run iteration t+1.  grid 1, block 256.
 __global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
                                const int* __restrict__ seg_cnt, int n_seg, int t, int max_iter,
@@ -652,55 +348,6 @@ __global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
   if (threadIdx.x == 0) *active_slot = s_any;
 }
 
-// neighbour count of every ORIGINAL point (meanshift_pytorch.py:46-49) + first-max argmax.
-// `dis < bw` is evaluated as d2 <= d2_max where d2_max is the largest fp32 whose correctly
-// rounded sqrt is < bw (host-computed) -- identical to the oracle's sqrtf(d2) < bw.
-// grid: (tiles, n_seg), block 256, one seed per thread.
-__global__ __launch_bounds__(MS_THREADS) void ms_count_kernel(
-    const float4* __restrict__ pts, const int* __restrict__ seg_off,
-    const int* __restrict__ seg_cnt, float d2_max, unsigned long long* __restrict__ best) {
-  __shared__ float4 s_pts[MS_CHUNK];
-  __shared__ unsigned long long s_red[MS_THREADS / 64];
-  const int seg = blockIdx.y;
-  const int n = seg_cnt[seg];
-  const int tile0 = blockIdx.x * MS_THREADS;
-  if (tile0 >= n) return;
-  const int base = seg_off[seg];
-  const int tid = threadIdx.x;
-  const int i = tile0 + tid;
-  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n) c = pts[base + i];
-  int count = 0;
-  for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
-    const int cnt = min(MS_CHUNK, n - j0);
-    __syncthreads();
-    for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + j0 + q];
-    __syncthreads();
-    for (int q = 0; q < cnt; ++q) {
-      const float4 a = s_pts[q];
-      const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      count += (d2 <= d2_max) ? 1 : 0;
-    }
-  }
-  unsigned long long key = 0ULL;
-  if (i < n) key = ((unsigned long long)(unsigned)count << 32) | (unsigned long long)(~(unsigned)i);
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)key, o, 64);
-    const unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
-    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-    key = other > key ? other : key;
-  }
-  if ((tid & 63) == 0) s_red[tid >> 6] = key;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long m = s_red[0];
-    for (int w = 1; w < MS_THREADS / 64; ++w) m = s_red[w] > m ? s_red[w] : m;
-    atomicMax(best + seg, m);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // Pruned neighbour count (exact).  The reference counts, for every point i, the points within bw
 // (meanshift_pytorch.py:46-48): n^2 distance tests.  Votes are tightly clustered, so most pairs
@@ -708,8 +355,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_kernel(
 //   r_i <= R and r_j <= R, R = 0.499 bw   =>   |a_i - a_j| <= 0.998 bw,
 // which is a hit under the reference's fp32 test as well (its rounding error is ~1e-7 relative,
 // the margin 2e-3).  "Core" points (r <= R) therefore all count each other without a test;
-// only pairs with a non-core partner are evaluated, with exactly the arithmetic of
-// ms_count_kernel.  counts[i] = (core_i ? n_core : hits among core columns)
+// only pairs with a non-core partner are evaluated, with the oracle's exact arithmetic:
+// `dis < bw` (meanshift_pytorch.py:48) as d2 <= d2_max, d2 = (dx*dx + dy*dy) + dz*dz unfused, where
+// d2_max is the largest fp32 whose correctly rounded sqrt is < bw (host-computed).  counts[i] = (core_i ? n_core : hits among core columns)
 //                              + hits among non-core columns.
 // Worst case (no core points) = the full n^2 scan; typical votes: ~10 % of it.
 // ---------------------------------------------------------------------------------------
@@ -869,7 +517,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ c0,
     const float4* __restrict__ c1, const unsigned long long* __restrict__ best,
-    const int* __restrict__ iters_ws, const float4* __restrict__ origin, float d2_max,
+    const int* __restrict__ iters_ws, float d2_max,
     float inv_kappa, float* __restrict__ ctr, uint8_t* __restrict__ labels,
     int* __restrict__ iters) {
   const int seg = blockIdx.y;
@@ -895,7 +543,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
   }
   if (blockIdx.x == 0 && tid == 0) {
     const int it = iters_ws[seg];
-    const float4 org = origin ? origin[seg] : pts[base];   // frame origin used by the iterations
+    const float4 org = pts[base];   // frame origin used by the iterations
     const float4 m = (it & 1) ? c1[base + max_idx] : c0[base + max_idx];
     ctr[seg * 3 + 0] = m.x * inv_kappa + org.x;
     ctr[seg * 3 + 1] = m.y * inv_kappa + org.y;
@@ -965,25 +613,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   const float d2_max = d2_threshold(bandwidth);
   const float4* P = (const float4*)pts;
 
-  // seeds per thread: 2 once a fit has enough seeds to keep the chip busy anyway
-  const long long seeds = (long long)n_seg * max_cnt_host;
-  // seeds per thread: more seeds per thread amortise the LDS point reads; only once there are
-  // enough seeds to keep the chip busy anyway.  PVN3D_MS_S overrides (tuning).
-  // Measured on MI355X (576 fits x 3072 points): S = 1 / 2 / 4 -> 8.9 / 9.5 / 10.2 ms per call.
-  int S_sel = 1;
-  (void)seeds;
-  if (const char* e = getenv("PVN3D_MS_S")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) S_sel = v; }
-  const int tile = MS_THREADS * S_sel;
+  // Two seeds per lane (packed fp32 math) once the largest fit fills at least two 512-seed tiles;
+  // below that the one-seed kernel has twice the workgroups.  The two kernels give identical bits
+  // (tests/test_gpu_postproc.py); the FORCE flags exist for that test and for A/B timing.
+  bool packed = max_cnt_host >= 1024;
+  if (flags & PVN3D_MS_FORCE_SCALAR) packed = false;
+  if (flags & PVN3D_MS_FORCE_PACKED) packed = true;
+  const int tile = MS_THREADS * (packed ? 2 : 1);
   const dim3 grid_it(pvn3d_ceil_div(max_cnt_host, tile), n_seg);
   const dim3 grid_1(pvn3d_ceil_div(max_cnt_host, MS_THREADS), n_seg);
-
-  const bool mfma = (flags & PVN3D_MS_ALIGNED32) && (flags & PVN3D_MS_USE_MFMA);
-  const dim3 grid_mf(pvn3d_ceil_div(max_cnt_host, 128), n_seg);
-  if (mfma) {
-    hipLaunchKernelGGL(ms_prep_kernel, dim3(n_seg), dim3(256), 0, st, P, seg_off, seg_cnt, kappa,
-                       S.origin, S.pts4s, S.feat);
-    PVN3D_LAUNCH_CHECK();
-  }
 
   hipEvent_t ev[2] = {nullptr, nullptr};
   int pending[2] = {0, 0};
@@ -997,21 +635,12 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   for (int t = 1; t <= max_iter + 1; ++t) {
     const float4* cin = S.cbuf[(t - 1) & 1];
     float4* cout = S.cbuf[t & 1];
-    if (mfma)
-      hipLaunchKernelGGL(ms_iter_mfma_kernel, grid_mf, dim3(256), 0, st, S.pts4s, S.feat, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.iters, t, max_iter, thresh, inv_kappa);
-    else if (S_sel == 4)
-      hipLaunchKernelGGL(ms_iter_kernel<4>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
-                         inv_kappa);
-    else if (S_sel == 2)
-      hipLaunchKernelGGL(ms_iter_kernel<2>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
-                         inv_kappa);
+    if (packed)
+      hipLaunchKernelGGL(ms_iter_kernel<true>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout,
+                         S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa);
     else
-      hipLaunchKernelGGL(ms_iter_kernel<1>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off,
-                         seg_cnt, cin, cout, S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa,
-                         inv_kappa);
+      hipLaunchKernelGGL(ms_iter_kernel<false>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout,
+                         S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa);
     if ((rc = (int)hipGetLastError()) != 0) break;
     if (poll && (t % poll_every) == 0 && t <= max_iter) {
       hipLaunchKernelGGL(ms_poll_kernel, dim3(1), dim3(256), 0, st, S.maxshift, seg_cnt, n_seg,
@@ -1030,15 +659,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     }
   }
   if (poll) {
+    // a device-to-host copy into poll_host may still be in flight (early break): let it land before
+    // the caller's buffer can be reused by the next call
+    for (int k = 0; k < 2; ++k)
+      if (pending[k]) (void)hipEventSynchronize(ev[k]);
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
   }
   if (rc) return rc;
-  static const bool full_count = [] { const char* e = getenv("PVN3D_MS_FULL_COUNT"); return e && atoi(e) != 0; }();
-  if (full_count) {      // the plain n^2 scan (A/B and fallback)
-    hipLaunchKernelGGL(ms_count_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                       d2_max, S.best);
-  } else {
+  {
     const float r_core = 0.499f * bandwidth;
     hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
                        S.core_idx, S.nc_idx, S.n_core);
@@ -1054,7 +683,7 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   }
   PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(ms_final_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                     S.cbuf[0], S.cbuf[1], S.best, S.iters, mfma ? S.origin : nullptr, d2_max,
+                     S.cbuf[0], S.cbuf[1], S.best, S.iters, d2_max,
                      inv_kappa, ctr, labels, iters);
   PVN3D_LAUNCH_CHECK();
   return 0;

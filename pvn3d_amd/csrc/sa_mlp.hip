@@ -37,7 +37,7 @@
 //     instead of branches) so that the compiler counts outstanding loads instead of falling
 //     back to s_waitcnt vmcnt(0).
 //   * B operand (activations): LDS.  Layer 0 streams its input in 32-channel chunks, double
-//     buffered, rows rotated by 4*(row/4) columns (conflict-free for both the row-gather
+//     buffered, rows of 96 floats shifted by 4*(row/4) columns (conflict-free for both the row-gather
 //     writer and the fragment reader); later layers read the previous activation H[k][64].
 //   * a wave owns row tiles mt = wave, wave+NW, ... (<= NT) x 2 column tiles; accumulators
 //     start from the bias; after a layer relu(acc) goes back to H
@@ -45,7 +45,6 @@
 // Epilogue SA: max over the nsample columns of each centre (through a wave-private LDS patch),
 // store point-major.
 // Epilogue FP: store point-major (intermediate levels) or (B, M, n) (the module's API layout).
-#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -75,6 +74,8 @@ constexpr int SM_CP = SM_KC / 4;     // pairs per chunk = depth of the weight pr
 constexpr int SM_MAX_LAYERS = 4;
 constexpr int SM_MAX_MT = 16;        // M <= 512
 constexpr int SM_EPAD = 68;          // row stride of the max-pool patch (16-byte aligned, conflict-free)
+constexpr int SM_CW = 96;            // row stride of a layer-0 chunk buffer: 64 columns + room for the rotation
+constexpr int SM_TAIL_ROWS = 8;      // widest layer-0 tail the specialised (GEN = false) kernels take
 
 struct MlpDesc {
   int n_layers;
@@ -148,23 +149,21 @@ __device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__
 }
 
 // ---- MFMA spans ---------------------------------------------------------------------------
-// B fragment pair q of a [rows][64] LDS buffer: rows 4q + 2j + half, column tiles col, col+32.
-// SWZ: row r is stored rotated by (r & ~3) columns.
+// B fragment pair q of an LDS buffer: rows 4q + 2j + half, column tiles col, col+32.
+// SWZ (layer-0 chunk buffers, row stride SM_CW): row r is stored shifted right by (r & ~3) columns --
+// conflict-free for the row-gather writer (8 lanes x 4 rows per point) and for this reader -- and the
+// rows are long enough that the shift never wraps, so every read of a span is the lane's base
+// address plus a compile-time offset (a wrapping rotation needed two address registers per pair).
+// !SWZ: activation buffer H[k][64].
 // CS (column split): only column tile `ct` is fetched, into b[j][0].
 template <bool SWZ, bool CS>
 __device__ __forceinline__ void ld_b(float (&b)[2][2], const float* __restrict__ rows_half, int col, int q, int ct) {
-  const float* r0 = rows_half + q * 4 * SM_COLS;
-  if (SWZ) {
-    const int c0 = ((col + 4 * q) & 63) ^ (CS ? ct * 32 : 0), c1 = c0 ^ 32;
-    b[0][0] = r0[c0];
-    b[1][0] = r0[2 * SM_COLS + c0];
-    if (!CS) { b[0][1] = r0[c1]; b[1][1] = r0[2 * SM_COLS + c1]; }
-  } else {
-    const int c0 = col + (CS ? ct * 32 : 0);
-    b[0][0] = r0[c0];
-    b[1][0] = r0[2 * SM_COLS + c0];
-    if (!CS) { b[0][1] = r0[c0 + 32]; b[1][1] = r0[2 * SM_COLS + c0 + 32]; }
-  }
+  constexpr int RS = SWZ ? SM_CW : SM_COLS;
+  const float* r0 = rows_half + q * 4 * RS + (SWZ ? 4 * q : 0);
+  const int c0 = col + (CS ? ct * 32 : 0);
+  b[0][0] = r0[c0];
+  b[1][0] = r0[2 * RS + c0];
+  if (!CS) { b[0][1] = r0[c0 + 32]; b[1][1] = r0[2 * RS + c0 + 32]; }
 }
 
 template <int NTC, int NT, bool CS>
@@ -221,12 +220,12 @@ __device__ __forceinline__ void span8(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP
 }
 
 // the last np (< 8, possibly 0) pairs of a layer: no refill
-template <int NTC, int NT, bool SWZ, bool CS>
+template <int NTC, int NT, bool SWZ, bool CS, int MAXP = SM_CP - 1>
 __device__ __forceinline__ void span_tail(f32x16 (&acc)[NT][2], float2 (&ring)[SM_CP][NTC > 0 ? NTC : 1],
                                           int np, const float* __restrict__ rows_half, int col, int ct) {
   if (NTC == 0) return;
 #pragma unroll
-  for (int u = 0; u < SM_CP - 1; ++u) {
+  for (int u = 0; u < MAXP; ++u) {
     if (u < np) {
       float b[2][2];
       ld_b<SWZ, CS>(b, rows_half, col, u, ct);
@@ -284,8 +283,8 @@ __device__ __forceinline__ void p_commit(const PStage<NB, PIT>& st, float* __res
       r.x = r.x + st.v[it][k].x * wk; r.y = r.y + st.v[it][k].y * wk;
       r.z = r.z + st.v[it][k].z * wk; r.w = r.w + st.v[it][k].w * wk;
     }
-    float* dst = cbuf + (4 * g) * SM_COLS + ((colx + 4 * g) & 63);    // rows 4g..4g+3, rotation 4g
-    dst[0] = r.x; dst[SM_COLS] = r.y; dst[2 * SM_COLS] = r.z; dst[3 * SM_COLS] = r.w;
+    float* dst = cbuf + (4 * g) * SM_CW + colx + 4 * g;    // rows 4g..4g+3, shifted by 4g columns
+    dst[0] = r.x; dst[SM_CW] = r.y; dst[2 * SM_CW] = r.z; dst[3 * SM_CW] = r.w;
   }
 }
 
@@ -314,17 +313,33 @@ __device__ __forceinline__ float c_load(const SaSrc& sa, const FpSrc& fp, const 
 }
 
 __device__ __forceinline__ void c_store(float* __restrict__ cbuf, int row, int lc, float v) {
-  cbuf[row * SM_COLS + ((lc + (row & ~3)) & 63)] = v;
+  cbuf[row * SM_CW + lc + (row & ~3)] = v;
 }
 
+// T loader (layer-0 tail of the specialised kernels, GEN = false): the <= 8 input channels that do
+// not fill a 32-channel chunk -- SA: the 3 relative-xyz channels (grouped_xyz - new_xyz); FP: the last
+// (width mod 32) <= 8 channels of the unknown points' own features, read with 4-byte loads (the table
+// may be a strided view such as pc[..., 3:]).  Thread -> column tid & 63, rows tid>>6 + NW*i < 8.
+template <int NW>
+struct TStage {
+  float v[SM_TAIL_ROWS / NW];
+};
+
 // ---- one workgroup's chain ------------------------------------------------------------------
-// dynamic LDS: H [hrows][64] | chunk [2][32][64] | bias [bias_all] | id [3][64] | w [3][64] | aux [3][64]
-template <bool IS_SA, int NT, int NW>
+// dynamic LDS: H [hrows][64] overlaid with chunk [2][32][64] | bias [bias_all] | id [3][64] | w [3][64] | aux [3][64]
+// (the chunk buffers are dead once layer 0 has been multiplied; H is first written after the barrier
+// that follows, so the two share their storage and a workgroup needs max(H, 16 KiB) instead of the sum)
+// GEN = true keeps the generic per-element loader for layer-0 inputs of any width / alignment;
+// GEN = false (chosen on the host, launch_chain) serves inputs made of whole 32-channel row-gather
+// chunks plus at most one T-loader tail -- every shape of PVN3D's backbone -- without carrying the
+// generic loader's address arithmetic in registers (it cost the 4-wave kernels 84 / 43 spilled VGPRs).
+template <bool IS_SA, int NT, int NW, bool GEN>
 struct Chain {
   static constexpr int NTHR = NW * 64;
   static constexpr int LROWS = SM_KC / NW;
   static constexpr int PIT = (SM_KC * SM_COLS / 4) / NTHR;   // float4 per thread per chunk
   static constexpr int NBA = IS_SA ? 1 : 3;                  // neighbours of the first row source
+  static constexpr int TR = SM_TAIL_ROWS / NW;               // T-loader values per thread
 
   const MlpDesc& d;
   const SaSrc& sa;
@@ -336,15 +351,42 @@ struct Chain {
   int bi, col0, cols_total, tid, lane, wave;
 
   // chunk kinds: [0, nA) P-gather from source A; [nA, nAB) P-gather from source B (FP unknown);
-  // the rest generic
+  // the rest generic (GEN) or one T-loader tail of tail_w channels (!GEN)
   int nA, nAB, n_chunks;
+  int tail_w;
+
+  __device__ __forceinline__ void t_issue(TStage<NW>& st, int tid) const {
+    const int lc = tid & 63, r0 = tid >> 6;
+    const bool cvalid = col0 + lc < cols_total;
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int r = r0 + NW * i;
+      float v = 0.f;
+      if (cvalid && r < tail_w) {
+        if (IS_SA) v = sa.xyz[((size_t)bi * sa.n + ci.id[lc]) * 3 + r];
+        else v = fp.unknown.tab[((size_t)bi * fp.unknown.rows + col0 + lc) * fp.unknown.ld + (nAB - nA) * SM_KC + r];
+      }
+      st.v[i] = v;
+    }
+  }
+  __device__ __forceinline__ void t_commit(const TStage<NW>& st, float* __restrict__ cbuf, int tid) const {
+    const int lc = tid & 63, r0 = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      const int r = r0 + NW * i;
+      float v = st.v[i];
+      if (IS_SA) v = (col0 + lc < cols_total && r < tail_w) ? v - ci.aux[r * 64 + lc] : 0.f;   // grouped_xyz -= new_xyz
+      c_store(cbuf, r, lc, v);
+    }
+  }
 
   __device__ __forceinline__ const RowSrc& srcA() const { return IS_SA ? sa.feat : fp.known; }
 
   // tile0: first row tile of this wave (tiles tile0, tile0 + NW, ...); CS: the wave owns only
   // column tile `ct` of row tile tile0 (layers with <= NW/2 row tiles, see run())
   template <int NTC, bool CS>
-  __device__ __forceinline__ void layer0(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int tile0, int ct) {
+  __device__ __forceinline__ void layer0(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int tile0, int ct,
+                                         int tid, int lane) {
     float2 ring[SM_CP][NTC > 0 ? NTC : 1];
 #pragma unroll
     for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
@@ -363,10 +405,14 @@ struct Chain {
       PStage<1, PIT> st;
       p_issue<1, PIT, NTHR>(st, fp.unknown, bi, 0, nullptr, col0, id_max, tid);
       p_commit<1, PIT, NTHR>(st, chunk, ci.aux, tid);
-    } else {
+    } else if (GEN) {
 #pragma unroll
       for (int i = 0; i < LROWS; ++i)
         c_store(chunk, lr0 + NW * i, lc, c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, lr0 + NW * i));
+    } else {
+      TStage<NW> st;
+      t_issue(st, tid);
+      t_commit(st, chunk, tid);
     }
     __syncthreads();
 #pragma unroll
@@ -380,42 +426,50 @@ struct Chain {
     for (; g < nA; ++g) {
       PStage<NBA, PIT> st;
       p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
-      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
-      p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.w, tid);
+      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct);
+      p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_CW, ci.w, tid);
       __syncthreads();
     }
     if (!IS_SA) {
       for (; g < nAB; ++g) {
         PStage<1, PIT> st;
         p_issue<1, PIT, NTHR>(st, fp.unknown, bi, (g - nA) * SM_KC, nullptr, col0, id_max, tid);
-        span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
-        p_commit<1, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_COLS, ci.aux, tid);
+        span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct);
+        p_commit<1, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_CW, ci.aux, tid);
         __syncthreads();
       }
     }
-    for (; g < n_chunks; ++g) {
-      float stage[LROWS];
+    if (GEN) {
+      for (; g < n_chunks; ++g) {
+        float stage[LROWS];
 #pragma unroll
-      for (int i = 0; i < LROWS; ++i)
-        stage[i] = c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, g * SM_KC + lr0 + NW * i);
-      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS, col, ct);
+        for (int i = 0; i < LROWS; ++i)
+          stage[i] = c_load<IS_SA>(sa, fp, ci, bi, lc, gcol, cvalid, g * SM_KC + lr0 + NW * i);
+        span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct);
 #pragma unroll
-      for (int i = 0; i < LROWS; ++i) c_store(chunk + (g & 1) * SM_KC * SM_COLS, lr0 + NW * i, lc, stage[i]);
+        for (int i = 0; i < LROWS; ++i) c_store(chunk + (g & 1) * SM_KC * SM_CW, lr0 + NW * i, lc, stage[i]);
+        __syncthreads();
+      }
+    } else if (g < n_chunks) {          // the T-loader tail (always the last chunk)
+      TStage<NW> st;
+      t_issue(st, tid);
+      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct);
+      t_commit(st, chunk + (g & 1) * SM_KC * SM_CW, tid);
       __syncthreads();
     }
     // ---- last chunk
     const int p0 = (n_chunks - 1) * SM_CP;
     const int np = pairs_total - p0;       // 1..8
-    const float* rows_half = chunk + ((n_chunks - 1) & 1) * SM_KC * SM_COLS + half * SM_COLS;
+    const float* rows_half = chunk + ((n_chunks - 1) & 1) * SM_KC * SM_CW + half * SM_CW;
     if (np == SM_CP)
       span8<NTC, NT, true, CS>(acc, ring, w, p0, rows_half, col, ct);
-    else
-      span_tail<NTC, NT, true, CS>(acc, ring, np, rows_half, col, ct);
+    else     // the specialised kernels' tail holds <= SM_TAIL_ROWS channels
+      span_tail<NTC, NT, true, CS, (GEN ? SM_CP - 1 : SM_TAIL_ROWS / 4)>(acc, ring, np, rows_half, col, ct);
   }
 
   template <int NTC, bool CS>
   __device__ __forceinline__ void layerN(f32x16 (&acc)[NT][2], const WPtr& w, int pairs_total, int boff, int tile0,
-                                         int ct) {
+                                         int ct, int lane) {
     float2 ring[SM_CP][NTC > 0 ? NTC : 1];
 #pragma unroll
     for (int u = 0; u < SM_CP; ++u) ring_load<NTC>(ring[u], w, u);
@@ -437,6 +491,12 @@ struct Chain {
     int boff = 0;
     SM_STAMP(0);
     for (int l = 0; l < d.n_layers; ++l) {
+      // Per-layer opaque copy of the thread id: every LDS / global address of the layer is derived from
+      // it, so none of that arithmetic can be hoisted out of the layer loop and kept alive (or spilled)
+      // across the other layers' MFMA loops; recomputing it costs a few dozen VALU per layer.
+      int tid = this->tid;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63;
       const int K = d.K[l], M = d.M[l];
       const int mt_total = (M + 31) >> 5;
       // Column split: a non-final layer with <= NW/2 row tiles would leave half of the waves
@@ -456,16 +516,16 @@ struct Chain {
       w.last = pairs_total - 1;
       if (l == 0) {
         if (cs) {
-          if (nt) layer0<1, true>(acc, w, pairs_total, tile0, ct);
-          else layer0<0, false>(acc, w, pairs_total, tile0, ct);
-        } else if (nt >= NT) layer0<NT, false>(acc, w, pairs_total, tile0, ct);
-        else if (NT > 1 && nt == NT - 1) layer0<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, tile0, ct);
-        else layer0<0, false>(acc, w, pairs_total, tile0, ct);
+          if (nt) layer0<1, true>(acc, w, pairs_total, tile0, ct, tid, lane);
+          else layer0<0, false>(acc, w, pairs_total, tile0, ct, tid, lane);
+        } else if (nt >= NT) layer0<NT, false>(acc, w, pairs_total, tile0, ct, tid, lane);
+        else if (NT > 1 && nt == NT - 1) layer0<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, tile0, ct, tid, lane);
+        else layer0<0, false>(acc, w, pairs_total, tile0, ct, tid, lane);
       } else {
         if (cs) {
-          if (nt) layerN<1, true>(acc, w, pairs_total, boff, tile0, ct);
-        } else if (nt >= NT) layerN<NT, false>(acc, w, pairs_total, boff, tile0, ct);
-        else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, boff, tile0, ct);
+          if (nt) layerN<1, true>(acc, w, pairs_total, boff, tile0, ct, lane);
+        } else if (nt >= NT) layerN<NT, false>(acc, w, pairs_total, boff, tile0, ct, lane);
+        else if (NT > 1 && nt == NT - 1) layerN<(NT > 1 ? NT - 1 : 0), false>(acc, w, pairs_total, boff, tile0, ct, lane);
       }
       __syncthreads();   // every wave has finished reading this layer's input
       SM_STAMP(1 + 2 * l);
@@ -502,6 +562,9 @@ struct Chain {
     }
 
     // ---- epilogue on the last layer's accumulators
+    int tid = this->tid;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int L = d.n_layers - 1;
     const int M = d.M[L];
     const int mt_total = (M + 31) >> 5;
@@ -618,13 +681,13 @@ __device__ __forceinline__ bool row_src_vec_ok(const RowSrc& s) {
   return s.tab != nullptr && (s.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(s.tab) & 15) == 0;
 }
 
-template <bool IS_SA, int NT, int NW>
+template <bool IS_SA, int NT, int NW, bool GEN>
 __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int hrows,
                                                int bias_all, int cols_total, const OutDesc& od) {
   extern __shared__ float s_mem[];
   float* H = s_mem;
-  float* chunk = H + (size_t)hrows * SM_COLS;
-  float* s_bias = chunk + 2 * SM_KC * SM_COLS;
+  float* chunk = H;                                   // overlaid (hrows * 64 >= 2 * SM_KC * SM_CW, launch_chain)
+  float* s_bias = H + (size_t)hrows * SM_COLS;
   ColInfo ci;
   ci.id = reinterpret_cast<int*>(s_bias + bias_all);
   ci.w = reinterpret_cast<float*>(ci.id + 3 * 64);
@@ -668,42 +731,58 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
   }
   __syncthreads();
 
-  Chain<IS_SA, NT, NW> ch{d, sa, fp, H, chunk, s_bias, ci, bi, col0, cols_total, tid, lane, wave, 0, 0, 0};
+  Chain<IS_SA, NT, NW, GEN> ch{d, sa, fp, H, chunk, s_bias, ci, bi, col0, cols_total, tid, lane, wave, 0, 0, 0, 0};
   ch.n_chunks = (d.K[0] + SM_KC - 1) / SM_KC;
   if (IS_SA) {
     ch.nA = row_src_vec_ok(sa.feat) ? sa.feat.width / SM_KC : 0;
     ch.nAB = ch.nA;
+    ch.tail_w = sa.use_xyz ? 3 : 0;
   } else {
     ch.nA = row_src_vec_ok(fp.known) ? fp.known.width / SM_KC : 0;
     ch.nAB = ch.nA;
     if (ch.nA * SM_KC == fp.known.width && row_src_vec_ok(fp.unknown))
       ch.nAB = ch.nA + fp.unknown.width / SM_KC;
+    ch.tail_w = fp.unknown.width - (ch.nAB - ch.nA) * SM_KC;
   }
   ch.run(od);
 }
 
-template <bool IS_SA, int NW>
-#ifndef SM_NW4_WAVES
-#define SM_NW4_WAVES 3
-#endif
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? (IS_SA ? 4 : 2) : SM_NW4_WAVES)) void mlp_chain_kernel(
+// host mirror of the device-side chunk classification: can the specialised (GEN = false) kernels
+// serve this layer-0 input?
+bool host_vec_ok(const RowSrc& s) {
+  return s.tab != nullptr && (s.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(s.tab) & 15) == 0;
+}
+template <bool IS_SA>
+bool specialised_ok(const SaSrc& sa, const FpSrc& fp) {
+  if (IS_SA) return sa.feat.width % SM_KC == 0 && (sa.feat.width == 0 || host_vec_ok(sa.feat));
+  if (fp.known.width % SM_KC != 0 || !host_vec_ok(fp.known)) return false;
+  const int full = fp.unknown.width / SM_KC, rest = fp.unknown.width % SM_KC;
+  // (a strided unknown table with >= 32 channels falls to the generic kernel: the device would
+  // classify its whole chunks as generic too)
+  return rest <= SM_TAIL_ROWS && (full == 0 || host_vec_ok(fp.unknown));
+}
+
+// One row tile per wave, 4 waves (M <= 128).  (The generic-loader variant is allowed the registers of
+// two waves per SIMD: with three it spills.)
+template <bool IS_SA, bool GEN>
+__global__ __launch_bounds__(256, (GEN ? 2 : 3)) void mlp_chain_kernel(
     MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
-  mlp_chain_body<IS_SA, 1, NW>(d, sa, fp, hrows, bias_all, cols_total, od);
+  mlp_chain_body<IS_SA, 1, 4, GEN>(d, sa, fp, hrows, bias_all, cols_total, od);
 }
 
 // Two row tiles per wave, 4 waves (128 < M <= 256): every wave owns a tile of a 128-wide layer,
-// where the 8-wave kernel above leaves half of its waves without MFMA work.
-template <bool IS_SA>
+// where an 8-wave workgroup would leave half of its waves without MFMA work.
+template <bool IS_SA, bool GEN>
 __global__ __launch_bounds__(256, 2) void mlp_chain_mid_kernel(
     MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
-  mlp_chain_body<IS_SA, 2, 4>(d, sa, fp, hrows, bias_all, cols_total, od);
+  mlp_chain_body<IS_SA, 2, 4, GEN>(d, sa, fp, hrows, bias_all, cols_total, od);
 }
 
-// Two row tiles per wave (M > 256).
-template <bool IS_SA>
-__global__ __launch_bounds__(512) void mlp_chain_wide_kernel(
+// Two row tiles per wave, 8 waves (M > 256).
+template <bool IS_SA, bool GEN>
+__global__ __launch_bounds__(512, 2) void mlp_chain_wide_kernel(
     MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_all, int cols_total, OutDesc od) {
-  mlp_chain_body<IS_SA, 2, 8>(d, sa, fp, hrows, bias_all, cols_total, od);
+  mlp_chain_body<IS_SA, 2, 8, GEN>(d, sa, fp, hrows, bias_all, cols_total, od);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -955,55 +1034,48 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
   }
   if (max_mt > SM_MAX_MT) return (int)hipErrorInvalidValue;
   const bool ns_ok = !IS_SA || sa.ns <= 32;
-  const int hrows_in = hrows;
   // Measured (MI355X, 64 frames): the column-sliced kernel wins for M <= 64 (level 0) and
   // loses for M = 128 with K >= 99 (every wave re-fetches all weight fragments), so it is
   // used for <= 2 row tiles only.
-  static const int cols_max_mt = [] {
-    const char* e = getenv("PVN3D_MLP_COLS_MAX_MT");     // tuning override
-    return e ? atoi(e) : 2;
-  }();
-  if (max_mt <= cols_max_mt && max_mt <= 4 && ns_ok) {   // narrow chain: column-sliced kernel
+  if (max_mt <= 2 && ns_ok) {   // narrow chain: column-sliced kernel
     const size_t lds2 = ((size_t)2 * (hrows + SM_KC) * 32 + bias_all) * sizeof(float);
+    if (lds2 > 160 * 1024) return (int)hipErrorInvalidValue;
     const dim3 grid2(pvn3d_ceil_div(cols_total, 64), b);
-#define SM_LAUNCH_COLS(NTR)                                                                    \
-  do {                                                                                         \
-    auto kern = mlp_chain_cols_kernel<IS_SA, NTR>;                                             \
-    if (lds2 > 48 * 1024)                                                                      \
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                              (int)lds2));                                     \
-    hipLaunchKernelGGL(kern, grid2, dim3(128), lds2, st, d, sa, fp, hrows, bias_all, cols_total, od); \
-  } while (0)
-    if (max_mt <= 1) SM_LAUNCH_COLS(1); else if (max_mt <= 2) SM_LAUNCH_COLS(2); else SM_LAUNCH_COLS(4);
-#undef SM_LAUNCH_COLS
+    if (max_mt <= 1) {
+      PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_cols_kernel<IS_SA, 1>));
+      hipLaunchKernelGGL((mlp_chain_cols_kernel<IS_SA, 1>), grid2, dim3(128), lds2, st, d, sa, fp, hrows, bias_all,
+                         cols_total, od);
+    } else {
+      PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_cols_kernel<IS_SA, 2>));
+      hipLaunchKernelGGL((mlp_chain_cols_kernel<IS_SA, 2>), grid2, dim3(128), lds2, st, d, sa, fp, hrows, bias_all,
+                         cols_total, od);
+    }
     PVN3D_LAUNCH_CHECK();
     return 0;
   }
   const dim3 grid(pvn3d_ceil_div(cols_total, SM_COLS), b);
-#define SM_LAUNCH(KERN, NW)                                                                      \
-  do {                                                                                         \
-    auto kern = KERN;                                                                          \
-    /* SA epilogue: NW wave-private [32][SM_EPAD] patches overlay H | chunk */                 \
-    if (IS_SA) hrows = max(hrows_in, pvn3d_ceil_div(NW * 32 * SM_EPAD - 2 * SM_KC * SM_COLS, SM_COLS)); \
-    const size_t lds = ((size_t)hrows * SM_COLS + 2 * SM_KC * SM_COLS + bias_all + 9 * 64) * sizeof(float); \
-    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                                    \
-    if (lds > 48 * 1024)                                                                       \
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                              (int)lds));                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, d, sa, fp, hrows, bias_all, cols_total, od); \
+  const bool spec = specialised_ok<IS_SA>(sa, fp);
+  // H is overlaid with the two layer-0 chunk buffers and, in the SA epilogue, with NW wave-private
+  // [32][SM_EPAD] max-pool patches
+#define SM_LAUNCH(KERN, NW)                                                                                   \
+  do {                                                                                                        \
+    int hr = max(hrows, pvn3d_ceil_div(2 * SM_KC * SM_CW, SM_COLS)); \
+    if (IS_SA) hr = max(hr, pvn3d_ceil_div(NW * 32 * SM_EPAD, SM_COLS));                                      \
+    const size_t lds = ((size_t)hr * SM_COLS + bias_all + 9 * 64) * sizeof(float);                            \
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                                                   \
+    if (spec) {                                                                                               \
+      PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(KERN<IS_SA, false>));                                     \
+      hipLaunchKernelGGL((KERN<IS_SA, false>), grid, dim3(NW * 64), lds, st, d, sa, fp, hr, bias_all, cols_total, od); \
+    } else {                                                                                                  \
+      PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(KERN<IS_SA, true>));                                      \
+      hipLaunchKernelGGL((KERN<IS_SA, true>), grid, dim3(NW * 64), lds, st, d, sa, fp, hr, bias_all, cols_total, od); \
+    }                                                                                                         \
   } while (0)
-  // wide layers: 8 waves (two per SIMD hide each other's L2 / LDS waits), <= 2 row tiles each;
-  // narrow layers (<= 4 row tiles): 4 waves, one row tile each
-  static const int mid_kernel = [] {
-    const char* e = getenv("PVN3D_MLP_MID");             // tuning override: 0 = 8-wave kernel
-    return e ? atoi(e) : 1;
-  }();
-  if (max_mt <= 4) SM_LAUNCH((mlp_chain_kernel<IS_SA, 4>), 4);
-  else if (max_mt <= 8 && mid_kernel) SM_LAUNCH((mlp_chain_mid_kernel<IS_SA>), 4);
-  else if (max_mt <= 8) SM_LAUNCH((mlp_chain_kernel<IS_SA, 8>), 8);
-  else SM_LAUNCH((mlp_chain_wide_kernel<IS_SA>), 8);
+  // <= 4 row tiles: 4 waves, one row tile each; <= 8: 4 waves, two row tiles each; wider: 8 waves
+  // (two per SIMD hide each other's L2 / LDS waits), two row tiles each
+  if (max_mt <= 4) SM_LAUNCH(mlp_chain_kernel, 4);
+  else if (max_mt <= 8) SM_LAUNCH(mlp_chain_mid_kernel, 4);
+  else SM_LAUNCH(mlp_chain_wide_kernel, 8);
 #undef SM_LAUNCH
   PVN3D_LAUNCH_CHECK();
   return 0;

@@ -17,7 +17,6 @@
 //          volumetric clouds) the lane falls back to scanning all m points.  Aliased far cells of
 //          the toroidal table only add candidates.
 // Scratch is passed in by the caller; m <= 2048 (the sorted cloud must fit in LDS).
-#include <cstdlib>
 
 #include "common.h"
 
@@ -262,29 +261,21 @@ extern "C" int pvn3d_three_nn_grid(int b, int n, int m, const float* unknown, co
   hipStream_t st = (hipStream_t)stream;
   NgWs ws;
   ng_layout(b, m, (char*)workspace, &ws);
-  static const float h_scale = [] {       // cell size in units of the estimated point spacing (tuning)
-    const char* e = getenv("PVN3D_NN_H");
-    const float v = e ? (float)atof(e) : 0.f;
-    return v > 0.1f ? v : 1.6f;     // measured 1.2 / 1.5 / 1.8 / 2.2 / 2.8 -> 0.63 / 0.38 / 0.39 / 0.43 / 0.49 ms per 64-frame step
-  }();
+  // cell size in units of the estimated point spacing; measured 1.2 / 1.5 / 1.8 / 2.2 / 2.8 ->
+  // 0.63 / 0.38 / 0.39 / 0.43 / 0.49 ms per 64-frame step
+  const float h_scale = 1.6f;
   hipLaunchKernelGGL(nn_grid_build_kernel, dim3(b), dim3(1024), 0, st, m, h_scale, known, ws.cell_start,
                      ws.sorted, ws.hinfo);
   PVN3D_LAUNCH_CHECK();
   const size_t lds = (size_t)m * sizeof(float4) + (NG_T + 1) * sizeof(int);
   if (n >= 4096) {
-    auto kern = three_nn_grid_kernel<4>;
-    if (lds > 48 * 1024)
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(pvn3d_ceil_div(n, 1024), b), dim3(256), lds, st, n, m, unknown, ws.cell_start,
-                       ws.sorted, ws.hinfo, dist2, idx);
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_nn_grid_kernel<4>));
+    hipLaunchKernelGGL(three_nn_grid_kernel<4>, dim3(pvn3d_ceil_div(n, 1024), b), dim3(256), lds, st, n, m, unknown,
+                       ws.cell_start, ws.sorted, ws.hinfo, dist2, idx);
   } else {
-    auto kern = three_nn_grid_kernel<1>;
-    if (lds > 48 * 1024)
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(pvn3d_ceil_div(n, 256), b), dim3(256), lds, st, n, m, unknown, ws.cell_start,
-                       ws.sorted, ws.hinfo, dist2, idx);
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_nn_grid_kernel<1>));
+    hipLaunchKernelGGL(three_nn_grid_kernel<1>, dim3(pvn3d_ceil_div(n, 256), b), dim3(256), lds, st, n, m, unknown,
+                       ws.cell_start, ws.sorted, ws.hinfo, dist2, idx);
   }
   PVN3D_LAUNCH_CHECK();
   return 0;

@@ -33,22 +33,23 @@ def _poll_buf():
 
 
 MS_ALIGNED32 = 1    # include/pvn3d_hip.h PVN3D_MS_ALIGNED32
-MS_USE_MFMA = 4     # PVN3D_MS_USE_MFMA (experimental kernel, opt-in)
+MS_FORCE_SCALAR = 4  # PVN3D_MS_FORCE_SCALAR: one seed per lane
+MS_FORCE_PACKED = 8  # PVN3D_MS_FORCE_PACKED: two seeds per lane (packed fp32 math)
 
 
 def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300, labels=None,
-                        poll_every=8, aligned32=False):
+                        poll_every=8, aligned32=False, kernel=None):
     """Batched MeanShiftTorch.fit.
 
     pts4 (total,4) float32 cuda; seg_off/seg_cnt (n_seg) int32 cuda; max_cnt: host bound on
     seg_cnt.  Returns ctr (n_seg,3) float32, labels (total) uint8, iters (n_seg) int32.
     poll_every = 0 -> fully asynchronous (enqueues max_iter+1 iterations).
-    aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows
-    (layout promise needed by the opt-in MFMA-assisted kernel, env PVN3D_MS_MFMA=1).
+    aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows.
+    kernel: None (library default), "scalar" or "packed" -- pins the iteration kernel (identical results).
     """
     flags = MS_ALIGNED32 if aligned32 else 0
-    if aligned32 and os.environ.get("PVN3D_MS_MFMA", "0") == "1":
-        flags |= MS_USE_MFMA
+    if kernel is not None:
+        flags |= {"scalar": MS_FORCE_SCALAR, "packed": MS_FORCE_PACKED}[kernel]
     dev = pts4.device
     assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
     n_seg = int(seg_off.numel())

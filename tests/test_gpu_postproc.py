@@ -188,21 +188,54 @@ def test_batch_of_frames_equals_per_frame_and_threadpool(dev):
     assert len(out) == 4 and np.array_equal(out[2][0], poses_b[2])
 
 
-def test_mfma_assisted_kernel_matches_valu_and_is_deterministic(dev, monkeypatch):
-    """Opt-in MFMA-assisted iteration kernel (PVN3D_MS_MFMA=1): same centres within tolerance as
-    the default VALU kernel, bit-identical across repeated batched runs."""
-    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
-    fr = [synth.synth_frame(frame=30 + i, n_pts=2048, n_obj=400 + 100 * i) for i in range(4)]
-    st = lambda k: torch.stack([T(f[k], dev) for f in fr], 0)
-    args = (st("pcld"), st("mask"), st("ctr_of"), st("pred_kp_of"), True, 2, False, 1)
-    base = ev.cal_batch_poses_lm(*args)
-    monkeypatch.setenv("PVN3D_MS_MFMA", "1")
-    a = ev.cal_batch_poses_lm(*args)
-    b = ev.cal_batch_poses_lm(*args)
-    assert torch.equal(a["cls_kps"], b["cls_kps"]) and torch.equal(a["iters"], b["iters"])
-    assert (a["cls_kps"] - base["cls_kps"]).abs().max().item() < TOL
-    assert (a["iters"] - base["iters"]).abs().max().item() <= 1
-    assert (a["poses"] - base["poses"]).abs().max().item() < TOL
+def test_packed_and_scalar_iteration_kernels_are_bit_identical(dev):
+    """Two seeds per lane (v_pk_fma_f32) vs one: the same per-seed fp32 operation sequence, so the
+    centres, labels and iteration counts are identical bits, on tight and on heavy-tailed votes."""
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    rng = np.random.default_rng(3)
+    segs, off = [], [0]
+    for n, out_frac, sig_out in ((700, 0.1, 0.05), (2048, 0.3, 0.3), (1500, 0.0, 0.0), (33, 0.1, 0.05), (3072, 0.1, 0.3)):
+        a = rng.normal(size=(n, 3)) * 0.005 + np.array([0.1, -0.05, 0.9])
+        k = int(n * out_frac)
+        if k:
+            a[rng.permutation(n)[:k]] += rng.normal(size=(k, 3)) * sig_out
+        segs.append(a.astype(np.float32))
+        off.append(off[-1] + (n + 31) // 32 * 32)
+    pts4 = np.zeros((off[-1], 4), np.float32)
+    for a, o in zip(segs, off):
+        pts4[o:o + len(a), :3] = a
+    P = T(pts4, dev)
+    so = torch.tensor(off[:-1], dtype=torch.int32, device=dev)
+    sc = torch.tensor([len(a) for a in segs], dtype=torch.int32, device=dev)
+    outs = {}
+    for kern in ("scalar", "packed"):
+        c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern)
+        l = l.cpu().numpy()
+        valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)])     # rows past a segment's count are scratch
+        outs[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
+    for x, y in zip(outs["scalar"], outs["packed"]):
+        assert np.array_equal(x, y)
+    assert outs["packed"][2].max() > 20       # the heavy-tailed fits really iterate
+
+
+def test_stress_all_points_on_object_vs_oracle(dev, orc):
+    """BASELINE's 'N = 12 288' clustering size: every point of the cloud votes (n_obj = 12 288).
+    One centre fit + one keypoint fit against the C oracle (the full 9 fits take the oracle minutes)."""
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    f = synth.synth_frame(frame=3, n_pts=12288, n_obj=12288)
+    votes = [f["pcld"] - f["ctr_of"][0], f["pcld"] - f["pred_kp_of"][2]]
+    pts4 = np.zeros((2 * 12288, 4), np.float32)
+    for i, v in enumerate(votes):
+        pts4[i * 12288:(i + 1) * 12288, :3] = v
+    so = torch.tensor([0, 12288], dtype=torch.int32, device=dev)
+    sc = torch.tensor([12288, 12288], dtype=torch.int32, device=dev)
+    c, l, it = eng.meanshift_fit_batch(T(pts4, dev), so, sc, 12288, 0.08, 300)
+    c, l, it = c.cpu().numpy(), l.cpu().numpy().reshape(2, 12288), it.cpu().numpy()
+    for i, v in enumerate(votes):
+        oc, ol, oit = orc.meanshift_fit(v, 0.08, 300)
+        assert np.abs(c[i] - oc).max() < TOL
+        assert abs(int(it[i]) - oit) <= 1
+        assert np.array_equal(l[i].astype(bool), ol)
 
 
 @pytest.mark.gpu

@@ -171,3 +171,35 @@ def test_focal_loss_matches_reference_formula():
     assert logits.grad is not None and torch.isfinite(logits.grad).all()
     s = FocalLoss(gamma=0, size_average=False)(flat.detach(), target.reshape(-1))
     assert torch.allclose(s, torch.nn.functional.cross_entropy(flat.detach(), target.reshape(-1), reduction="sum"))
+
+
+def test_obj_kps_fixture_equals_reference_text_files():
+    """pvn3d_amd/data/obj_kps.npz (tools/import_obj_kps.py) against the reference's own keypoint text
+    files, array by array (where /root/reference exists), and against a pinned digest everywhere."""
+    import hashlib
+    import os
+    from pvn3d_amd import synth
+    z = synth.obj_kps()
+    h = hashlib.sha256()
+    for k in sorted(z):
+        if z[k].dtype.kind == "f":
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(z[k]).tobytes())
+    assert h.hexdigest() == OBJ_KPS_SHA256
+    ref = "/root/reference/pvn3d/datasets"
+    if not os.path.isdir(ref):
+        return
+    n = 0
+    for k in z:
+        parts = k.split("/")
+        if len(parts) != 3:
+            continue
+        d = {"lm": "linemod/lm_obj_kps", "ycb": "ycb/ycb_object_kps"}[parts[0]]
+        want = np.loadtxt(os.path.join(ref, d, parts[1], parts[2] + ".txt"), dtype=np.float32)
+        assert np.array_equal(z[k], want), k
+        n += 1
+    assert n == 2 * (13 + 21)
+    assert np.array_equal(z["ycb_radius"], np.loadtxt(os.path.join(ref, "ycb/dataset_config/radius.txt")))
+
+
+OBJ_KPS_SHA256 = "56bb1a533c1996126af150ad758d015a3e6a8379355d8acea3cae391dd9699bb"
