@@ -50,17 +50,35 @@
 #include "common.h"
 
 #ifdef SM_PROBE
-// cycle stamps per phase of the first workgroups of a launch (tuning builds only, tools/mlp_probe.py)
-__device__ unsigned long long g_sm_probe[64 * 16];
+// tuning builds only (tools/build_probe_lib.sh, tools/mlp_probe.py): cycles spent between consecutive
+// stamps, summed over ALL workgroups of a launch (wave 0's view); slot 16+i counts the visits of stamp i
+// (1024 independent slot sets indexed by workgroup id: atomics on ONE word serialise at ~11 ns each and
+// the in-order vmcnt makes every later load of the stamping wave wait for them)
+__device__ unsigned long long g_sm_probe[1024 * 32];
+#define SM_PROBE_DECL unsigned long long sm_last_ = __builtin_readcyclecounter()
 #define SM_STAMP(i)                                                                  \
   do {                                                                               \
-    if (tid == 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < 64)                 \
-      g_sm_probe[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = __builtin_readcyclecounter(); \
+    if (threadIdx.x == 0) {                                                          \
+      const unsigned long long now_ = __builtin_readcyclecounter();                  \
+      unsigned long long* slot_ = g_sm_probe + 32 * ((blockIdx.x + gridDim.x * blockIdx.y) & 1023u); \
+      atomicAdd(slot_ + (i), now_ - sm_last_);                                       \
+      atomicAdd(slot_ + 16 + (i), 1ull);                                             \
+      sm_last_ = now_;                                                               \
+    }                                                                                \
   } while (0)
-extern "C" int pvn3d_debug_mlp_probe_read(unsigned long long* host64x16) {
-  return (int)hipMemcpyFromSymbol(host64x16, HIP_SYMBOL(g_sm_probe), sizeof(unsigned long long) * 64 * 16);
+extern "C" int pvn3d_debug_mlp_probe_read(unsigned long long* host32) {
+  static unsigned long long all[1024 * 32];
+  hipError_t e = hipMemcpyFromSymbol(all, HIP_SYMBOL(g_sm_probe), sizeof(all));
+  if (e != hipSuccess) return (int)e;
+  for (int i = 0; i < 32; ++i) {
+    host32[i] = 0;
+    for (int s = 0; s < 1024; ++s) host32[i] += all[s * 32 + i];
+  }
+  for (int i = 0; i < 1024 * 32; ++i) all[i] = 0;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sm_probe), all, sizeof(all));
 }
 #else
+#define SM_PROBE_DECL do { } while (0)
 #define SM_STAMP(i) do { } while (0)
 #endif
 
@@ -75,6 +93,7 @@ constexpr int SM_MAX_LAYERS = 4;
 constexpr int SM_MAX_MT = 16;        // M <= 512
 constexpr int SM_EPAD = 68;          // row stride of the max-pool patch (16-byte aligned, conflict-free)
 constexpr int SM_CW = 96;            // row stride of a layer-0 chunk buffer: 64 columns + room for the rotation
+constexpr int SM_NUM_CU = 256;       // MI355X; only used to guess which workgroups start in a CU's 2nd / 3rd slot
 constexpr int SM_TAIL_ROWS = 8;      // widest layer-0 tail the specialised (GEN = false) kernels take
 
 struct MlpDesc {
@@ -83,6 +102,11 @@ struct MlpDesc {
   int M[SM_MAX_LAYERS];              // true output width
   const float* W[SM_MAX_LAYERS];     // packed [ceil(K/4)][ceil(M/32)][64][2]
   const float* bias[SM_MAX_LAYERS];  // [ceil(M/32)*32], zero padded
+  // start-up stagger (set by launch_chain): the workgroups that fill resident slot s > 0 of a CU at the
+  // start of the launch wait s * stagger cycles first.  All workgroups do identical work, so co-resident
+  // ones otherwise run in lock-step -- in their MFMA-free prologue / hand-over / epilogue phases at the
+  // same time -- and the offset, once made, persists through the launch (slots refill as they finish).
+  int wgs_per_cu, stagger;
 };
 
 struct RowSrc {       // point-major table: row r of frame b is tab[((size_t)b * rows + r) * ld ...]
@@ -138,12 +162,31 @@ __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ 
   }
 }
 
-// all biases of the chain -> LDS (layer l at offset sum_{i<l} roundup32(M_i)); caller syncs
-__device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__ sb, int tid, int nthreads) {
+// all biases of the chain -> LDS (layer l at offset sum_{i<l} roundup32(M_i)); caller syncs.
+// Every load is issued before the first store: one global round trip for the whole chain instead of
+// one per layer (under load a round trip is several thousand cycles of a workgroup's prologue).
+template <int NTHREADS>
+__device__ __forceinline__ void stage_bias(const MlpDesc& d, float* __restrict__ sb, int tid) {
+  constexpr int J = (SM_MAX_MT * 32 + NTHREADS - 1) / NTHREADS;
+  float v[SM_MAX_LAYERS][J];
+#pragma unroll
+  for (int l = 0; l < SM_MAX_LAYERS; ++l) {
+    const int mp = l < d.n_layers ? ((d.M[l] + 31) >> 5) << 5 : 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = tid + j * NTHREADS;
+      v[l][j] = i < mp ? d.bias[l][i] : 0.f;
+    }
+  }
   int off = 0;
-  for (int l = 0; l < d.n_layers; ++l) {
-    const int mp = ((d.M[l] + 31) >> 5) << 5;
-    for (int i = tid; i < mp; i += nthreads) sb[off + i] = d.bias[l][i];
+#pragma unroll
+  for (int l = 0; l < SM_MAX_LAYERS; ++l) {
+    const int mp = l < d.n_layers ? ((d.M[l] + 31) >> 5) << 5 : 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = tid + j * NTHREADS;
+      if (i < mp) sb[off + i] = v[l][j];
+    }
     off += mp;
   }
 }
@@ -354,6 +397,9 @@ struct Chain {
   // the rest generic (GEN) or one T-loader tail of tail_w channels (!GEN)
   int nA, nAB, n_chunks;
   int tail_w;
+#ifdef SM_PROBE
+  unsigned long long sm_last_;
+#endif
 
   __device__ __forceinline__ void t_issue(TStage<NW>& st, int tid) const {
     const int lc = tid & 63, r0 = tid >> 6;
@@ -396,11 +442,14 @@ struct Chain {
     const int half = lane >> 5, col = lane & 31;
     const int id_max = IS_SA ? 0 : fp.n - 1;
 
-    // ---- prologue: chunk 0
+    // ---- prologue: chunk 0 (and, from the first row source, chunk 1: its gathers are kept TWO chunks
+    // ahead of the MFMAs -- under load a gather takes 5-6 k cycles (tools/mlp_probe.py) while a chunk of the
+    // narrow layers is multiplied in 1-4 k, so one chunk of cover left the layer-0 loop latency-bound)
+    PStage<NBA, PIT> sA0, sA1;
     if (nA > 0) {
-      PStage<NBA, PIT> st;
-      p_issue<NBA, PIT, NTHR>(st, srcA(), bi, 0, ci.id, col0, id_max, tid);
-      p_commit<NBA, PIT, NTHR>(st, chunk, ci.w, tid);
+      p_issue<NBA, PIT, NTHR>(sA0, srcA(), bi, 0, ci.id, col0, id_max, tid);
+      if (nA > 1) p_issue<NBA, PIT, NTHR>(sA1, srcA(), bi, SM_KC, ci.id, col0, id_max, tid);
+      p_commit<NBA, PIT, NTHR>(sA0, chunk, ci.w, tid);
     } else if (nAB > 0) {
       PStage<1, PIT> st;
       p_issue<1, PIT, NTHR>(st, fp.unknown, bi, 0, nullptr, col0, id_max, tid);
@@ -415,21 +464,46 @@ struct Chain {
       t_commit(st, chunk, tid);
     }
     __syncthreads();
+    SM_STAMP(7);
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
       acc_bias(acc[t][0], s_bias + (tile0 + NW * t) * 32, half);
       if (!CS) acc[t][1] = acc[t][0];
     }
 
-    // ---- steady state: gather chunk g while chunk g-1 is multiplied
+    // ---- steady state: chunk g-1 is multiplied while chunk g lands and chunk g+1 is requested.
+    // Invariant at every step: chunks < g are staged, chunk g (if g < nA) is in flight in sA1 / sA0
+    // alternately.  Unrolled by two so that the two register stages are addressed statically and every
+    // load of the loop body is unconditional (the compiler then counts vmcnt exactly).
+#define SM_SPAN_PREV(G) \
+  span8<NTC, NT, true, CS>(acc, ring, w, ((G) - 1) * SM_CP, chunk + (((G) - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct)
     int g = 1;
-    for (; g < nA; ++g) {
-      PStage<NBA, PIT> st;
-      p_issue<NBA, PIT, NTHR>(st, srcA(), bi, g * SM_KC, ci.id, col0, id_max, tid);
-      span8<NTC, NT, true, CS>(acc, ring, w, (g - 1) * SM_CP, chunk + ((g - 1) & 1) * SM_KC * SM_CW + half * SM_CW, col, ct);
-      p_commit<NBA, PIT, NTHR>(st, chunk + (g & 1) * SM_KC * SM_CW, ci.w, tid);
+    for (; g + 2 < nA; g += 2) {
+      p_issue<NBA, PIT, NTHR>(sA0, srcA(), bi, (g + 1) * SM_KC, ci.id, col0, id_max, tid);
+      SM_SPAN_PREV(g);
+      p_commit<NBA, PIT, NTHR>(sA1, chunk + (g & 1) * SM_KC * SM_CW, ci.w, tid);
+      __syncthreads();
+      p_issue<NBA, PIT, NTHR>(sA1, srcA(), bi, (g + 2) * SM_KC, ci.id, col0, id_max, tid);
+      SM_SPAN_PREV(g + 1);
+      p_commit<NBA, PIT, NTHR>(sA0, chunk + ((g + 1) & 1) * SM_KC * SM_CW, ci.w, tid);
       __syncthreads();
     }
+    if (g + 1 < nA) {            // two left: g in flight (sA1), g + 1 still to request
+      p_issue<NBA, PIT, NTHR>(sA0, srcA(), bi, (g + 1) * SM_KC, ci.id, col0, id_max, tid);
+      SM_SPAN_PREV(g);
+      p_commit<NBA, PIT, NTHR>(sA1, chunk + (g & 1) * SM_KC * SM_CW, ci.w, tid);
+      __syncthreads();
+      SM_SPAN_PREV(g + 1);
+      p_commit<NBA, PIT, NTHR>(sA0, chunk + ((g + 1) & 1) * SM_KC * SM_CW, ci.w, tid);
+      __syncthreads();
+      g += 2;
+    } else if (g < nA) {         // one left, in flight (sA1)
+      SM_SPAN_PREV(g);
+      p_commit<NBA, PIT, NTHR>(sA1, chunk + (g & 1) * SM_KC * SM_CW, ci.w, tid);
+      __syncthreads();
+      g += 1;
+    }
+#undef SM_SPAN_PREV
     if (!IS_SA) {
       for (; g < nAB; ++g) {
         PStage<1, PIT> st;
@@ -458,6 +532,7 @@ struct Chain {
       __syncthreads();
     }
     // ---- last chunk
+    SM_STAMP(8);
     const int p0 = (n_chunks - 1) * SM_CP;
     const int np = pairs_total - p0;       // 1..8
     const float* rows_half = chunk + ((n_chunks - 1) & 1) * SM_KC * SM_CW + half * SM_CW;
@@ -699,8 +774,18 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
   xcd_frame_map(bi, bx);
   const int col0 = bx * SM_COLS;
 
+  if (d.wgs_per_cu > 1) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned slot = lin / SM_NUM_CU;
+    if (slot > 0 && slot < (unsigned)d.wgs_per_cu) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      const unsigned long long wait = (unsigned long long)slot * (unsigned)d.stagger;
+      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  SM_PROBE_DECL;
   SM_STAMP(14);
-  stage_bias(d, s_bias, tid, NW * 64);
+  stage_bias<NW * 64>(d, s_bias, tid);
   if (tid < 64) {     // per-column gather info
     const int gcol = col0 + tid;
     const bool cvalid = gcol < cols_total;
@@ -744,7 +829,28 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
       ch.nAB = ch.nA + fp.unknown.width / SM_KC;
     ch.tail_w = fp.unknown.width - (ch.nAB - ch.nA) * SM_KC;
   }
+#ifdef SM_PROBE
+  ch.sm_last_ = sm_last_;
+#endif
   ch.run(od);
+}
+
+// resident workgroups per CU (registers: `by_regs`; LDS) and the start-up stagger between them:
+// a workgroup's life is about wgs_per_cu x (its MFMA issue time per SIMD) x 1.25; co-resident workgroups
+// are spread evenly over it.  No stagger for launches that do not fill every slot several times over.
+void set_stagger(MlpDesc* d, int nw, int by_regs, size_t lds, unsigned n_wg) {
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > by_regs) per_cu = by_regs;
+  if (per_cu < 1) per_cu = 1;
+  d->wgs_per_cu = per_cu;
+  d->stagger = 0;
+  if (per_cu < 2 || n_wg < 4u * SM_NUM_CU * per_cu) { d->wgs_per_cu = 1; return; }
+  double mfma = 0;        // MFMA instructions of the busiest wave
+  for (int l = 0; l < d->n_layers; ++l) {
+    const int mt = (d->M[l] + 31) / 32, tiles = (mt + nw - 1) / nw;
+    mfma += 2.0 * ((d->K[l] + 3) / 4) * tiles * 2;
+  }
+  d->stagger = (int)(64.0 * mfma * 1.25);      // = life / per_cu
 }
 
 // host mirror of the device-side chunk classification: can the specialised (GEN = false) kernels
@@ -845,6 +951,7 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
   int bi, bx;
   xcd_frame_map(bi, bx);
   const int col0 = bx * 64 + wave * 32;
+  SM_PROBE_DECL;
   SM_STAMP(14);
   const int half = lane >> 5, col = lane & 31;
 
@@ -866,7 +973,7 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
     id0 = ip[0]; id1 = ip[1]; id2 = ip[2];
     w0 = wp[0]; w1 = wp[1]; w2 = wp[2];
   }
-  stage_bias(d, s_bias, tid, 128);
+  stage_bias<128>(d, s_bias, tid);
   __syncthreads();                         // the only barrier of this kernel
   if (col0 >= cols_total) return;          // wave-uniform
   SM_STAMP(0);
@@ -1024,8 +1131,11 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
 }
 
 template <bool IS_SA>
-int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
+int launch_chain(const MlpDesc& d_in, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
                  const OutDesc& od, hipStream_t st) {
+  MlpDesc d = d_in;
+  d.wgs_per_cu = 1;
+  d.stagger = 0;
   int hrows = 4, max_mt = 1, bias_all = 0;
   for (int l = 0; l < d.n_layers; ++l) {
     if (l + 1 < d.n_layers) hrows = max(hrows, ((d.M[l] + 31) / 32) * 32);
@@ -1063,6 +1173,7 @@ int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int 
     if (IS_SA) hr = max(hr, pvn3d_ceil_div(NW * 32 * SM_EPAD, SM_COLS));                                      \
     const size_t lds = ((size_t)hr * SM_COLS + bias_all + 9 * 64) * sizeof(float);                            \
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                                                   \
+    set_stagger(&d, NW, NW == 8 ? 1 : (max_mt <= 4 ? 3 : 2), lds, grid.x * grid.y);                           \
     if (spec) {                                                                                               \
       PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(KERN<IS_SA, false>));                                     \
       hipLaunchKernelGGL((KERN<IS_SA, false>), grid, dim3(NW * 64), lds, st, d, sa, fp, hr, bias_all, cols_total, od); \

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase cycle stamps of the fused MLP kernels (needs a -DSM_PROBE build, PVN3D_HIP_LIB=...).
-Runs each SA/FP chain of Pointnet2MSG alone and prints, averaged over the first 64 workgroups,
-the cycles between stamps: 14 body start, 0 run start, 6 (column-sliced kernel) first input chunk in LDS, 1/3/5 after layer l's MMA (+barrier),
+Runs each SA/FP chain of Pointnet2MSG alone and prints, averaged over ALL workgroups of the launch,
+the cycles spent up to each stamp since the previous one: 14 body start, 0 run start, 7 first layer-0 chunk staged, 8 layer-0 steady loop done, 6 (column-sliced kernel) first input chunk in LDS, 1/3/5 after layer l's MMA (+barrier),
 2/4 after the activation store, 15 end."""
 import ctypes
 import os
@@ -29,19 +29,14 @@ orig_sa, orig_fp = _ext.sa_mlp_maxpool, _ext.fp_interp_mlp
 
 def report(tag):
     torch.cuda.synchronize()
-    buf = np.zeros((64, 16), dtype=np.uint64)
+    buf = np.zeros(32, dtype=np.uint64)
     lib.pvn3d_debug_mlp_probe_read(buf.ctypes.data)
-    b = buf.astype(np.int64)
-    order = [14, 0, 6, 1, 2, 3, 4, 5, 15]
-    segs = []
-    prev = None
-    for k in order:
-        if prev is not None and (b[:, k] > 0).all() and (b[:, prev] > 0).all():
-            segs.append("%d->%d:%7.0f" % (prev, k, float(np.mean(b[:, k] - b[:, prev]))))
-        if (b[:, k] > 0).all():
-            prev = k
-    tot = float(np.mean(b[:, 15] - b[:, 14]))
-    print("%-28s total %8.0f  %s" % (tag, tot, "  ".join(segs)))
+    b = buf.astype(np.float64)
+    n_wg = max(b[16 + 15], 1.0)
+    order = [14, 0, 6, 7, 8, 1, 2, 3, 4, 5, 15]
+    segs = ["->%d:%7.0f" % (k, b[k] / n_wg) for k in order if b[16 + k] > 0]
+    tot = sum(b[k] for k in order if k != 14) / n_wg
+    print("%-30s wgs %6d  cycles/wg %8.0f  %s" % (tag, int(n_wg), tot, "  ".join(segs)))
 
 
 def sa(*a, **k):
@@ -59,5 +54,6 @@ def fp(*a, **k):
 with torch.no_grad():
     net(pc)
     torch.cuda.synchronize()
+    lib.pvn3d_debug_mlp_probe_read(np.zeros(32, dtype=np.uint64).ctypes.data)     # reset the accumulators
     _ext.sa_mlp_maxpool, _ext.fp_interp_mlp = sa, fp
     net(pc)
