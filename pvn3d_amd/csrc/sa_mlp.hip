@@ -93,7 +93,6 @@ constexpr int SM_MAX_LAYERS = 4;
 constexpr int SM_MAX_MT = 16;        // M <= 512
 constexpr int SM_EPAD = 68;          // row stride of the max-pool patch (16-byte aligned, conflict-free)
 constexpr int SM_CW = 96;            // row stride of a layer-0 chunk buffer: 64 columns + room for the rotation
-constexpr int SM_NUM_CU = 256;       // MI355X; only used to guess which workgroups start in a CU's 2nd / 3rd slot
 constexpr int SM_TAIL_ROWS = 8;      // widest layer-0 tail the specialised (GEN = false) kernels take
 
 struct MlpDesc {
@@ -102,11 +101,6 @@ struct MlpDesc {
   int M[SM_MAX_LAYERS];              // true output width
   const float* W[SM_MAX_LAYERS];     // packed [ceil(K/4)][ceil(M/32)][64][2]
   const float* bias[SM_MAX_LAYERS];  // [ceil(M/32)*32], zero padded
-  // start-up stagger (set by launch_chain): the workgroups that fill resident slot s > 0 of a CU at the
-  // start of the launch wait s * stagger cycles first.  All workgroups do identical work, so co-resident
-  // ones otherwise run in lock-step -- in their MFMA-free prologue / hand-over / epilogue phases at the
-  // same time -- and the offset, once made, persists through the launch (slots refill as they finish).
-  int wgs_per_cu, stagger;
 };
 
 struct RowSrc {       // point-major table: row r of frame b is tab[((size_t)b * rows + r) * ld ...]
@@ -774,15 +768,6 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
   xcd_frame_map(bi, bx);
   const int col0 = bx * SM_COLS;
 
-  if (d.wgs_per_cu > 1) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-    const unsigned slot = lin / SM_NUM_CU;
-    if (slot > 0 && slot < (unsigned)d.wgs_per_cu) {
-      const unsigned long long t0 = __builtin_readcyclecounter();
-      const unsigned long long wait = (unsigned long long)slot * (unsigned)d.stagger;
-      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   SM_PROBE_DECL;
   SM_STAMP(14);
   stage_bias<NW * 64>(d, s_bias, tid);
@@ -833,24 +818,6 @@ __device__ __forceinline__ void mlp_chain_body(const MlpDesc& d, const SaSrc& sa
   ch.sm_last_ = sm_last_;
 #endif
   ch.run(od);
-}
-
-// resident workgroups per CU (registers: `by_regs`; LDS) and the start-up stagger between them:
-// a workgroup's life is about wgs_per_cu x (its MFMA issue time per SIMD) x 1.25; co-resident workgroups
-// are spread evenly over it.  No stagger for launches that do not fill every slot several times over.
-void set_stagger(MlpDesc* d, int nw, int by_regs, size_t lds, unsigned n_wg) {
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > by_regs) per_cu = by_regs;
-  if (per_cu < 1) per_cu = 1;
-  d->wgs_per_cu = per_cu;
-  d->stagger = 0;
-  if (per_cu < 2 || n_wg < 4u * SM_NUM_CU * per_cu) { d->wgs_per_cu = 1; return; }
-  double mfma = 0;        // MFMA instructions of the busiest wave
-  for (int l = 0; l < d->n_layers; ++l) {
-    const int mt = (d->M[l] + 31) / 32, tiles = (mt + nw - 1) / nw;
-    mfma += 2.0 * ((d->K[l] + 3) / 4) * tiles * 2;
-  }
-  d->stagger = (int)(64.0 * mfma * 1.25);      // = life / per_cu
 }
 
 // host mirror of the device-side chunk classification: can the specialised (GEN = false) kernels
@@ -1131,11 +1098,8 @@ __global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 
 }
 
 template <bool IS_SA>
-int launch_chain(const MlpDesc& d_in, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
+int launch_chain(const MlpDesc& d, const SaSrc& sa, const FpSrc& fp, int b, int cols_total,
                  const OutDesc& od, hipStream_t st) {
-  MlpDesc d = d_in;
-  d.wgs_per_cu = 1;
-  d.stagger = 0;
   int hrows = 4, max_mt = 1, bias_all = 0;
   for (int l = 0; l < d.n_layers; ++l) {
     if (l + 1 < d.n_layers) hrows = max(hrows, ((d.M[l] + 31) / 32) * 32);
@@ -1173,7 +1137,6 @@ int launch_chain(const MlpDesc& d_in, const SaSrc& sa, const FpSrc& fp, int b, i
     if (IS_SA) hr = max(hr, pvn3d_ceil_div(NW * 32 * SM_EPAD, SM_COLS));                                      \
     const size_t lds = ((size_t)hr * SM_COLS + bias_all + 9 * 64) * sizeof(float);                            \
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;                                                   \
-    set_stagger(&d, NW, NW == 8 ? 1 : (max_mt <= 4 ? 3 : 2), lds, grid.x * grid.y);                           \
     if (spec) {                                                                                               \
       PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(KERN<IS_SA, false>));                                     \
       hipLaunchKernelGGL((KERN<IS_SA, false>), grid, dim3(NW * 64), lds, st, d, sa, fp, hr, bias_all, cols_total, od); \
