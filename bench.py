@@ -21,9 +21,17 @@ grouping and interpolation never touch HBM (they feed the MFMA kernel through LD
 Frames are independent, so N GPUs run N x frames per step with no data-path collective (weak
 scaling); the only communication is the timing reduction.
 
+``--strong`` keeps the TOTAL number of frames per step at ``--frames`` (BASELINE config 4: 64 frames per
+batch sharded over the ranks) instead of ``--frames`` per GPU; at N > 1 every step ends with the per-frame
+result all-gather (pvn3d_amd/sharding.py) inside the timed region -- the only collective of the path.
+
 Extra JSON objects: ``roofline`` (dominant kernel, measured with events inside the timed region),
 ``rooflines`` (every stage), ``cpu_baseline`` (the reference's dense-torch MeanShift + numpy
-Kabsch restated in oracle/, timed on the host cores on a bounded sample; rank 0, N=1 only).
+Kabsch restated in oracle/, timed on the host cores on a bounded sample; rank 0, N=1 only),
+``configs`` (rank 0, N=1: the other BASELINE configurations, each on a few steps: B=1 latency, the
+n_obj = 12 288 stress case, the YCB 5-object frame, config 1 (N = 2048) with its CPU time in full, a
+heavy-tailed vote set with its measured MeanShift iteration counts) and ``device_copy`` (measured
+HBM copy / fill bandwidth on this device, the achievable roofline next to the 8 TB/s peak).
 """
 import argparse
 import json
@@ -225,16 +233,11 @@ def run_postproc(inp, timer, poll_every):
     return res
 
 
-def cpu_baseline(frame, budget_s=25.0):
-    """Reference CPU path (dense torch MeanShift + numpy Kabsch, oracle/torch_port.py) on ONE
-    frame of the same workload on the host cores; plus the C/OpenMP oracle for comparison.
-    Bounded: if the first fit predicts more than `budget_s` for the frame, only the centre fit
-    and the first keypoint fit are run and the 9-fit frame time is extrapolated (and labelled)."""
-    from oracle import posecal, torch_port, native
-    cores = os.cpu_count() or 1
-    threads = min(cores, 32)          # the dense (n,n,3) temporaries are memory-bound
+def _time_dense_frame(frame, threads, budget_s):
+    """Dense torch-CPU restatement of the reference's post-processing on one frame with `threads` torch
+    threads.  Returns (seconds per frame, seconds inside MeanShift fits, fits timed, extrapolated?)."""
+    from oracle import posecal, torch_port
     torch.set_num_threads(threads)
-    n_fit = [0]
     t_fit = []
 
     class _Stop(Exception):
@@ -244,19 +247,32 @@ def cpu_baseline(frame, budget_s=25.0):
         t0 = time.perf_counter()
         c, l, it = torch_port.meanshift_fit_dense(torch.from_numpy(np.ascontiguousarray(A)), bw)
         t_fit.append(time.perf_counter() - t0)
-        n_fit[0] += 1
-        if n_fit[0] >= 2 and sum(t_fit) / len(t_fit) * 9 > budget_s:
+        if len(t_fit) >= 2 and sum(t_fit) / len(t_fit) * 9 > budget_s:
             raise _Stop()
         return c.numpy(), l.numpy(), it
-    extrapolated = False
     t0 = time.perf_counter()
     try:
         posecal.cal_frame_poses_lm(frame["pcld"], frame["mask"], frame["ctr_of"], frame["pred_kp_of"], True, 2,
                                    False, frame["mesh_kps"], fit=fit, bft=torch_port.best_fit_transform_np)
-        t_ref = time.perf_counter() - t0
+        return time.perf_counter() - t0, sum(t_fit), len(t_fit), False
     except _Stop:
-        extrapolated = True
-        t_ref = sum(t_fit) / len(t_fit) * 9
+        per = sum(t_fit) / len(t_fit)
+        return per * 9, per * 9, len(t_fit), True
+
+
+def cpu_baseline(frame, budget_s=20.0, one_thread_budget_s=8.0):
+    """Reference CPU path (dense torch MeanShift + numpy Kabsch, oracle/torch_port.py) on ONE frame of the
+    same workload on the host cores, at the chosen thread count and at 1 thread; plus the C/OpenMP oracle.
+    Bounded: if the first fits predict more than the budget for the frame, only those fits are run and
+    the 9-fit frame time is extrapolated (and labelled)."""
+    from oracle import posecal, native
+    cores = os.cpu_count() or 1
+    # the dense (n,n,3) temporaries are memory-bound: 32 threads measured 13x faster than 256 on the
+    # 256-core GPU-box host (round 1), so the thread count is capped there
+    threads = min(cores, 32)
+    t_ref, t_ms, n_fits, extrapolated = _time_dense_frame(frame, threads, budget_s)
+    t1, t1_ms, n1, ex1 = _time_dense_frame(frame, 1, one_thread_budget_s)
+    torch.set_num_threads(threads)
     native.set_num_threads(min(cores, 64))
     t0 = time.perf_counter()
     posecal.cal_frame_poses_lm(frame["pcld"], frame["mask"], frame["ctr_of"], frame["pred_kp_of"], True, 2, False,
@@ -266,11 +282,135 @@ def cpu_baseline(frame, budget_s=25.0):
     sample = ("1 frame (N=%d, n_obj=%d, 9 fits) vote+cluster+pose, dense torch-CPU restatement of "
               "MeanShiftTorch.fit + numpy Kabsch" % (len(frame["pcld"]), n_obj))
     if extrapolated:
-        sample += "; %d of 9 fits timed (%.1f s), frame time extrapolated x9/%d" % (len(t_fit), sum(t_fit), len(t_fit))
+        sample += "; %d of 9 fits timed, frame time extrapolated x9/%d" % (n_fits, n_fits)
     return dict(value=1.0 / t_ref, unit="frames/s", cores=threads, kind="port", sample=sample,
-                seconds_per_frame=t_ref, host_cores_available=cores,
+                seconds_per_frame=t_ref, meanshift_share=t_ms / t_ref, host_cores_available=cores,
+                threads_choice="min(cores, 32): the dense (n,n,3) temporaries are memory-bound; 256 threads "
+                               "measured 13x slower than 32 on this host class",
+                one_thread=dict(value=1.0 / t1, unit="frames/s", cores=1, seconds_per_frame=t1,
+                                fits_timed=n1, extrapolated=ex1),
                 c_openmp_port=dict(value=1.0 / t_c, unit="frames/s", cores=min(cores, 64),
                                    seconds_per_frame=t_c))
+
+
+def _median_ms(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def device_copy_bandwidth(dev):
+    """Achievable HBM bandwidth on this device: 1 GiB device-to-device copy (read + write) and fill."""
+    a = torch.empty(256 * 1024 * 1024, device=dev)
+    b = torch.empty_like(a)
+    ms_c = _median_ms(lambda: b.copy_(a), 5)
+    ms_f = _median_ms(lambda: b.fill_(1.0), 5)
+    del a, b
+    return dict(copy_gbs=2 * (1 << 30) / (ms_c * 1e-3) / 1e9, fill_gbs=(1 << 30) / (ms_f * 1e-3) / 1e9,
+                unit="GB/s", bytes=1 << 30, note="copy counts read + write bytes")
+
+
+def extra_configs(net, dev, poll_every, with_cpu):
+    """The BASELINE configurations next to the headline one, each on a few steps (rank 0, N = 1)."""
+    from pvn3d_amd import synth
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    out = []
+    off = StageTimer(False)
+
+    def to_dev(frames):
+        st = lambda k: torch.from_numpy(np.stack([f[k] for f in frames], 0)).to(dev)
+        return dict(pcld=st("pcld").contiguous(), mask=st("mask").to(torch.int32).contiguous(),
+                    ctr_of=st("ctr_of").contiguous(), pred_kp_of=st("pred_kp_of").contiguous(), frames=frames)
+
+    def post(inp):
+        return run_postproc(inp, off, poll_every)
+
+    def pose_err(res, frames):
+        p = res["poses"].cpu().numpy()
+        return float(max(max(np.abs(p[i][:, :3] - f["R"]).max(), np.abs(p[i][:, 3] - f["t"]).max())
+                         for i, f in enumerate(frames)))
+
+    # (i) B = 1 latency, config 2 (the reference evaluates at test_mini_batch_size = 1, common.py:41)
+    inp = make_inputs(1, 12288, 3072, dev, seed_base=7000)
+    inp["pc"] = torch.cat([inp["pcld"], inp["feats"].transpose(1, 2)], 2).contiguous()
+    ms_a = _median_ms(lambda: run_net(net, inp, off), 20) if net is not None else None
+    ms_b = _median_ms(lambda: post(inp), 20)
+    both = (lambda: (run_net(net, inp, off), post(inp))) if net is not None else (lambda: post(inp))
+    ms_ab = _median_ms(both, 20)
+    res = post(inp)
+    out.append(dict(name="b1_latency", workload="config 2 (LineMOD eval path), ONE frame per call: N=12288, n_obj=3072, K=8",
+                    ms_per_frame=dict(pointnet2_msg=ms_a, vote_cluster_pose=ms_b, both_serial=ms_ab),
+                    frames_per_s=1e3 / ms_ab, meanshift_iters_max=int(res["iters"].max().item()),
+                    pose_err_vs_ground_truth=pose_err(res, inp["frames"])))
+
+    # (ii) the n_obj = 12 288 stress case (every point of the cloud votes), 8 frames per call
+    fr = [synth.synth_frame(frame=7100 + i, n_pts=12288, n_obj=12288) for i in range(8)]
+    inp = to_dev(fr)
+    ms = _median_ms(lambda: post(inp), 5)
+    res = post(inp)
+    it = res["iters"].cpu().numpy().astype(np.float64)
+    pairs = float((it * 12288.0 * 12288.0).sum())
+    out.append(dict(name="stress_nobj_12288", workload="vote -> MeanShift x9 -> Kabsch with n_obj = N = 12288, 8 frames per call",
+                    ms_per_frame=ms / 8, frames_per_s=8e3 / ms, meanshift_iters=dict(min=int(it.min()), max=int(it.max()), mean=float(it.mean())),
+                    pair_evals_per_s=pairs / (ms * 1e-3), pose_err_vs_ground_truth=pose_err(res, fr)))
+
+    # (iii) config 3: YCB multi-instance frame, 21 classes, 5 objects, centre-cluster filter on
+    fy = [synth.synth_frame_ycb(frame=7200 + i) for i in range(16)]
+    sty = lambda k: torch.from_numpy(np.stack([f[k] for f in fy], 0)).to(dev)
+    yp, ym, yc, yk = sty("pcld").contiguous(), sty("mask").to(torch.int32).contiguous(), sty("ctr_of").contiguous(), sty("pred_kp_of").contiguous()
+    run_y = lambda: ev.cal_batch_poses(yp, ym, yc, yk, True, 22, True, poll_every=poll_every)
+    ms = _median_ms(run_y, 5)
+    ry = run_y()
+    poses = ry["poses"].cpu().numpy()
+    err = 0.0
+    for i, f in enumerate(fy):
+        for cid, (R, t) in f["poses"].items():
+            err = max(err, float(np.abs(poses[i, cid - 1][:, :3] - R).max()), float(np.abs(poses[i, cid - 1][:, 3] - t).max()))
+    ms1 = _median_ms(lambda: ev.cal_batch_poses(yp[:1], ym[:1], yc[:1], yk[:1], True, 22, True, poll_every=poll_every), 10)
+    out.append(dict(name="ycb_multi_instance", workload="config 3: N=12288, 21 classes, 5 objects of 1228 points, use_ctr_clus_flter=True; "
+                                                         "16 frames per call",
+                    ms_per_frame=ms / 16, frames_per_s=16e3 / ms, ms_single_frame_call=ms1,
+                    meanshift_iters_max=int(ry["iters"].max().item()), pose_err_vs_ground_truth=err))
+
+    # (iv) config 1: one 2048-point cloud, 1 object, all points on it; CPU path in full
+    f1 = [synth.synth_frame(frame=7300 + i, n_pts=2048, n_obj=2048) for i in range(64)]
+    inp1, inp64 = to_dev(f1[:1]), to_dev(f1)
+    ms1 = _median_ms(lambda: post(inp1), 20)
+    ms64 = _median_ms(lambda: post(inp64), 5)
+    c1 = dict(name="config1_n2048", workload="config 1: single synthetic 2048-pt cloud, 1 object, 8 keypoints (+centre): "
+                                            "vote -> MeanShift x9 -> Kabsch",
+              ms_per_frame_b1=ms1, ms_per_frame_b64=ms64 / 64, frames_per_s_b64=64e3 / ms64,
+              pose_err_vs_ground_truth=pose_err(post(inp64), f1))
+    if with_cpu:
+        cores = os.cpu_count() or 1
+        t_ref, t_ms, _n, _e = _time_dense_frame(f1[0], min(cores, 32), 1e9)
+        t_one, _a, _b, _c = _time_dense_frame(f1[0], 1, 1e9)
+        c1["cpu_reference_path"] = dict(seconds_per_frame=t_ref, cores=min(cores, 32), seconds_per_frame_1_thread=t_one,
+                                        meanshift_share=t_ms / t_ref, kind="port",
+                                        sample="1 frame in full (9 fits), dense torch-CPU MeanShift + numpy Kabsch")
+        c1["gpu_over_cpu_b1"] = t_ref * 1e3 / ms1
+    out.append(c1)
+
+    # (v) heavy-tailed votes: 10 % outliers with sigma = 30 cm (far points creep for many iterations)
+    fh = [synth.synth_frame(frame=7400 + i, n_pts=12288, n_obj=3072, sig_out=0.30) for i in range(16)]
+    inph = to_dev(fh)
+    ms = _median_ms(lambda: post(inph), 5)
+    res = post(inph)
+    it = res["iters"].cpu().numpy().astype(np.float64)
+    cnt = res["counts"].cpu().numpy().astype(np.float64)
+    out.append(dict(name="heavy_tail_votes", workload="config 2 frames with 10 % vote outliers of sigma = 30 cm, 16 frames per call",
+                    ms_per_frame=ms / 16, frames_per_s=16e3 / ms,
+                    meanshift_iters=dict(min=int(it.min()), max=int(it.max()), mean=float(it.mean())),
+                    valu_tflops_16flop_per_pair=16.0 * float((it * cnt * cnt).sum()) / (ms * 1e-3) / 1e12,
+                    pose_err_vs_ground_truth=pose_err(res, fh)))
+    return out
 
 
 def main():
@@ -287,6 +427,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream, islands back to back")
     ap.add_argument("--ops-only", action="store_true",
                     help="island (A) = bare SA/FP op chain with synthetic features (no MLP GEMMs)")
+    ap.add_argument("--strong", action="store_true",
+                    help="--frames is the TOTAL per step, split over the ranks (BASELINE config 4: 64 frames sharded)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -302,7 +445,14 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     scale = args.n_pts / 12288.0
-    inp = make_inputs(args.frames, args.n_pts, args.n_obj, dev, seed_base=1000 * rank)
+    from pvn3d_amd import sharding
+    if args.strong:
+        lo, hi = sharding.shard_range(args.frames, rank, world)
+        frames_local, frames_total = hi - lo, args.frames
+        assert frames_local > 0, "--strong needs at least one frame per rank"
+    else:
+        frames_local, frames_total = args.frames, args.frames * world
+    inp = make_inputs(frames_local, args.n_pts, args.n_obj, dev, seed_base=1000 * rank)
     inp["pc"] = torch.cat([inp["pcld"], inp["feats"].transpose(1, 2)], 2).contiguous()   # (F, N, 3+6)
     net = None if args.ops_only else make_net(dev)
     timer_off = StageTimer(False)
@@ -317,17 +467,31 @@ def main():
     # mode so they do not overlap).
     side = torch.cuda.Stream(device=dev)
 
+    def gather_results(res):
+        """The path's only collective: per-frame result rows (3x4 pose, K+1 keypoints, iteration counts) of
+        every rank to every rank, once per batch (RCCL over xGMI; no-op at world size 1)."""
+        if world == 1:
+            return None
+        rows = torch.cat([res["poses"].reshape(frames_local, -1).to(torch.float32),
+                          res["cls_kps"].reshape(frames_local, -1).to(torch.float32),
+                          res["iters"].reshape(frames_local, -1).to(torch.float32)], 1)
+        if args.strong:
+            return sharding.gather_frame_results(rows, frames_total)
+        bufs = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(bufs, rows)
+        return bufs
+
     def step(timer):
         if args.serial:
             keep = island_a(timer)
             res = run_postproc(inp, timer, args.poll_every)
-            return keep, res
+            return keep, res, gather_results(res)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             keep = island_a(timer_off)
         res = run_postproc(inp, timer_off, args.poll_every)
         torch.cuda.current_stream(dev).wait_stream(side)
-        return keep, res
+        return keep, res, gather_results(res)
 
     for _ in range(args.warmup):
         step(timer_off)
@@ -338,7 +502,7 @@ def main():
     timer = StageTimer(args.serial and not args.no_stage_events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        keep, res = step(timer)
+        keep, res, gathered = step(timer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -378,13 +542,13 @@ def main():
     iters = res["iters"].cpu().numpy()
 
     if rank == 0:
-        total_frames = args.frames * world * args.steps
+        total_frames = frames_total * args.steps
         stage_ms = timer.totals_ms()
         per_step = {k: v / args.steps for k, v in stage_ms.items()}
         op_step = {k: v / args.steps for k, v in op_timer.totals_ms().items()}
         alg = algorithmic_bytes_per_frame(args.n_pts)
         rooflines = {}
-        F = args.frames
+        F = frames_local
         for name in ["ball_query", "group", "three_interpolate", "three_nn", "gather", "fps"]:
             if name in op_step and op_step[name] > 0:
                 gbs = alg[name] * F / (op_step[name] * 1e-3) / 1e9
@@ -451,10 +615,12 @@ def main():
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LineMOD 'ape' eval path: %s + vote -> MeanShift x9 -> Kabsch; N=%d pts, "
                                    "n_obj=%d, K=8" % (island, args.n_pts, args.n_obj),
-                       "frames_per_gpu_per_step": args.frames, "parallelism": "frames sharded x%d, no collective" % world,
+                       "frames_per_gpu_per_step": frames_local, "frames_per_step_all_gpus": frames_total,
+                       "parallelism": "frames sharded x%d; one all-gather of per-frame result rows per step%s"
+                                      % (world, "" if world > 1 else " (no-op at 1 GPU)"),
                        "streams": "1 (serial)" if args.serial else "3 (Pointnet2MSG feature path || its xyz-only geometry (FPS, ball query, three_nn) || "
                                   "vote-cluster-pose)" if net is not None else "2 (SA/FP ops || vote-cluster-pose)"},
             "op_chain_stage_ms_per_step": op_step if net is not None else None,
@@ -469,6 +635,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f0)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if "vote_cluster_pose" in per_step:
+                # the north_star's ">= 10x the reference CPU MeanShift vote-clustering" on identical inputs:
+                # one frame's CPU MeanShift time vs the GPU's vote->cluster->pose time per frame
+                out["cpu_baseline"]["vote_clustering_gpu_over_cpu"] = (
+                    out["cpu_baseline"]["seconds_per_frame"] * out["cpu_baseline"]["meanshift_share"]
+                    / (per_step["vote_cluster_pose"] * 1e-3 / F))
+        if world == 1 and not args.no_extra_configs and args.n_pts == 12288:
+            out["device_copy"] = device_copy_bandwidth(dev)
+            out["configs"] = extra_configs(net, dev, args.poll_every, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -115,20 +115,29 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
   }
 }
 
+// exclusive prefix sum over the wave on the DPP path (row shifts, then row_bcast 15 / 31): six VALU
+// instructions, no LDS traffic (a __shfl_up ladder is six dependent ds_bpermute round trips, and a
+// centre needs three scans)
 __device__ __forceinline__ int wave_excl_scan_add(int v, int lane, int* total) {
+  (void)lane;
   int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(x, o, 64);
-    if (lane >= o) x += t;
-  }
-  *total = __shfl(x, 63, 64);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  *total = __builtin_amdgcn_readlane(x, 63);
   return x - v;
 }
 
 // Pull the hits of one bitmap out in ascending index order.  words = ceil(n/32) <= 1024.
+// The row is assembled in a wave-private LDS staging line `stage` (BQG_STAGE ints) and leaves with one
+// coalesced store per 64 slots: the lanes find their hits at different times, and 4-byte stores issued
+// one lane at a time cost a memory transaction each.
+constexpr int BQG_STAGE = 64;
 __device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int nsample,
-                                                 int* __restrict__ out, int lane) {
+                                                 int* __restrict__ out, int* __restrict__ stage, int lane) {
   // lane owns WPL consecutive words
   const int wpl = (words + 63) >> 6;
   const int w0 = lane * wpl;
@@ -151,8 +160,10 @@ __device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int ns
         if (v) { f = (w0 + i) * 32 + __builtin_ctz(v); break; }
       }
     }
-    first = __shfl(f, fl, 64);
+    first = __builtin_amdgcn_readlane(f, fl);
   }
+  const bool staged = nsample <= BQG_STAGE;
+  int* dst = staged ? stage : out;
   if (mine > 0) {
     for (int i = 0; i < wpl; ++i) {
       const int w = w0 + i;
@@ -163,75 +174,88 @@ __device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int ns
       while (v && rank < nsample) {
         const int bit = __builtin_ctz(v);
         v &= v - 1;
-        out[rank++] = w * 32 + bit;
+        dst[rank++] = w * 32 + bit;
       }
       if (v) rank += __builtin_popcount(v);
     }
   }
   // pad slots [min(total, nsample), nsample) with the first hit; no hit -> zeros
   const int filled = total < nsample ? total : nsample;
-  for (int l = filled + lane; l < nsample; l += 64) out[l] = first;
+  for (int l = filled + lane; l < nsample; l += 64) dst[l] = first;
+  if (staged && lane < nsample) out[lane] = stage[lane];     // (same wave: LDS ops complete in order)
 }
 
-// one wave per centre, 4 waves per workgroup.  dynamic LDS: per wave 2 bitmaps of `words` words.
+// one wave per centre at a time, 4 waves per workgroup, each wave works through centres
+// j = blockIdx.x*4 + wave, + 4*gridDim.x, ... (its bitmaps are cleared once: the emission leaves them
+// clean).  dynamic LDS: per wave 2 bitmaps of `words` words.
 template <bool PAIR, int AL>
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb, int words,
-    const float* __restrict__ new_xyz, const int* __restrict__ cell_start,
+    const float* __restrict__ new_xyz_all, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, int* __restrict__ idxa, int* __restrict__ idxb) {
   extern __shared__ unsigned s_bm[];  // [4 waves][PAIR ? 2 : 1][words]
   __shared__ int s_pref[4][32];
   __shared__ int s_beg[4][32];
+  __shared__ int s_stage[4][BQG_STAGE];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bi = blockIdx.y;
-  const int j = blockIdx.x * 4 + wave;
   unsigned* bma = s_bm + (size_t)wave * (PAIR ? 2 : 1) * words;
   unsigned* bmb = bma + words;
   for (int i = lane; i < (PAIR ? 2 : 1) * words; i += 64) bma[i] = 0u;
-  if (j >= m) return;
-  new_xyz += ((size_t)bi * m + j) * 3;
   cell_start += (size_t)bi * (grid_t(AL) + 1);
   sorted += (size_t)bi * n;
-  const float cx = new_xyz[0], cy = new_xyz[1], cz = new_xyz[2];
-  const int gx = (int)floorf(cx * inv_h), gy = (int)floorf(cy * inv_h), gz = (int)floorf(cz * inv_h);
-  // lanes 0..26: one neighbour cell each
-  int beg = 0, cnt = 0;
-  if (lane < 27) {
-    const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
-    const int bucket = grid_bucket_c<AL>(gx + ox, gy + oy, gz + oz);
-    beg = cell_start[bucket];
-    cnt = cell_start[bucket + 1] - beg;
-  }
-  int total;
-  const int pref = wave_excl_scan_add(cnt, lane, &total);
-  if (lane < 32) {
-    s_pref[wave][lane] = (lane < 27) ? pref : 0x7fffffff;
-    s_beg[wave][lane] = beg;
-  }
-  // (single wave: LDS writes above are ordered before the reads below by lgkmcnt waits)
-  for (int f0 = 0; f0 < total; f0 += 64) {
-    const int f = f0 + lane;
-    if (f < total) {
-      // owner cell q: largest q with pref[q] <= f  (pref is non-decreasing, 27 entries)
-      int q = 0;
-#pragma unroll
-      for (int s = 16; s >= 1; s >>= 1) {
-        const int t = q + s;
-        if (t < 27 && s_pref[wave][t] <= f) q = t;
-      }
-      const int qbeg = s_beg[wave][q];   // (LDS, not a shuffle: the owner lane may be inactive here)
-      const int qpref = s_pref[wave][q];
-      const float4 p = sorted[qbeg + (f - qpref)];
-      const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      const int k = __float_as_int(p.w);
-      if (d2 < r2a) atomicOr(&bma[k >> 5], 1u << (k & 31));
-      if (PAIR && d2 < r2b) atomicOr(&bmb[k >> 5], 1u << (k & 31));
+  // the centre's coordinates and its 27 bucket ranges are fetched one centre ahead (two dependent
+  // global round trips that would otherwise head every centre's latency chain)
+  auto fetch_cells = [&](int j, float& cx, float& cy, float& cz, int& beg, int& cnt) {
+    const float* c = new_xyz_all + ((size_t)bi * m + min(j, m - 1)) * 3;
+    cx = c[0]; cy = c[1]; cz = c[2];
+    const int gx = (int)floorf(cx * inv_h), gy = (int)floorf(cy * inv_h), gz = (int)floorf(cz * inv_h);
+    beg = 0; cnt = 0;
+    if (lane < 27) {      // lanes 0..26: one neighbour cell each
+      const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
+      const int bucket = grid_bucket_c<AL>(gx + ox, gy + oy, gz + oz);
+      beg = cell_start[bucket];
+      cnt = cell_start[bucket + 1] - beg;
     }
+  };
+  float ncx, ncy, ncz;
+  int nbeg, ncnt;
+  fetch_cells(blockIdx.x * 4 + wave, ncx, ncy, ncz, nbeg, ncnt);
+  for (int j = blockIdx.x * 4 + wave; j < m; j += 4 * gridDim.x) {
+    const float cx = ncx, cy = ncy, cz = ncz;
+    const int beg = nbeg, cnt = ncnt;
+    fetch_cells(j + 4 * gridDim.x, ncx, ncy, ncz, nbeg, ncnt);
+    int total;
+    const int pref = wave_excl_scan_add(cnt, lane, &total);
+    if (lane < 32) {
+      s_pref[wave][lane] = (lane < 27) ? pref : 0x7fffffff;
+      s_beg[wave][lane] = beg;
+    }
+    // (single wave: LDS writes above are ordered before the reads below by lgkmcnt waits)
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      const int f = f0 + lane;
+      if (f < total) {
+        // owner cell q: largest q with pref[q] <= f  (pref is non-decreasing, 27 entries)
+        int q = 0;
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) {
+          const int t = q + s;
+          if (t < 27 && s_pref[wave][t] <= f) q = t;
+        }
+        const int qbeg = s_beg[wave][q];   // (LDS, not a shuffle: the owner lane may be inactive here)
+        const int qpref = s_pref[wave][q];
+        const float4 p = sorted[qbeg + (f - qpref)];
+        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const int k = __float_as_int(p.w);
+        if (d2 < r2a) atomicOr(&bma[k >> 5], 1u << (k & 31));
+        if (PAIR && d2 < r2b) atomicOr(&bmb[k >> 5], 1u << (k & 31));
+      }
+    }
+    emit_from_bitmap(bma, words, nsa, idxa + ((size_t)bi * m + j) * nsa, s_stage[wave], lane);
+    if (PAIR) emit_from_bitmap(bmb, words, nsb, idxb + ((size_t)bi * m + j) * nsb, s_stage[wave], lane);
   }
-  emit_from_bitmap(bma, words, nsa, idxa + ((size_t)bi * m + j) * nsa, lane);
-  if (PAIR) emit_from_bitmap(bmb, words, nsb, idxb + ((size_t)bi * m + j) * nsb, lane);
 }
 
 }  // namespace
@@ -260,16 +284,16 @@ extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, in
   const float inv_h = 1.0f / (rmax * 1.001f);
   const int words = (n + 31) / 32;
   const size_t qlds = (size_t)4 * (pair ? 2 : 1) * words * sizeof(unsigned);
-  const dim3 qgrid(pvn3d_ceil_div(m, 4), b);
+  // enough workgroups to fill the chip a few times over, then several centres per wave
+  int qx = pvn3d_ceil_div(m, 4);
+  while (qx > 8 && (long long)qx * b > 8192) qx = (qx + 1) / 2;
+  const dim3 qgrid(qx, b);
   const float r2a = radius0 * radius0, r2b = radius1 * radius1;
 #define BQG_RUN(AL)                                                                             \
   do {                                                                                          \
     auto bk = grid_build_kernel<AL>;                                                            \
     const size_t blds = (size_t)(grid_t(AL) + (grid_t(AL) >> 5)) * sizeof(int);                 \
-    if (blds > 48 * 1024)                                                                       \
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(bk),                \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                              (int)blds));                                      \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(bk));                                   \
     hipLaunchKernelGGL(bk, dim3(b), dim3(1024), blds, st, n, inv_h, xyz, ws.cell_start,         \
                        ws.sorted);                                                              \
     PVN3D_LAUNCH_CHECK();                                                                       \

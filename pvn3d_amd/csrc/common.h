@@ -33,8 +33,12 @@ static inline int pvn3d_allow_big_lds(K kern) {
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   if (dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return 0;
+  hipFuncAttributes fa;
+  e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+  if (e != hipSuccess) return (int)e;
+  // the CU has 160 KiB; the kernel's static __shared__ arrays come out of the same budget
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024);
+                          160 * 1024 - (int)fa.sharedSizeBytes);
   if (e != hipSuccess) return (int)e;
   if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
   return 0;

@@ -51,10 +51,15 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(
 // CPB contiguous output streams -- long sequential HBM write bursts per workgroup, and idx is
 // re-read from L2 only once per CPB channels.
 // grid: (n_pchunks, ceil(c/CPB), b); dynamic LDS = CPB*n floats; n % 4 == 0, P % 4 == 0.
+// QueryAndGroup's relative-xyz channels ride in the same launch: with xyz != nullptr the grid has three
+// more row blocks (gridDim.y = ceil(c/CPB) + 3), block ceil(c/CPB) + k stages coordinate k of the cloud
+// (AoS (b,n,3), strided read) and writes out[b][k][p] = xyz[idx[p]][k] - new_xyz[p / nsample][k]; the
+// feature rows then start at channel 3 (pointnet2_utils.py:311-321: grouped_xyz -= new_xyz; cat).
 template <int CPB>
 __global__ __launch_bounds__(256) void group_points_rows_kernel(
     int c, int n, int P, int pchunk, const float* __restrict__ points,
-    const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride) {
+    const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride,
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz, int nsample) {
   extern __shared__ float s_row[];  // [CPB][n]
   const int tid = threadIdx.x;
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in
@@ -69,6 +74,31 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
     by = (int)(w / gridDim.x);
     bx = (int)(w % gridDim.x);
   }
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int feat_rows = (c + CPB - 1) / CPB;
+  if (by >= feat_rows) {          // relative-xyz channel k (only launched with xyz != nullptr)
+    const int k = by - feat_rows;
+    const float* xb = xyz + (size_t)bi * n * 3 + k;
+    for (int q = tid; q < n; q += 256) s_row[q] = xb[(size_t)q * 3];
+    __syncthreads();
+    const int* ip = idx + (size_t)bi * P;
+    const float* cb = new_xyz + (size_t)bi * (P / nsample) * 3 + k;
+    float* o = out + (size_t)bi * out_batch_stride + (size_t)k * P;
+    const int p_end = min(bx * pchunk + pchunk, P);
+    for (int p = bx * pchunk + tid * 4; p < p_end; p += 1024) {
+      const int4 id = *reinterpret_cast<const int4*>(ip + p);
+      v4f val;
+      if ((nsample & 3) == 0) {      // the four positions share one centre
+        const float cc = cb[(size_t)(p / nsample) * 3];
+        val = v4f{s_row[id.x] - cc, s_row[id.y] - cc, s_row[id.z] - cc, s_row[id.w] - cc};
+      } else {
+        val = v4f{s_row[id.x] - cb[(size_t)(p / nsample) * 3], s_row[id.y] - cb[(size_t)((p + 1) / nsample) * 3],
+                  s_row[id.z] - cb[(size_t)((p + 2) / nsample) * 3], s_row[id.w] - cb[(size_t)((p + 3) / nsample) * 3]};
+      }
+      __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + p));
+    }
+    return;
+  }
   const int c0 = by * CPB;
   const int nc = min(CPB, c - c0);
   const int n4 = n >> 2;
@@ -79,11 +109,10 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
   const int p_begin = bx * pchunk;
   const int p_end = min(p_begin + pchunk, P);
   const int* ip = idx + (size_t)bi * P;
-  float* o = out + (size_t)bi * out_batch_stride + (size_t)c0 * P;
+  float* o = out + (size_t)bi * out_batch_stride + (size_t)(c0 + (xyz ? 3 : 0)) * P;
   // idx is loaded one iteration ahead: gfx950 counts loads and stores in the same in-order
   // vmcnt, so waiting for an idx load issued AFTER the previous iteration's stores would wait
   // for their write acknowledgements too; issued before them it only needs vmcnt(#stores).
-  typedef float v4f __attribute__((ext_vector_type(4)));
   int p = p_begin + tid * 4;
   int4 id = *reinterpret_cast<const int4*>(ip + min(p, P - 4));
   if (nc == CPB) {
@@ -164,11 +193,17 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(
             grad_out[((size_t)bi * c + l) * P + p]);
 }
 
+// xyz / new_xyz != nullptr: also write the three relative-xyz channels in front of the c feature channels
+// (`out` is then the (b, 3+c, P) tensor); returns 1 if that request could not be served by the row-owner
+// kernel (the caller then uses the separate xyz kernel + a plain feature launch), 0 on success.
 int launch_group(int b, int c, int n, int P, const float* points, const int* idx, float* out,
-                 size_t out_batch_stride, hipStream_t st) {
+                 size_t out_batch_stride, hipStream_t st, const float* xyz = nullptr,
+                 const float* new_xyz = nullptr, int nsample = 1) {
   if (b <= 0 || c <= 0 || P <= 0) return 0;
   const bool aligned = (P % 4 == 0) && (out_batch_stride % 4 == 0) &&
                        (((uintptr_t)out & 15) == 0) && (((uintptr_t)idx & 15) == 0);
+  // (at n = 12288 -- level 0, 9 channels -- a workgroup stages a 48 KiB row for 16-32 KiB of output; the
+  // direct-gather kernel below was measured there too and is slower still: 66 + 104 us vs 49 + 62 us)
   const bool rows_ok = aligned && (n % 4 == 0) && (size_t)n * 4 <= 128 * 1024 && (((uintptr_t)points & 15) == 0);
   if (rows_ok) {
     // rows per workgroup: measured best (MI355X, 64 clouds) with ~16 KiB of LDS per workgroup,
@@ -177,7 +212,7 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     int cpb = 4;
     while (cpb > 1 && (size_t)cpb * n * 4 > 16 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;
-    const int rows = pvn3d_ceil_div(c, cpb);
+    const int rows = pvn3d_ceil_div(c, cpb) + (xyz ? 3 : 0);
     // split the position range until there are a few thousand workgroups
     int pch = pvn3d_ceil_div(4096, rows * b);
     if (pch < 1) pch = 1;
@@ -185,23 +220,24 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     if (pchunk < 4096) pchunk = 4096;
     pch = pvn3d_ceil_div(P, pchunk);
     const size_t lds = (size_t)cpb * n * sizeof(float);
+#define GP_ARGS c, n, P, pchunk, points, idx, out, out_batch_stride, xyz, new_xyz, nsample
     switch (cpb) {
       case 4:
         PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<4>));
-        hipLaunchKernelGGL(group_points_rows_kernel<4>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
-                           points, idx, out, out_batch_stride);
+        hipLaunchKernelGGL(group_points_rows_kernel<4>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
         break;
       case 2:
         PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<2>));
-        hipLaunchKernelGGL(group_points_rows_kernel<2>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
-                           points, idx, out, out_batch_stride);
+        hipLaunchKernelGGL(group_points_rows_kernel<2>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
         break;
       default:
         PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<1>));
-        hipLaunchKernelGGL(group_points_rows_kernel<1>, dim3(pch, rows, b), dim3(256), lds, st, c, n, P, pchunk,
-                           points, idx, out, out_batch_stride);
+        hipLaunchKernelGGL(group_points_rows_kernel<1>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
         break;
     }
+#undef GP_ARGS
+  } else if (xyz) {
+    return 1;
   } else if (aligned) {
     const int gx = pvn3d_ceil_div(P, 1024);
     // split channels until there are a few thousand workgroups (256 CUs x 8)
@@ -239,6 +275,10 @@ extern "C" int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample,
   const int c_out = (use_xyz ? 3 : 0) + (features ? c : 0);
   if (c_out == 0) return (int)hipErrorInvalidValue;
   const size_t bstride = (size_t)c_out * P;
+  if (use_xyz && features && c > 0) {      // one launch: feature rows + the three relative-xyz rows
+    const int rc = launch_group(b, c, n, P, features, idx, out, bstride, st, xyz, new_xyz, nsample);
+    if (rc != 1) return rc;
+  }
   if (use_xyz) {
     hipLaunchKernelGGL(group_xyz_rel_kernel, dim3(pvn3d_ceil_div(P, 256), 1, b), dim3(256), 0, st,
                        n, m, nsample, xyz, new_xyz, idx, out, bstride);

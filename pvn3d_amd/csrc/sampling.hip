@@ -284,10 +284,7 @@ int launch_fps_reg(int b, int n, int m, int L, int Q, const float* dataset, int*
   if (!use_lds) lds = 0;
   if (use_lds) {
     auto kern = fps_reg_kernel<THREADS, PPT, true>;
-    if (lds > 48 * 1024)
-      PVN3D_RETURN_IF_ERR(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)lds));
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(kern));
     hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, st, n, m, L, Q, dataset,
                        idxs FPS_PROBE_NULL);
   } else {
