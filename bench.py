@@ -410,6 +410,25 @@ def extra_configs(net, dev, poll_every, with_cpu):
                     meanshift_iters=dict(min=int(it.min()), max=int(it.max()), mean=float(it.mean())),
                     valu_tflops_16flop_per_pair=16.0 * float((it * cnt * cnt).sum()) / (ms * 1e-3) / 1e12,
                     pose_err_vs_ground_truth=pose_err(res, fh)))
+    # (vi) config 5: one training step of the voting branch, mini_batch_size = 24 (common.py:37), fp32 and bf16
+    from pvn3d_amd import train_step as ts
+    B = 24
+    batch = ts.synthetic_batch(B, 12288, dev, seed_base=7500, n_obj=3072)
+    entry = dict(name="train_step", workload="config 5 on ONE GPU: Pointnet2MSG + offset heads, forward + vote loss + backward + Adam "
+                                              "step, %d frames of N=12288 per step; native gather/scatter ops + vote loss, "
+                                              "library (MIOpen/hipBLASLt) 1x1-conv GEMMs" % B)
+    for tag, dt in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
+        torch.manual_seed(1)
+        model = ts.PointVoteNet().to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt)), 5, warm=2)
+        entry[tag] = dict(ms_per_step=ms, frames_per_s=B * 1e3 / ms, loss_first=float(losses[0]), loss_last=float(losses[-1]),
+                          peak_mem_gb=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+        del model, opt
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+    out.append(entry)
     return out
 
 

@@ -54,9 +54,13 @@ __device__ __forceinline__ int grid_bucket_c(int cx, int cy, int cz) {
   return (cx & M) | ((cy & M) << AL) | ((cz & M) << (2 * AL));
 }
 
+// Cell coordinates are taken relative to the cloud's first point: floor((p - origin) / h) is then exact
+// to ~6e-8 * (extent / h) cells, far inside the 0.1 % margin of h = 1.001 r for any cloud whose extent
+// is below ~10^4 cells (with absolute coordinates a cloud given in millimetres, or far from the
+// origin, could put a point with d2 < r^2 outside the 27 cells that are searched).
 template <int AL>
-__device__ __forceinline__ int grid_bucket(float x, float y, float z, float inv_h) {
-  return grid_bucket_c<AL>((int)floorf(x * inv_h), (int)floorf(y * inv_h), (int)floorf(z * inv_h));
+__device__ __forceinline__ int grid_bucket(float x, float y, float z, float ox, float oy, float oz, float inv_h) {
+  return grid_bucket_c<AL>((int)floorf((x - ox) * inv_h), (int)floorf((y - oy) * inv_h), (int)floorf((z - oz) * inv_h));
 }
 
 // LDS index of bucket c, padded by one word per 32 so that a thread scanning its own 32 (or 4)
@@ -78,9 +82,10 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
   cell_start += (size_t)blockIdx.x * (T + 1);
   sorted += (size_t)blockIdx.x * n;
   for (int i = tid; i < T + (T >> 5); i += 1024) s_cnt[i] = 0;
+  const float ox = xyz[0], oy = xyz[1], oz = xyz[2];
   __syncthreads();
   for (int k = tid; k < n; k += 1024)
-    atomicAdd(&s_cnt[pad32(grid_bucket<AL>(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2], inv_h))], 1);
+    atomicAdd(&s_cnt[pad32(grid_bucket<AL>(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2], ox, oy, oz, inv_h))], 1);
   __syncthreads();
   // exclusive scan: each thread owns PER consecutive buckets
   int local = 0;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
   __syncthreads();
   for (int k = tid; k < n; k += 1024) {
     const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const int pos = atomicAdd(&s_cnt[pad32(grid_bucket<AL>(x, y, z, inv_h))], 1);
+    const int pos = atomicAdd(&s_cnt[pad32(grid_bucket<AL>(x, y, z, ox, oy, oz, inv_h))], 1);
     sorted[pos] = make_float4(x, y, z, __int_as_float(k));
   }
 }
@@ -191,7 +196,7 @@ __device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int ns
 template <bool PAIR, int AL>
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb, int words,
-    const float* __restrict__ new_xyz_all, const int* __restrict__ cell_start,
+    const float* __restrict__ new_xyz_all, const float* __restrict__ xyz_all, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, int* __restrict__ idxa, int* __restrict__ idxb) {
   extern __shared__ unsigned s_bm[];  // [4 waves][PAIR ? 2 : 1][words]
   __shared__ int s_pref[4][32];
@@ -205,12 +210,13 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
   for (int i = lane; i < (PAIR ? 2 : 1) * words; i += 64) bma[i] = 0u;
   cell_start += (size_t)bi * (grid_t(AL) + 1);
   sorted += (size_t)bi * n;
+  const float ox = xyz_all[(size_t)bi * n * 3], oy = xyz_all[(size_t)bi * n * 3 + 1], oz = xyz_all[(size_t)bi * n * 3 + 2];
   // the centre's coordinates and its 27 bucket ranges are fetched one centre ahead (two dependent
   // global round trips that would otherwise head every centre's latency chain)
   auto fetch_cells = [&](int j, float& cx, float& cy, float& cz, int& beg, int& cnt) {
     const float* c = new_xyz_all + ((size_t)bi * m + min(j, m - 1)) * 3;
     cx = c[0]; cy = c[1]; cz = c[2];
-    const int gx = (int)floorf(cx * inv_h), gy = (int)floorf(cy * inv_h), gz = (int)floorf(cz * inv_h);
+    const int gx = (int)floorf((cx - ox) * inv_h), gy = (int)floorf((cy - oy) * inv_h), gz = (int)floorf((cz - oz) * inv_h);
     beg = 0; cnt = 0;
     if (lane < 27) {      // lanes 0..26: one neighbour cell each
       const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
@@ -299,11 +305,11 @@ extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, in
     PVN3D_LAUNCH_CHECK();                                                                       \
     if (pair)                                                                                   \
       hipLaunchKernelGGL((ball_query_grid_kernel<true, AL>), qgrid, dim3(256), qlds, st, n, m,  \
-                         inv_h, r2a, nsample0, r2b, nsample1, words, new_xyz, ws.cell_start,    \
+                         inv_h, r2a, nsample0, r2b, nsample1, words, new_xyz, xyz, ws.cell_start, \
                          ws.sorted, idx0, idx1);                                                \
     else                                                                                        \
       hipLaunchKernelGGL((ball_query_grid_kernel<false, AL>), qgrid, dim3(256), qlds, st, n, m, \
-                         inv_h, r2a, nsample0, 0.f, 0, words, new_xyz, ws.cell_start,           \
+                         inv_h, r2a, nsample0, 0.f, 0, words, new_xyz, xyz, ws.cell_start,      \
                          ws.sorted, idx0, nullptr);                                             \
   } while (0)
   if (grid_al_for(n) == 5) BQG_RUN(5); else BQG_RUN(4);

@@ -196,6 +196,52 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
   atomicAdd(gp + id[2], g * w[2]);
 }
 
+// Row-owner scatter (the forward row kernel run backwards): a workgroup owns CPB channel rows of one
+// cloud's grad_points as LDS accumulators, streams a span of unknown points -- idx / weight / grad_out
+// read with coalesced loads -- and adds the three weighted contributions with LDS float atomics; the
+// rows leave with coalesced stores (the span covers all points) or one global atomic per touched
+// element (spans split over several workgroups).  The element-per-thread kernel above issues
+// 3 * c * n global atomics per cloud: 8.6 ms of a 65 ms training step at c = 256, n = 12288, 24 frames.
+// grid: (n_jchunks, ceil(c/CPB), b); dynamic LDS = CPB*m floats.
+template <int CPB>
+__global__ __launch_bounds__(256) void three_interpolate_grad_rows_kernel(
+    int c, int n, int m, int jchunk, const float* __restrict__ grad_out, const int* __restrict__ idx,
+    const float* __restrict__ weight, float* __restrict__ grad_points) {
+  extern __shared__ float s_acc[];  // [CPB][m]
+  const int tid = threadIdx.x;
+  const int bi = blockIdx.z, c0 = blockIdx.y * CPB;
+  const int nc = min(CPB, c - c0);
+  for (int q = tid; q < nc * m; q += 256) s_acc[q] = 0.f;
+  __syncthreads();
+  const int j_begin = blockIdx.x * jchunk, j_end = min(j_begin + jchunk, n);
+  const int* ip = idx + (size_t)bi * n * 3;
+  const float* wp = weight + (size_t)bi * n * 3;
+  const float* g = grad_out + ((size_t)bi * c + c0) * n;
+  for (int j = j_begin + tid; j < j_end; j += 256) {
+    const int i0 = ip[j * 3], i1 = ip[j * 3 + 1], i2 = ip[j * 3 + 2];
+    const float w0 = wp[j * 3], w1 = wp[j * 3 + 1], w2 = wp[j * 3 + 2];
+#pragma unroll
+    for (int u = 0; u < CPB; ++u) {
+      if (u < nc) {
+        const float gv = g[(size_t)u * n + j];
+        atomicAdd(&s_acc[u * m + i0], gv * w0);
+        atomicAdd(&s_acc[u * m + i1], gv * w1);
+        atomicAdd(&s_acc[u * m + i2], gv * w2);
+      }
+    }
+  }
+  __syncthreads();
+  float* o = grad_points + ((size_t)bi * c + c0) * m;
+  if (gridDim.x == 1) {
+    for (int q = tid; q < nc * m; q += 256) o[q] = s_acc[q];
+  } else {
+    for (int q = tid; q < nc * m; q += 256) {
+      const float v = s_acc[q];
+      if (v != 0.f) atomicAdd(o + q, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pvn3d_three_nn(int b, int n, int m, const float* unknown, const float* known,
@@ -276,6 +322,39 @@ extern "C" int pvn3d_three_interpolate_grad(int b, int c, int n, int m, const fl
     hipLaunchKernelGGL(three_interpolate_scalar_kernel, dim3(pvn3d_ceil_div(m, 256), c, b),
                        dim3(256), 0, st, c, n, m, (size_t)m * 3, grad_out, idx, weight,
                        grad_points);
+    PVN3D_LAUNCH_CHECK();
+    return 0;
+  }
+  if ((size_t)m * 4 <= 64 * 1024 && n > 0) {     // rows of known points fit the LDS: row-owner scatter
+    int cpb = 4;
+    while (cpb > 1 && (size_t)cpb * m * 4 > 64 * 1024) cpb >>= 1;
+    while (cpb > 1 && cpb > c) cpb >>= 1;
+    const int rows = pvn3d_ceil_div(c, cpb);
+    // split the unknown points only when the rows alone do not fill the chip
+    int jch = pvn3d_ceil_div(2048, rows * b);
+    if (jch < 1) jch = 1;
+    int jchunk = pvn3d_ceil_div(pvn3d_ceil_div(n, jch), 256) * 256;
+    if (jchunk < 1024) jchunk = 1024;
+    jch = pvn3d_ceil_div(n, jchunk);
+    if (jch > 1) PVN3D_RETURN_IF_ERR(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, st));
+    const size_t lds = (size_t)cpb * m * sizeof(float);
+    switch (cpb) {
+      case 4:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_grad_rows_kernel<4>));
+        hipLaunchKernelGGL(three_interpolate_grad_rows_kernel<4>, dim3(jch, rows, b), dim3(256), lds, st, c, n, m,
+                           jchunk, grad_out, idx, weight, grad_points);
+        break;
+      case 2:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_grad_rows_kernel<2>));
+        hipLaunchKernelGGL(three_interpolate_grad_rows_kernel<2>, dim3(jch, rows, b), dim3(256), lds, st, c, n, m,
+                           jchunk, grad_out, idx, weight, grad_points);
+        break;
+      default:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_grad_rows_kernel<1>));
+        hipLaunchKernelGGL(three_interpolate_grad_rows_kernel<1>, dim3(jch, rows, b), dim3(256), lds, st, c, n, m,
+                           jchunk, grad_out, idx, weight, grad_points);
+        break;
+    }
     PVN3D_LAUNCH_CHECK();
     return 0;
   }

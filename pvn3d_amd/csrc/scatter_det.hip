@@ -116,8 +116,8 @@ int det_prepare(void* ws, size_t ws_bytes, size_t count, const float* g, size_t 
     const int wb = (int)((w_count + 256 * 8 - 1) / (256 * 8)) < 1024 ? (int)((w_count + 256 * 8 - 1) / (256 * 8)) : 1024;
     hipLaunchKernelGGL(absmax_kernel, dim3(wb > 0 ? wb : 1), dim3(256), 0, st, w, w_count, out->amax + 1);
   } else {
-    const unsigned one = 0x3f800000u;
-    PVN3D_RETURN_IF_ERR(hipMemcpyAsync(out->amax + 1, &one, sizeof(unsigned), hipMemcpyHostToDevice, st));
+    // |w|max = 1.0f, written by the device (an async copy from a stack variable could outlive it)
+    PVN3D_RETURN_IF_ERR(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out->amax + 1), 0x3f800000, 1, st));
   }
   PVN3D_LAUNCH_CHECK();
   return 0;

@@ -5,6 +5,7 @@ summation order is fixed, so the loss is bit-reproducible.  ``FocalLoss`` (:13-4
 segmentation loss, not on the hot path) is provided in plain torch so that
 ``from lib.loss import OFLoss, FocalLoss`` keeps working when this module is substituted."""
 import torch
+from torch.amp import custom_bwd, custom_fwd
 from torch.nn.modules.loss import _Loss
 
 from .._lib import lib, check
@@ -16,6 +17,7 @@ def _stream(t):
 
 class _OfL1Loss(torch.autograd.Function):
     @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # fp32 loss inside a bf16 autocast region
     def forward(ctx, pred_ofsts, kp_targ_ofst, w_labels):
         bs, n_kpts, n_pts, c = pred_ofsts.shape
         pred = pred_ofsts.contiguous()
@@ -29,6 +31,7 @@ class _OfL1Loss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @custom_bwd(device_type="cuda")
     def backward(ctx, grad_loss):
         pred, targ, w_labels, wsum = ctx.saved_tensors
         bs, n_kpts, n_pts, c = pred.shape
@@ -53,6 +56,8 @@ def of_l1_loss(pred_ofsts, kp_targ_ofst, labels, sigma=1.0, normalize=True, redu
     if not pred_ofsts.is_cuda:
         raise RuntimeError("CPU not supported")
     bs, n_kpts, n_pts, c = pred_ofsts.size()
+    if pred_ofsts.dtype in (torch.bfloat16, torch.float16):
+        pred_ofsts = pred_ofsts.float()        # mixed-precision heads: the loss itself is evaluated in fp32
     if c != 3 or pred_ofsts.dtype != torch.float32:
         raise RuntimeError("pred_ofsts must be a float tensor of shape (bs, n_kpts, n_pts, 3)")
     w_labels = (labels.reshape(bs, n_pts) > 1e-8).float().contiguous()

@@ -12,6 +12,19 @@ import torch
 import torch.nn as nn
 
 
+# Bumped by invalidate_packed(): part of every cache signature below.  The per-tensor signature
+# (data_ptr, _version) does not see writes that bypass autograd's version counter (collectives, `.data`
+# updates), so code that changes weights that way calls invalidate_packed() -- sharding.broadcast_parameters
+# and train_step do.
+_WEIGHTS_EPOCH = [0]
+
+
+def invalidate_packed():
+    """Drop every cached folded/packed SharedMLP: call after changing weights or BatchNorm buffers through
+    a path that does not bump tensor._version (torch.distributed collectives, `.data` writes)."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
 class PackedMLP(object):
     """Device buffers + the host pointer arrays pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp take."""
 
@@ -71,7 +84,7 @@ def pack_shared_mlp(mlp, max_width=512, n_xyz_first=0):
     sig = []
     for t in list(mlp.parameters()) + list(mlp.buffers()):
         sig.append((t.data_ptr(), t._version))
-    sig = (tuple(sig), mlp.training, n_xyz_first)
+    sig = (tuple(sig), mlp.training, n_xyz_first, _WEIGHTS_EPOCH[0])
     cache = getattr(mlp, "_pvn3d_packed", None)
     if cache is not None and cache[0] == sig:
         return cache[1]

@@ -16,8 +16,16 @@ in one fused pass (no separate subtract / torch.cat) and accepts a precomputed `
 import torch
 import torch.nn as nn
 from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
 
 from . import _ext
+
+# Mixed-precision training (BASELINE config 5, bf16): inside a torch.autocast region the 1x1-conv GEMMs run
+# in bf16 and hand bf16 activations to these ops.  The gather / scatter kernels are fp32 (like the
+# reference's), so every differentiable op casts its floating inputs to fp32 on entry and runs with
+# autocast off (custom_fwd / custom_bwd); indices and xyz are fp32 / int32 already.
+_fwd32 = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = custom_bwd(device_type="cuda")
 
 
 class FurthestPointSampling(Function):
@@ -38,6 +46,7 @@ furthest_point_sample = FurthestPointSampling.apply
 
 class GatherOperation(Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, features, idx):
         """features (B,C,N), idx (B,npoint) -> (B,C,npoint)"""
         ctx.save_for_backward(idx)
@@ -45,6 +54,7 @@ class GatherOperation(Function):
         return _ext.gather_points(features, idx)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n_src), None
@@ -72,6 +82,7 @@ three_nn = ThreeNN.apply
 
 class ThreeInterpolate(Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, features, idx, weight):
         """features (B,c,m), idx/weight (B,n,3) -> (B,c,n)"""
         ctx.save_for_backward(idx, weight)
@@ -79,6 +90,7 @@ class ThreeInterpolate(Function):
         return _ext.three_interpolate(features, idx, weight)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
         g = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_src)
@@ -90,6 +102,7 @@ three_interpolate = ThreeInterpolate.apply
 
 class GroupingOperation(Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, features, idx):
         """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)"""
         ctx.save_for_backward(idx)
@@ -97,6 +110,7 @@ class GroupingOperation(Function):
         return _ext.group_points(features, idx)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n_src), None
@@ -125,6 +139,7 @@ class _GroupXyzFeatures(Function):
     """Fused gather + (xyz - centre) + concat; backward scatters to `features` (and xyz^T)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, xyz, new_xyz, features, idx, use_xyz):
         ctx.save_for_backward(idx)
         ctx.use_xyz = use_xyz
@@ -133,6 +148,7 @@ class _GroupXyzFeatures(Function):
         return _ext.group_xyz_features(xyz, new_xyz, features, idx, use_xyz)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         c0 = 3 if ctx.use_xyz else 0

@@ -196,12 +196,28 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     F, N = pcld.size(0), pcld.size(1)
     K = pred_kp_of.size(1)
     C = n_cls - 1
-    inst_frame = torch.arange(F, dtype=torch.int32, device=dev).repeat_interleave(C)
-    inst_cls = torch.arange(1, n_cls, dtype=torch.int32, device=dev).repeat(F)
-    n_inst = F * C
     cls_ids = torch.arange(1, n_cls, device=dev, dtype=mask.dtype).view(1, C, 1)
     present = (mask.unsqueeze(1) == cls_ids).any(dim=2)                        # (F,C)
     present0 = present          # pred_cls_ids of the reference come from the ORIGINAL mask (:49)
+    # Only the (frame, class) pairs that occur get an instance slot: ONE small device->host copy per batch
+    # (F*C flags; the reference synchronises per class and per mean-shift iteration).  With every class
+    # slot instantiated the vote buffer alone is F*C*(K+1)*N*16 bytes (2.4 GB at 64 frames, 21 classes)
+    # and every launch carries 21 - (objects in view) empty segments per frame.
+    pairs = torch.nonzero(present.cpu())                                        # (n_inst, 2) on the host
+    n_inst = int(pairs.size(0))
+    poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
+    poses_full[:, :, 0, 0] = 1.0
+    poses_full[:, :, 1, 1] = 1.0
+    poses_full[:, :, 2, 2] = 1.0
+    kps_full = torch.zeros((F, C, K + 1, 3), dtype=torch.float32, device=dev)
+    iters_full = torch.zeros((F, C, K + 1), dtype=torch.int32, device=dev)
+    if n_inst == 0:
+        return dict(poses=poses_full, present=present0, present_new=present, cls_kps=kps_full, iters=iters_full,
+                    new_mask=mask)
+    pf = pairs[:, 0].to(device=dev, dtype=torch.long)
+    pc = pairs[:, 1].to(device=dev, dtype=torch.long)
+    inst_frame = pf.to(torch.int32)
+    inst_cls = (pc + 1).to(torch.int32)
     out = None
     if use_ctr_clus_flter:
         out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
@@ -212,7 +228,9 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
                                        radius, max_iter, poll_every=poll_every,
                                        aligned32=(N % 32 == 0))
         thr = torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)).to(dev)
-        mask, present = relabel_by_centre(pcld, ctr_of[:, 0], mask, c0.view(F, C, 3), present, thr)
+        ctrs = torch.zeros((F, C, 3), dtype=torch.float32, device=dev)
+        ctrs[pf, pc] = c0
+        mask, present = relabel_by_centre(pcld, ctr_of[:, 0], mask, ctrs, present, thr)
     # per-class centre fit on the (re-labelled) mask
     out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
     votes, seg_off, seg_cnt = out
@@ -230,13 +248,15 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
     iters = torch.cat([it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)], 1)
     npts = K + 1 if use_ctr else K
-    A = mesh_kps_all.to(device=dev, dtype=torch.float32)[:, :npts].unsqueeze(0) \
-        .expand(F, C, npts, 3).contiguous().view(n_inst, npts, 3)
+    A = mesh_kps_all.to(device=dev, dtype=torch.float32)[pc, :npts].contiguous()
     B = cls_kps[:, :npts].contiguous()
-    valid = present.view(-1).to(torch.int32)
+    valid = present[pf, pc].to(torch.int32).contiguous()
     poses = best_fit_transform_batch(A, B, valid)
-    return dict(poses=poses.view(F, C, 3, 4), present=present0, present_new=present, cls_kps=cls_kps.view(F, C, K + 1, 3),
-                iters=iters.view(F, C, K + 1), new_mask=mask)
+    poses_full[pf, pc] = poses
+    kps_full[pf, pc] = cls_kps
+    iters_full[pf, pc] = iters.to(torch.int32)
+    return dict(poses=poses_full, present=present0, present_new=present, cls_kps=kps_full, iters=iters_full,
+                new_mask=mask)
 
 
 def add_adds_batch(pts_list, pred_RT, gt_RT):

@@ -23,20 +23,67 @@ LM_OBJ_DICT = {'ape': 1, 'benchvise': 2, 'cam': 4, 'can': 5, 'cat': 6, 'driller'
 LM_ID2OBJ = dict((v, k) for k, v in LM_OBJ_DICT.items())
 
 
+def _accuracy_curve_area(dists, n_total, max_dis=0.1):
+    """Area under the accuracy-vs-threshold step curve on [0, 0.1] m, scaled to 1 (what the reference's
+    VOCap returns for the sorted in-range distances and the running fraction k / n, basic_utils.py:30-42):
+    the curve steps to k / n_total at the k-th smallest distance and is held to the end of the range."""
+    d = np.sort(np.asarray(dists, dtype=np.float64))
+    d = d[d <= max_dis]
+    k = d.size
+    if k == 0:
+        return 0.0
+    edges = np.concatenate(([0.0], d, [0.1]))
+    frac = (np.arange(1, k + 1, dtype=np.float32) / np.float32(n_total)).astype(np.float64)   # fp32 like the reference
+    height = np.concatenate((frac, frac[-1:]))
+    return float(np.sum(np.diff(edges) * height) * 10.0)
+
+
 def VOCap(rec, prec):
-    """Area under the accuracy-threshold curve up to 0.1 m (reference :32-44, verbatim semantics)."""
-    idx = np.where(rec != np.inf)
-    if len(idx[0]) == 0:
-        return 0
-    rec = rec[idx]
-    prec = prec[idx]
-    mrec = np.array([0.0] + list(rec) + [0.1])
-    mpre = np.array([0.0] + list(prec) + [prec[-1]])
-    for i in range(1, prec.shape[0]):
-        mpre[i] = max(mpre[i], mpre[i - 1])
-    i = np.where(mrec[1:] != mrec[0:-1])[0] + 1
-    ap = np.sum((mrec[i] - mrec[i - 1]) * mpre[i]) * 10
-    return ap
+    """Reference signature kept (basic_utils.py:30): rec = sorted distances with out-of-range ones set to inf,
+    prec = (1..n) / n."""
+    rec = np.asarray(rec, dtype=np.float64)
+    return _accuracy_curve_area(rec[np.isfinite(rec)], len(prec))
+
+
+def read_ply_vertices(path):
+    """(n, 3) float64 vertex coordinates of a PLY file (ascii or binary little/big endian); what the
+    reference's `ply_vtx` (plyfile-based, basic_utils.py:483-495) returns."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("%s is not a PLY file" % path)
+        fmt, n_vtx, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError("%s: unterminated PLY header" % path)
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n_vtx = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError("%s: list property inside the vertex element" % path)
+                props.append((tok[2], tok[1]))
+            elif tok[0] == "end_header":
+                break
+        names = [n for n, _ in props]
+        if not all(c in names for c in "xyz"):
+            raise ValueError("%s: vertex element without x / y / z" % path)
+        if fmt == "ascii":
+            rows = np.loadtxt(f, max_rows=n_vtx, ndmin=2)
+            return np.stack([rows[:, names.index(c)] for c in "xyz"], 1).astype(np.float64)
+        code = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+                "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+                "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+        end = "<" if fmt == "binary_little_endian" else ">"
+        rec = np.dtype([(n, end + code[t]) for n, t in props])
+        data = np.frombuffer(f.read(rec.itemsize * n_vtx), dtype=rec, count=n_vtx)
+        return np.stack([data[c].astype(np.float64) for c in "xyz"], 1)
 
 
 def best_fit_transform(A, B):
@@ -79,12 +126,7 @@ class Basic_Utils(object):
 
     def cal_auc(self, add_dis, max_dis=0.1):
         """AUC of the ADD(-S) accuracy curve, in percent (reference :597-605)."""
-        D = np.array(add_dis)
-        D[np.where(D > max_dis)] = np.inf
-        D = np.sort(D)
-        n = len(add_dis)
-        acc = np.cumsum(np.ones((1, n)), dtype=np.float32) / n
-        return VOCap(D, acc) * 100
+        return _accuracy_curve_area(add_dis, len(add_dis), max_dis) * 100
 
     def cal_add_cuda(self, pred_RT, gt_RT, p3ds):
         """mean_k |pred(x_k) - gt(x_k)| as a 0-dim CUDA tensor (reference :617-623)."""
@@ -98,20 +140,32 @@ class Basic_Utils(object):
 
     def get_pointxyz(self, cls, ds_type='ycb'):
         """Mesh points of an object from the dataset tree, as the reference reads them (:497-521):
-        YCB `<ycb_root>/models/<cls>/points.xyz`; LineMOD `obj_%02d.ply` sub-sampled to 2000 points
-        is NOT reproduced (it needs plyfile and Python's `random`): pass LineMOD points through
-        ``set_pointxyz``.  The datasets are not part of this repository."""
+        YCB `<config.ycb_root>/models/<cls>/points.xyz`; LineMOD
+        `datasets/linemod/Linemod_preprocessed/models/obj_%02d.ply` (relative to the working directory, like
+        the reference; `config.lm_root` overrides the directory), millimetres -> metres, sub-sampled to 2000
+        vertices with `random.sample` as at :514-516.  ``set_pointxyz`` supplies points directly (the
+        datasets are not part of this repository).  Raises FileNotFoundError when the file is missing."""
+        import os
         key = (ds_type, self._name(cls, ds_type) if ds_type == "ycb" else int(cls))
         cache = self.__dict__.setdefault("_ptsxyz", {})
         if key in cache:
             return cache[key]
-        if ds_type != "ycb":
-            raise FileNotFoundError("LineMOD mesh points for object %s: call set_pointxyz() first" % (cls,))
-        root = getattr(self.config, "ycb_root", None) if self.config is not None else None
-        if root is None:
-            raise FileNotFoundError("config.ycb_root is not set; call set_pointxyz() or pass a config")
-        import os
-        pts = np.loadtxt(os.path.join(root, "models", "%s/points.xyz" % key[1]), dtype=np.float32)
+        if ds_type == "ycb":
+            root = getattr(self.config, "ycb_root", None) if self.config is not None else None
+            if root is None:
+                raise FileNotFoundError("YCB mesh points of %s: config.ycb_root is not set (or call set_pointxyz())" % (key[1],))
+            pts = np.loadtxt(os.path.join(root, "models", "%s/points.xyz" % key[1]), dtype=np.float32)
+        else:
+            import random
+            root = getattr(self.config, "lm_root", None) if self.config is not None else None
+            pth = os.path.join(root or "datasets/linemod/Linemod_preprocessed", "models", "obj_%02d.ply" % int(cls))
+            if not os.path.isfile(pth):
+                raise FileNotFoundError("LineMOD mesh %s not found (or call set_pointxyz())" % pth)
+            pts = read_ply_vertices(pth) / 1000.0
+            if len(pts) > 2000:
+                drop = random.sample(range(len(pts)), len(pts) - 2000)
+                pts = np.delete(pts, drop, axis=0)
+            pts = pts.astype(np.float32)
         cache[key] = pts
         return pts
 

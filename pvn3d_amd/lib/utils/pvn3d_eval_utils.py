@@ -201,9 +201,16 @@ class TorchEval(object):
         return sv_info
 
     def cal_lm_add(self, obj_id, test_occ=False, diameter_m=None):
-        """LineMOD summary for one object (reference :298-343).  diameter_m: the object's diameter
-        in metres (`lm_r_lst[obj_id]['diameter'] / 1000` from the dataset's models_info.yml)."""
+        """LineMOD summary for one object (reference :298-343).  diameter_m: the object's diameter in
+        metres; default = `lm_r_lst[obj_id]['diameter'] / 1000` of the reference's models_info.yml
+        (bundled, tools/import_obj_kps.py), as the reference looks it up at :314."""
         cls_id = obj_id
+        if diameter_m is None:
+            from ... import synth as _synth
+            z = _synth.obj_kps()
+            ids = list(z["lm_diameter_ids"])
+            if int(obj_id) in ids:
+                diameter_m = float(z["lm_diameter_mm"][ids.index(int(obj_id))]) / 1000.0
         self.cls_add_s_dis[cls_id] = self.cls_adds_dis[cls_id] if obj_id in LM_SYM_CLS_IDS \
             else self.cls_add_dis[cls_id]
         self.cls_add_s_dis[0] += self.cls_add_s_dis[cls_id]
@@ -264,18 +271,27 @@ class TorchEval(object):
             out = [[poses[f]] for f in range(poses.shape[0])]
         self.last_poses = out
         if RTs is not None and cls_ids is not None:
+            # metrics of every frame first, merged only when all of them succeeded; missing mesh points are an
+            # error (an evaluation that silently accumulates nothing reports AUC 0) unless
+            # `self.poses_only_without_mesh` is set
+            per_frame = []
             try:
                 for f in range(bs):
                     if ds_type == "ycb":
-                        add_l, adds_l = eval_metric(cls_ids[f].long(), out[f][1], out[f][0], RTs[f], masks[f],
-                                                    labels[f] if labels is not None else None, n_cls=self.n_cls,
-                                                    bs_utils=self.bs_utils)
+                        per_frame.append(eval_metric(cls_ids[f].long(), out[f][1], out[f][0], RTs[f], masks[f],
+                                                     labels[f] if labels is not None else None, n_cls=self.n_cls,
+                                                     bs_utils=self.bs_utils))
                     else:
-                        add_l, adds_l = eval_metric_lm(cls_ids[f].long(), out[f], RTs[f], masks[f],
-                                                       labels[f] if labels is not None else None, obj_id,
-                                                       n_cls=self.n_cls, bs_utils=self.bs_utils)
-                    self.cls_add_dis = self.merge_lst(self.cls_add_dis, add_l)
-                    self.cls_adds_dis = self.merge_lst(self.cls_adds_dis, adds_l)
-            except FileNotFoundError:
-                pass      # no mesh points available: poses only
+                        per_frame.append(eval_metric_lm(cls_ids[f].long(), out[f], RTs[f], masks[f],
+                                                        labels[f] if labels is not None else None, obj_id,
+                                                        n_cls=self.n_cls, bs_utils=self.bs_utils))
+            except FileNotFoundError as e:
+                if not getattr(self, "poses_only_without_mesh", False):
+                    raise RuntimeError("ground-truth poses were given but the object's mesh points are not available "
+                                       "(%s); provide the dataset files, call bs_utils.set_pointxyz(), or set "
+                                       "TorchEval.poses_only_without_mesh = True to skip ADD / ADD-S" % e)
+                per_frame = []
+            for add_l, adds_l in per_frame:
+                self.cls_add_dis = self.merge_lst(self.cls_add_dis, add_l)
+                self.cls_adds_dis = self.merge_lst(self.cls_adds_dis, adds_l)
         return out

@@ -28,6 +28,8 @@ class Conv2d(nn.Sequential):
         super(Conv2d, self).__init__()
         if activation is None:
             activation = nn.ReLU(inplace=True)
+        # (evaluating the 1x1 convolution as a batched torch.matmul instead was measured on MI355X:
+        # 95.8 vs 65.0 ms per bf16 training step of 24 frames -- MIOpen's tuned solvers win once found)
         conv = nn.Conv2d(in_size, out_size, kernel_size=kernel_size, stride=stride,
                          padding=padding, bias=bias and not bn)
         init(conv.weight)

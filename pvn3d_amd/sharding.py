@@ -85,5 +85,10 @@ def broadcast_parameters(module, src=0, group=None):
     replication guarantees implicitly)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
+    # the collective writes through data_ptr without bumping tensor._version: cached folded Conv+BN weights
+    # of the fused inference kernels would otherwise survive the update
+    from .lib.pointnet2_utils import _fused_mlp
+    _fused_mlp.invalidate_packed()

@@ -1,0 +1,88 @@
+"""One data-parallel training step of the PointNet++ voting branch (BASELINE config 5).
+
+What runs where:
+  * FPS, gather, ball query, grouping, three_nn, three_interpolate and ALL their gradients: the hand-written
+    gfx950 kernels of this package (fp32 gathers / atomic or deterministic scatters), through the reference's
+    autograd Function API (lib/pointnet2_utils/pointnet2_utils.py);
+  * the 1x1-conv SharedMLP layers (the grouped-point x MLP-weight contraction) forward and backward: plain
+    library GEMMs -- torch Conv2d / Conv1d, i.e. MIOpen / hipBLASLt on the bf16 MFMA pipes under
+    ``torch.autocast(dtype=torch.bfloat16)`` -- with fp32 master weights.  Training-mode BatchNorm needs the
+    batch statistics of every layer's pre-activation over ALL columns before the next layer can start, so the
+    single-pass fused chain of the inference path (csrc/sa_mlp.hip) does not apply here; a 1x1 convolution
+    between two materialised tensors is a plain GEMM and belongs to the vendor library;
+  * the vote loss (of_l1_loss, lib/loss.py) forward and backward: csrc/vote_loss.hip, fp32;
+  * gradient averaging across ranks: bucketed asynchronous all-reduce (sharding.all_reduce_gradients; RCCL
+    over xGMI) instead of the reference's nn.DataParallel reduce-to-GPU-0 (train_linemod_pvn3d.py:480).
+
+The reference's RGB CNN, DenseFusion and segmentation head (lib/pvn3d.py:157-322) are out of scope; the
+per-point keypoint / centre offset heads here are the minimal 1x1-conv heads needed to drive the backward of
+the hot path with the reference's own loss (train_linemod_pvn3d.py:307-375: loss_kp_of + loss_ctr_of).
+"""
+import torch
+import torch.nn as nn
+
+from . import sharding
+from .lib.loss import OFLoss
+from .lib.pointnet2_utils import _fused_mlp
+from .lib.pointnet2_msg import Pointnet2MSG
+
+
+class PointVoteNet(nn.Module):
+    """Pointnet2MSG backbone + per-point keypoint-offset and centre-offset heads.
+    forward(pointcloud (B, N, 3 + C)) -> pred_kp_of (B, K, N, 3), pred_ctr_of (B, 1, N, 3)."""
+
+    def __init__(self, input_channels=6, n_kps=8, width=128):
+        super(PointVoteNet, self).__init__()
+        self.n_kps = n_kps
+        self.backbone = Pointnet2MSG(input_channels=input_channels)
+        self.kp_head = nn.Sequential(nn.Conv1d(128, width, 1), nn.BatchNorm1d(width), nn.ReLU(inplace=True),
+                                     nn.Conv1d(width, n_kps * 3, 1))
+        self.ctr_head = nn.Sequential(nn.Conv1d(128, width, 1), nn.BatchNorm1d(width), nn.ReLU(inplace=True),
+                                      nn.Conv1d(width, 3, 1))
+
+    def forward(self, pointcloud):
+        feats = self.backbone(pointcloud)                      # (B, 128, N)
+        B, _, N = feats.shape
+        kp = self.kp_head(feats).view(B, self.n_kps, 3, N).permute(0, 1, 3, 2).contiguous()
+        ctr = self.ctr_head(feats).view(B, 1, 3, N).permute(0, 1, 3, 2).contiguous()
+        return kp, ctr
+
+
+def vote_loss(pred_kp_of, pred_ctr_of, kp_targ_ofst, ctr_targ_ofst, labels):
+    """loss_kp_of + loss_ctr_of of the reference's model_fn (train_linemod_pvn3d.py:327-336), fp32."""
+    crit = OFLoss()
+    return crit(pred_kp_of, kp_targ_ofst, labels).sum() + crit(pred_ctr_of, ctr_targ_ofst, labels).sum()
+
+
+def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_bytes=64 << 20):
+    """forward + vote loss + backward + gradient all-reduce + optimizer step.  batch: dict(pc (B,N,3+C),
+    kp_targ_ofst (B,N,K,3), ctr_targ_ofst (B,N,1,3), labels (B,N,1)).  Returns the (detached) loss."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    if autocast_dtype is not None:
+        with torch.autocast(device_type="cuda", dtype=autocast_dtype):
+            kp, ctr = model(batch["pc"])
+            loss = vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
+    else:
+        kp, ctr = model(batch["pc"])
+        loss = vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
+    loss.backward()
+    sharding.all_reduce_gradients(model.parameters(), bucket_bytes=bucket_bytes, group=group)
+    optimizer.step()
+    _fused_mlp.invalidate_packed()       # folded Conv+BN weights cached by the fused inference kernels are stale now
+    return loss.detach()
+
+
+def synthetic_batch(n_frames, n_pts, dev, seed_base=0, n_obj=None):
+    """Training batch with the tensor contract of the reference's dataset items (linemod_dataset.py:
+    cld_rgb_nrm (N, 9), kp_targ_ofst (N, K, 3), ctr_targ_ofst (N, 1, 3), labels (N,))."""
+    import numpy as np
+    from . import synth
+    n_obj = n_obj if n_obj is not None else n_pts // 4
+    fr = [synth.synth_frame(frame=seed_base + i, n_pts=n_pts, n_obj=n_obj) for i in range(n_frames)]
+    pc = np.stack([np.concatenate([f["pcld"], f["feats"].T], 1) for f in fr], 0).astype(np.float32)
+    kp_t = np.stack([np.transpose(f["pred_kp_of"], (1, 0, 2)) for f in fr], 0).astype(np.float32)      # truth + noise
+    ctr_t = np.stack([np.transpose(f["ctr_of"], (1, 0, 2)) for f in fr], 0).astype(np.float32)
+    lab = np.stack([f["mask"] for f in fr], 0).astype(np.float32)[..., None]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return dict(pc=T(pc), kp_targ_ofst=T(kp_t), ctr_targ_ofst=T(ctr_t), labels=T(lab))

@@ -519,3 +519,75 @@ def test_all_levels_equal_reference_kernels_fixture(ext, golden, dev, c):
         d2, idx = ext.three_nn(levels[l], levels[l + 1])
         assert np.array_equal(idx[0].cpu().numpy(), z["c%d_nn%d_idx" % (c, l)].astype(np.int32)), "three_nn idx %d" % l
         assert np.array_equal(d2[0].cpu().numpy(), z["c%d_nn%d_d2" % (c, l)]), "three_nn dist2 %d" % l
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE config 5: one training step (native gather / scatter ops + vote loss, library GEMMs)
+def _torch_only_ops():
+    """Grouping and interpolation written with plain torch indexing (fp32, autograd-differentiable): the
+    gradient reference for the native backward kernels."""
+    def group(xyz, new_xyz, features, idx, use_xyz):
+        B, m, ns = idx.shape
+        li = idx.long().view(B, 1, m * ns)
+        gx = torch.gather(xyz.transpose(1, 2), 2, li.expand(-1, 3, -1)).view(B, 3, m, ns) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            return gx
+        gf = torch.gather(features, 2, li.expand(-1, features.size(1), -1)).view(B, -1, m, ns)
+        return torch.cat([gx, gf], 1) if use_xyz else gf
+
+    def interp(features, idx, weight):
+        B, n, _ = idx.shape
+        li = idx.long().view(B, 1, n * 3).expand(-1, features.size(1), -1)
+        return (torch.gather(features, 2, li).view(B, -1, n, 3) * weight.unsqueeze(1)).sum(-1)
+    return group, interp
+
+
+def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
+    from pvn3d_amd import train_step as ts
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_utils as pu
+    torch.manual_seed(0)
+    batch = ts.synthetic_batch(2, 1024, dev, seed_base=50, n_obj=300)
+    model = ts.PointVoteNet().to(dev).train()
+    # scale the network down to the cloud: 1024 points
+    for sa, npoint in zip(model.backbone.SA_modules, (512, 256, 128, 32)):
+        sa.npoint = npoint
+
+    def grads(native):
+        model.zero_grad(set_to_none=True)
+        group, interp = _torch_only_ops()
+        orig = (pu.QueryAndGroup.forward, pu.three_interpolate)
+        if not native:
+            def qg_forward(self, xyz, new_xyz, features=None, idx=None):
+                if idx is None:
+                    idx = pu.ball_query(self.radius, self.nsample, xyz, new_xyz)
+                return group(xyz, new_xyz, features, idx, self.use_xyz)
+            pu.QueryAndGroup.forward = qg_forward
+            pu.three_interpolate = interp
+        try:
+            kp, ctr = model(batch["pc"])
+            loss = ts.vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
+            loss.backward()
+        finally:
+            pu.QueryAndGroup.forward, pu.three_interpolate = orig
+        return loss.item(), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    l_nat, g_nat = grads(True)
+    l_ref, g_ref = grads(False)
+    assert abs(l_nat - l_ref) <= 1e-4 * abs(l_ref)
+    assert len(g_nat) == len(g_ref) > 50
+    names = [n for n, p in model.named_parameters() if p.grad is not None]
+    # (a conv bias in front of a training-mode BatchNorm has an identically zero gradient: numerical noise
+    # only, so errors are taken relative to at least 1e-4 of the largest gradient norm; eight levels of
+    # training-mode BatchNorm over a 2-frame batch amplify the fp32 summation-order differences of the
+    # scatter kernels to ~2e-3 in the first layers)
+    floor = 1e-4 * max(b.norm().item() for b in g_ref)
+    worst = max(((a - b).norm().item() / max(b.norm().item(), floor), n) for a, b, n in zip(g_nat, g_ref, names))
+    assert worst[0] <= 5e-3, "gradient of %s differs: relative L2 error %.3g" % (worst[1], worst[0])
+    # bf16 autocast: runs, finite, close to fp32 at the loss level, and the optimizer step lowers the loss
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        kp, ctr = model(batch["pc"])
+        l_bf16 = ts.vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"]).item()
+    assert abs(l_bf16 - l_nat) <= 3e-2 * abs(l_nat)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = [ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16).item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]

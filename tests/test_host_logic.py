@@ -200,6 +200,10 @@ def test_obj_kps_fixture_equals_reference_text_files():
         n += 1
     assert n == 2 * (13 + 21)
     assert np.array_equal(z["ycb_radius"], np.loadtxt(os.path.join(ref, "ycb/dataset_config/radius.txt")))
+    import yaml
+    info = yaml.safe_load(open(os.path.join(ref, "linemod/dataset_config/models_info.yml")))
+    assert {int(i): float(d) for i, d in zip(z["lm_diameter_ids"], z["lm_diameter_mm"])} == \
+        {int(k): float(v["diameter"]) for k, v in info.items()}
 
 
-OBJ_KPS_SHA256 = "56bb1a533c1996126af150ad758d015a3e6a8379355d8acea3cae391dd9699bb"
+OBJ_KPS_SHA256 = "d037d40a5cdbae7d2fab25de91655a731d9df33ee162a8f9a496906be18f2301"

@@ -123,7 +123,7 @@ def test_host_auc_equals_reference(golden):
     import os
     # basic_utils imports the ctypes library at module level; load only the pure functions
     src = open(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "lib", "utils", "basic_utils.py")).read()
-    start = src.index("def VOCap(rec, prec):")
+    start = src.index("def _accuracy_curve_area(dists, n_total, max_dis=0.1):")
     end = src.index("def best_fit_transform(A, B):")
     ns = {}
     exec("import numpy as np\n" + src[start:end], ns)

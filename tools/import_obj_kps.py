@@ -5,6 +5,7 @@ Reads (in the build container only; /root/reference does not exist on the GPU bo
   pvn3d/datasets/linemod/lm_obj_kps/<obj>/{farthest.txt,corners.txt}   (13 objects)
   pvn3d/datasets/ycb/ycb_object_kps/<obj>/{farthest.txt,corners.txt}   (21 objects)
   pvn3d/datasets/ycb/dataset_config/{classes.txt,radius.txt}
+  pvn3d/datasets/linemod/dataset_config/models_info.yml                (object diameters, mm)
 which are what Basic_Utils.get_kps / get_ctr (pvn3d/lib/utils/basic_utils.py:541-595) and
 Config.ycb_r_lst (pvn3d/common.py:80) load.  Output: pvn3d_amd/data/obj_kps.npz
 """
@@ -32,6 +33,11 @@ for name in ycb_cls:
     out["ycb/%s/corners" % name] = np.loadtxt(os.path.join(ycb_dir, name, "corners.txt"), dtype=np.float32)
 out["ycb_classes"] = np.array(ycb_cls)
 out["ycb_radius"] = np.loadtxt(os.path.join(REF, "pvn3d/datasets/ycb/dataset_config/radius.txt")).astype(np.float64)
+import yaml
+with open(os.path.join(REF, "pvn3d/datasets/linemod/dataset_config/models_info.yml")) as f:
+    info = yaml.safe_load(f)                       # Config.lm_r_lst (pvn3d/common.py:131-133)
+out["lm_diameter_ids"] = np.array(sorted(info), dtype=np.int32)
+out["lm_diameter_mm"] = np.array([info[k]["diameter"] for k in sorted(info)], dtype=np.float64)
 out["lm_names"] = np.array(list(LM_OBJ.keys()))
 out["lm_ids"] = np.array(list(LM_OBJ.values()), dtype=np.int32)
 np.savez_compressed(OUT, **out)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel table from a rocprofv3 kernel_trace.csv: calls, mean / min duration, share, grouped by
-(short kernel name, grid, LDS bytes).  Usage: python tools/kernel_table.py trace.csv [filter]"""
+(short kernel name, grid, LDS bytes).  Usage: python tools/kernel_table.py trace.csv [filter] [--last-ms T]
+(--last-ms: only dispatches that started within the last T ms of the trace, e.g. the timed steps after a warm-up)"""
 import csv
 import re
 import sys
@@ -24,7 +25,16 @@ def short(name):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    flt = sys.argv[2] if len(sys.argv) > 2 else None
+    args = sys.argv[2:]
+    last_ms = None
+    if "--last-ms" in args:
+        i = args.index("--last-ms")
+        last_ms = float(args[i + 1])
+        del args[i:i + 2]
+    flt = args[0] if args else None
+    if last_ms is not None:
+        t_end = max(int(r["End_Timestamp"]) for r in rows)
+        rows = [r for r in rows if int(r["Start_Timestamp"]) >= t_end - last_ms * 1e6]
     groups = defaultdict(list)
     for r in rows:
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
