@@ -192,11 +192,14 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * flags: PVN3D_MS_ALIGNED32 -- the caller guarantees seg_off[s] % 32 == 0 and that rows
  * [seg_off[s], seg_off[s] + roundup32(seg_cnt[s])) belong to segment s (pvn3d_vote_compact's
  * layout does; informational).  The iteration kernel keeps two seeds per lane (packed fp32 math)
- * when max_cnt_host >= 1024 and one otherwise; both give identical bits, and
- * PVN3D_MS_FORCE_SCALAR / PVN3D_MS_FORCE_PACKED pin the choice (tests, A/B timing). */
+ * when max_cnt_host >= 1024 and one otherwise, and splits a fit's points over the four waves of a
+ * workgroup when the launch would not fill the chip; all variants give identical bits, and the
+ * PVN3D_MS_FORCE_* flags pin the choice (tests, A/B timing). */
 #define PVN3D_MS_ALIGNED32 1
 #define PVN3D_MS_FORCE_SCALAR 4
 #define PVN3D_MS_FORCE_PACKED 8
+#define PVN3D_MS_FORCE_WHOLE 16
+#define PVN3D_MS_FORCE_SPLIT 32
 size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
 int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,
                               int n_seg, int total, int max_cnt_host, float bandwidth,

@@ -163,27 +163,70 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 // PK = false: one seed per lane, 8 (fast form) or 9 VALU instructions per (seed, point) pair.
 // PK = true : two seeds per lane held as float2; the exponent and the four accumulations are packed
 //             fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 with the point operand broadcast through
-//             op_sel), 3.5 packed + 1 v_exp_f32 per pair instead of 7 + 1.  tile = 512 seeds.
-// Both evaluate, per seed, exactly the same sequence of fp32 operations (fmaf chains in the same
-// order), so the two kernels give bit-identical results.
+//             op_sel), 3.5 packed + 1 v_exp_f32 per pair instead of 7 + 1.
+// SPLIT = false: a workgroup owns 256 * S seeds, every wave walks ALL points of the fit for its seeds.
+// SPLIT = true : a workgroup owns 64 * S seeds and its four waves walk one quarter of every staged point
+//             chunk each, then add their partial sums through LDS: a workgroup's latency -- the floor
+//             of an iteration launch once only a few fits are still running (one wave alone needs 74 us
+//             for 3072 points) -- drops four-fold, for four times as many workgroups.  Chosen by the
+//             host for launches that do not fill the chip (few fits, heavy-tailed stragglers, B = 1).
+// Canonical summation order (all four variants, so that they give identical bits): per seed four
+// partial sums, one per quarter [128 w, 128 w + 128) of every 512-point chunk, each accumulated in
+// point order across the chunks; total = (P0 + P1) + (P2 + P3).
 // ---------------------------------------------------------------------------------------
 typedef float ms_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ ms_f2 ms_fma2(ms_f2 a, ms_f2 b, ms_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ ms_f2 ms_splat(float x) { return ms_f2{x, x}; }
 
-template <bool PK>
+constexpr int MS_QUARTER = MS_CHUNK / 4;
+
+// the four running sums of S seeds (S = 1: element .x only)
+struct MsAcc {
+  ms_f2 w, x, y, z;
+};
+
+template <bool PK, bool FAST>
+__device__ __forceinline__ void ms_accumulate(MsAcc& A, const float4* __restrict__ sp, int q_begin, int q_end,
+                                              ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
+#pragma unroll 4
+  for (int q = q_begin; q < q_end; ++q) {
+    const float4 a = sp[q];
+    if (PK) {
+      // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : (one subtract +) three FMAs
+      const ms_f2 e0 = FAST ? ms_splat(a.w) : ms_splat(a.w) - pcm;
+      const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), e0)));
+      const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+      A.w += w;
+      A.x = ms_fma2(w, ms_splat(a.x), A.x);
+      A.y = ms_fma2(w, ms_splat(a.y), A.y);
+      A.z = ms_fma2(w, ms_splat(a.z), A.z);
+    } else {
+      const float e0 = FAST ? a.w : a.w - pcm.x;
+      const float e = fmaf(p2z.x, a.z, fmaf(p2y.x, a.y, fmaf(p2x.x, a.x, e0)));
+      const float w = __builtin_amdgcn_exp2f(e);
+      A.w.x += w;
+      A.x.x = fmaf(w, a.x, A.x.x);
+      A.y.x = fmaf(w, a.y, A.y.x);
+      A.z.x = fmaf(w, a.z, A.z.x);
+    }
+  }
+}
+
+template <bool PK, bool SPLIT>
 __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
     unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
     int max_iter, float thresh, float kappa, float inv_kappa) {
   constexpr int S = PK ? 2 : 1;
+  constexpr int LANES = SPLIT ? 64 : MS_THREADS;     // distinct seed lanes of the workgroup
   __shared__ float4 s_pts[MS_CHUNK];
   __shared__ float s_red[2][MS_THREADS / 64];
+  __shared__ MsAcc s_part[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
   const int seg = blockIdx.y;
   const int n = seg_cnt[seg];
-  const int tile0 = blockIdx.x * (MS_THREADS * S);
+  const int tile0 = blockIdx.x * (LANES * S);
   if (tile0 >= n) return;
   unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
   if (t > 1) {
@@ -193,6 +236,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   const int base = seg_off[seg];
   const float4 org = pts[base];  // frame origin: the fit's first point
   const int tid = threadIdx.x;
+  const int sl = SPLIT ? (tid & 63) : tid;            // seed lane
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
   // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
   // |c'|^2 <= 64 (no overflow: the largest weight is exp2(|c'|^2)) the per-pair subtraction of
@@ -201,10 +246,11 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
   const bool fast = t > 1 && __uint_as_float(cmx[t - 1]) <= 64.f;
 
-  float cx[S], cy[S], cz[S], c2x[S], c2y[S], c2z[S], cm[S], sw[S], sx[S], sy[S], sz[S];
+  float cx[S], cy[S], cz[S];
+  ms_f2 p2x = ms_splat(0.f), p2y = ms_splat(0.f), p2z = ms_splat(0.f), pcm = ms_splat(0.f);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int i = tile0 + s * MS_THREADS + tid;
+    const int i = tile0 + s * LANES + sl;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) {
       if (t == 1) {
@@ -215,17 +261,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
       }
     }
     cx[s] = c.x; cy[s] = c.y; cz[s] = c.z;
-    c2x[s] = 2.f * c.x; c2y[s] = 2.f * c.y; c2z[s] = 2.f * c.z;
-    cm[s] = fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x));
-    sw[s] = sx[s] = sy[s] = sz[s] = 0.f;
+    p2x[s] = 2.f * c.x; p2y[s] = 2.f * c.y; p2z[s] = 2.f * c.z;
+    pcm[s] = fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x));
   }
-  // packed views of the per-seed state (PK only; element s = seed s of this lane)
-  ms_f2 p2x, p2y, p2z, pcm, psw, psx, psy, psz;
-  if (PK) {
-    p2x = ms_f2{c2x[0], c2x[S - 1]}; p2y = ms_f2{c2y[0], c2y[S - 1]}; p2z = ms_f2{c2z[0], c2z[S - 1]};
-    pcm = ms_f2{cm[0], cm[S - 1]};
-    psw = psx = psy = psz = ms_splat(0.f);
-  }
+  constexpr int NACC = SPLIT ? 1 : 4;
+  MsAcc acc[NACC];
+#pragma unroll
+  for (int w = 0; w < NACC; ++w) acc[w].w = acc[w].x = acc[w].y = acc[w].z = ms_splat(0.f);
 
   for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
     const int cnt = min(MS_CHUNK, n - j0);
@@ -244,68 +286,44 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     }
     __syncthreads();
     const int cnt4 = (cnt + 3) & ~3;
-    if (PK) {
-      if (fast) {
-#pragma unroll 4
-        for (int q = 0; q < cnt4; ++q) {
-          const float4 a = s_pts[q];
-          const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), ms_splat(a.w))));
-          const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-          psw += w;
-          psx = ms_fma2(w, ms_splat(a.x), psx);
-          psy = ms_fma2(w, ms_splat(a.y), psy);
-          psz = ms_fma2(w, ms_splat(a.z), psz);
-        }
-      } else {
-#pragma unroll 4
-        for (int q = 0; q < cnt4; ++q) {
-          const float4 a = s_pts[q];
-          const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), ms_splat(a.w) - pcm)));
-          const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-          psw += w;
-          psx = ms_fma2(w, ms_splat(a.x), psx);
-          psy = ms_fma2(w, ms_splat(a.y), psy);
-          psz = ms_fma2(w, ms_splat(a.z), psz);
-        }
-      }
-    } else if (fast) {
-#pragma unroll 4
-      for (int q = 0; q < cnt4; ++q) {
-        const float4 a = s_pts[q];
-        const float e = fmaf(c2z[0], a.z, fmaf(c2y[0], a.y, fmaf(c2x[0], a.x, a.w)));
-        const float w = __builtin_amdgcn_exp2f(e);
-        sw[0] += w;
-        sx[0] = fmaf(w, a.x, sx[0]);
-        sy[0] = fmaf(w, a.y, sy[0]);
-        sz[0] = fmaf(w, a.z, sz[0]);
-      }
+    if (SPLIT) {
+      const int qb = wave * MS_QUARTER, qe = min(qb + MS_QUARTER, cnt4);
+      if (fast) ms_accumulate<PK, true>(acc[0], s_pts, qb, qe, p2x, p2y, p2z, pcm);
+      else ms_accumulate<PK, false>(acc[0], s_pts, qb, qe, p2x, p2y, p2z, pcm);
     } else {
-#pragma unroll 4
-      for (int q = 0; q < cnt4; ++q) {
-        const float4 a = s_pts[q];
-        // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : one subtract + three FMAs instead of
-        // three subtracts + mul + two FMAs (the frame is centred, so magnitudes stay ~1)
-        const float e = fmaf(c2z[0], a.z, fmaf(c2y[0], a.y, fmaf(c2x[0], a.x, a.w - cm[0])));
-        const float w = __builtin_amdgcn_exp2f(e);
-        sw[0] += w;
-        sx[0] = fmaf(w, a.x, sx[0]);
-        sy[0] = fmaf(w, a.y, sy[0]);
-        sz[0] = fmaf(w, a.z, sz[0]);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int qb = w * MS_QUARTER, qe = min(qb + MS_QUARTER, cnt4);
+        if (fast) ms_accumulate<PK, true>(acc[w], s_pts, qb, qe, p2x, p2y, p2z, pcm);
+        else ms_accumulate<PK, false>(acc[w], s_pts, qb, qe, p2x, p2y, p2z, pcm);
       }
     }
   }
-  if (PK) {
-    sw[0] = psw.x; sx[0] = psx.x; sy[0] = psy.x; sz[0] = psz.x;
-    sw[S - 1] = psw.y; sx[S - 1] = psx.y; sy[S - 1] = psy.y; sz[S - 1] = psz.y;
+  // total = (P0 + P1) + (P2 + P3)
+  MsAcc tot;
+  if (SPLIT) {
+    if (wave > 0) s_part[wave - 1][sl] = acc[0];
+    __syncthreads();
+    if (wave > 0) return;
+    const MsAcc p1 = s_part[0][sl], p2 = s_part[1][sl], p3 = s_part[2][sl];
+    tot.w = (acc[0].w + p1.w) + (p2.w + p3.w);
+    tot.x = (acc[0].x + p1.x) + (p2.x + p3.x);
+    tot.y = (acc[0].y + p1.y) + (p2.y + p3.y);
+    tot.z = (acc[0].z + p1.z) + (p2.z + p3.z);
+  } else {
+    tot.w = (acc[0].w + acc[NACC > 1 ? 1 : 0].w) + (acc[NACC > 2 ? 2 : 0].w + acc[NACC > 3 ? 3 : 0].w);
+    tot.x = (acc[0].x + acc[NACC > 1 ? 1 : 0].x) + (acc[NACC > 2 ? 2 : 0].x + acc[NACC > 3 ? 3 : 0].x);
+    tot.y = (acc[0].y + acc[NACC > 1 ? 1 : 0].y) + (acc[NACC > 2 ? 2 : 0].y + acc[NACC > 3 ? 3 : 0].y);
+    tot.z = (acc[0].z + acc[NACC > 1 ? 1 : 0].z) + (acc[NACC > 2 ? 2 : 0].z + acc[NACC > 3 ? 3 : 0].z);
   }
 
   float mshift = 0.f, mcm = 0.f;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int i = tile0 + s * MS_THREADS + tid;
+    const int i = tile0 + s * LANES + sl;
     if (i < n) {
-      const float inv = 1.0f / sw[s];
-      const float nx = sx[s] * inv, ny = sy[s] * inv, nz = sz[s] * inv;
+      const float inv = 1.0f / tot.w[s];
+      const float nx = tot.x[s] * inv, ny = tot.y[s] * inv, nz = tot.z[s] * inv;
       const float ex = nx - cx[s], ey = ny - cy[s], ez = nz - cz[s];
       const float sh = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_kappa;
       mshift = fmaxf(mshift, sh);
@@ -318,6 +336,14 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   for (int o = 32; o >= 1; o >>= 1) {
     mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
     mcm = fmaxf(mcm, __shfl_xor(mcm, o, 64));
+  }
+  if (SPLIT) {          // one wave left
+    if (tid == 0) {
+      atomicMax(ms + t, __float_as_uint(mshift));
+      atomicMax(cmx + t, __float_as_uint(mcm));
+      atomicMax(iters + seg, t);
+    }
+    return;
   }
   if ((tid & 63) == 0) { s_red[0][tid >> 6] = mshift; s_red[1][tid >> 6] = mcm; }
   __syncthreads();
@@ -613,13 +639,19 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   const float d2_max = d2_threshold(bandwidth);
   const float4* P = (const float4*)pts;
 
-  // Two seeds per lane (packed fp32 math) once the largest fit fills at least two 512-seed tiles;
-  // below that the one-seed kernel has twice the workgroups.  The two kernels give identical bits
+  // Two seeds per lane (packed fp32 math) once the largest fit fills at least two 128-seed tiles.  The
+  // split-point workgroup shape (64 seed lanes, each wave a quarter of the points) is the default: measured
+  // on MI355X it is 6 % faster than whole-fit waves on the full 576-fit batch (5.65 vs 6.01 ms) and 1.6x
+  // faster when stragglers of heavy-tailed vote sets run alone (3.15 vs 5.19 ms per frame), because an
+  // iteration launch can never finish before its slowest workgroup.  All four kernels give identical bits
   // (tests/test_gpu_postproc.py); the FORCE flags exist for that test and for A/B timing.
-  bool packed = max_cnt_host >= 1024;
+  bool packed = max_cnt_host >= 256;
   if (flags & PVN3D_MS_FORCE_SCALAR) packed = false;
   if (flags & PVN3D_MS_FORCE_PACKED) packed = true;
-  const int tile = MS_THREADS * (packed ? 2 : 1);
+  bool split = true;
+  if (flags & PVN3D_MS_FORCE_WHOLE) split = false;
+  if (flags & PVN3D_MS_FORCE_SPLIT) split = true;
+  const int tile = (split ? 64 : MS_THREADS) * (packed ? 2 : 1);
   const dim3 grid_it(pvn3d_ceil_div(max_cnt_host, tile), n_seg);
   const dim3 grid_1(pvn3d_ceil_div(max_cnt_host, MS_THREADS), n_seg);
 
@@ -635,12 +667,12 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   for (int t = 1; t <= max_iter + 1; ++t) {
     const float4* cin = S.cbuf[(t - 1) & 1];
     float4* cout = S.cbuf[t & 1];
-    if (packed)
-      hipLaunchKernelGGL(ms_iter_kernel<true>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout,
-                         S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa);
-    else
-      hipLaunchKernelGGL(ms_iter_kernel<false>, grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout,
-                         S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa);
+#define MS_ITER(PK_, SP_)                                                                                    \
+  hipLaunchKernelGGL((ms_iter_kernel<PK_, SP_>), grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout, \
+                     S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa)
+    if (packed) { if (split) MS_ITER(true, true); else MS_ITER(true, false); }
+    else { if (split) MS_ITER(false, true); else MS_ITER(false, false); }
+#undef MS_ITER
     if ((rc = (int)hipGetLastError()) != 0) break;
     if (poll && (t % poll_every) == 0 && t <= max_iter) {
       hipLaunchKernelGGL(ms_poll_kernel, dim3(1), dim3(256), 0, st, S.maxshift, seg_cnt, n_seg,

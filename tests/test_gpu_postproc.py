@@ -188,9 +188,10 @@ def test_batch_of_frames_equals_per_frame_and_threadpool(dev):
     assert len(out) == 4 and np.array_equal(out[2][0], poses_b[2])
 
 
-def test_packed_and_scalar_iteration_kernels_are_bit_identical(dev):
-    """Two seeds per lane (v_pk_fma_f32) vs one: the same per-seed fp32 operation sequence, so the
-    centres, labels and iteration counts are identical bits, on tight and on heavy-tailed votes."""
+def test_iteration_kernel_variants_are_bit_identical(dev):
+    """Two seeds per lane (v_pk_fma_f32) vs one, and the four waves of a workgroup splitting the points vs
+    every wave walking all of them: the same per-seed fp32 operation sequence and summation order, so
+    the centres, labels and iteration counts are identical bits, on tight and on heavy-tailed votes."""
     from pvn3d_amd.lib.utils import _vote_engine as eng
     rng = np.random.default_rng(3)
     segs, off = [], [0]
@@ -208,14 +209,15 @@ def test_packed_and_scalar_iteration_kernels_are_bit_identical(dev):
     so = torch.tensor(off[:-1], dtype=torch.int32, device=dev)
     sc = torch.tensor([len(a) for a in segs], dtype=torch.int32, device=dev)
     outs = {}
-    for kern in ("scalar", "packed"):
+    for kern in ("scalar+whole", "packed+whole", "scalar+split", "packed+split"):
         c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern)
         l = l.cpu().numpy()
         valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)])     # rows past a segment's count are scratch
         outs[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
-    for x, y in zip(outs["scalar"], outs["packed"]):
-        assert np.array_equal(x, y)
-    assert outs["packed"][2].max() > 20       # the heavy-tailed fits really iterate
+    for kern in ("packed+whole", "scalar+split", "packed+split"):
+        for x, y in zip(outs["scalar+whole"], outs[kern]):
+            assert np.array_equal(x, y), kern
+    assert outs["packed+split"][2].max() > 20       # the heavy-tailed fits really iterate
 
 
 def test_stress_all_points_on_object_vs_oracle(dev, orc):
