@@ -168,8 +168,8 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 // SPLIT = true : a workgroup owns 64 * S seeds and its four waves walk one quarter of every staged point
 //             chunk each, then add their partial sums through LDS: a workgroup's latency -- the floor
 //             of an iteration launch once only a few fits are still running (one wave alone needs 74 us
-//             for 3072 points) -- drops four-fold, for four times as many workgroups.  Chosen by the
-//             host for launches that do not fill the chip (few fits, heavy-tailed stragglers, B = 1).
+//             for 3072 points) -- drops four-fold, for four times as many workgroups.  The
+//             default (host side, pvn3d_meanshift_fit_batch).
 // Canonical summation order (all four variants, so that they give identical bits): per seed four
 // partial sums, one per quarter [128 w, 128 w + 128) of every 512-point chunk, each accumulated in
 // point order across the chunks; total = (P0 + P1) + (P2 + P3).

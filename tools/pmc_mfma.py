@@ -4,9 +4,10 @@
 One counter pass (kernel trace + SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_WAVE_CYCLES,
 SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY) of `tools/bench_ops.py --ops msg`, then per launch:
   duration_us            End - Start of the dispatch (kernel trace of the same pass)
-  effective_clock_ghz    GRBM_GUI_ACTIVE / duration        (DVFS: MI355X_MICROARCH.md, "DVFS give-back")
-  mfma_busy              SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)   -- share of SIMD-cycles with the
-                         matrix pipe executing, at the clock the kernel actually ran at
+  effective_clock_ghz    GRBM_GUI_ACTIVE / 8 / duration    (the counter is summed over the 8 XCDs; DVFS:
+                         MI355X_MICROARCH.md, "DVFS give-back")
+  mfma_busy              SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)   -- share of SIMD-cycles with
+                         the matrix pipe executing, at the clock the kernel actually ran at
   mfma_busy_vs_sq_busy   SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)  (SQ_BUSY is summed over the 32 shader
                          engines, 32 SIMDs each) -- the same ratio from SQ's own busy window
   tflops                 algorithmic flops of the launch / duration; at_clock = 64 flop/clk/SIMD x 1024 x clock
@@ -31,6 +32,7 @@ CHAINS = [("SA0 ns16", [9, 16, 16, 32], 2048 * 16), ("SA0 ns32", [9, 32, 32, 64]
           ("FP3", [1536, 512, 512], 512), ("FP2", [768, 512, 512], 1024), ("FP1", [608, 256, 256], 2048),
           ("FP0", [262, 128, 128], 12288)]
 FRAMES = 64
+N_XCD = 8          # GRBM_GUI_ACTIVE comes back summed over the XCDs
 
 
 def main():
@@ -55,16 +57,17 @@ def main():
     for (name, dims, cols), d in zip(CHAINS, ids):
         c, (us, kern) = ctr[d], dur[d]
         fl = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * cols * FRAMES
-        clk = c["GRBM_GUI_ACTIVE"] / (us * 1e3)
+        gui = c["GRBM_GUI_ACTIVE"] / N_XCD
+        clk = gui / (us * 1e3)
         rows.append(dict(chain=name, kernel=kern, duration_us=us, effective_clock_ghz=clk,
-                         mfma_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"]),
+                         mfma_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui),
                          mfma_busy_vs_sq_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * c["SQ_BUSY_CYCLES"]),
                          tflops=fl / (us * 1e-6) / 1e12, tflops_peak_at_clock=64 * 1024 * clk * 1e9 / 1e12,
                          wave_cycles_share=dict(wait_any=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                                                 wait_inst_any=c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                                                 active_inst_any=c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]),
                          counters=c))
-        tot_fl += fl; tot_us += us; tot_busy += c["SQ_VALU_MFMA_BUSY_CYCLES"]; tot_act += c["GRBM_GUI_ACTIVE"]
+        tot_fl += fl; tot_us += us; tot_busy += c["SQ_VALU_MFMA_BUSY_CYCLES"]; tot_act += gui
     res = dict(tag=tag, command="rocprofv3 --kernel-trace --pmc %s -- python tools/bench_ops.py --ops msg --reps 1" % " ".join(CTRS),
                frames=FRAMES, launches=rows,
                total=dict(duration_us=tot_us, tflops=tot_fl / (tot_us * 1e-6) / 1e12, mfma_busy=tot_busy / (1024.0 * tot_act),

@@ -32,7 +32,7 @@ def run_pass(counter, outdir, extra=()):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "p", "--output-format", "csv", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--serial", "--steps", str(STEPS), "--warmup", str(WARMUP),
-           "--no-cpu-baseline", "--no-stage-events"] + list(extra)
+           "--no-cpu-baseline", "--no-stage-events", "--no-extra-configs"] + list(extra)
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
     per_kernel = collections.defaultdict(float)
     with open(os.path.join(outdir, "p_counter_collection.csv")) as f:
@@ -62,7 +62,7 @@ def main():
                         stages[st]["write_bytes"] += wr
                     break
     res = dict(tag=tag, command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --serial "
-               "--steps %d --warmup %d --no-cpu-baseline --no-stage-events [--ops-only]" % (STEPS, WARMUP),
+               "--steps %d --warmup %d --no-cpu-baseline --no-stage-events --no-extra-configs [--ops-only]" % (STEPS, WARMUP),
                frames_per_step=64, correction="FETCH_SIZE x2 (gfx950), KB->bytes x1024, totals / %d steps" % n_steps,
                stage_bytes_per_step={k: dict(v, total_bytes=v["read_bytes"] + v["write_bytes"]) for k, v in stages.items()},
                kernels=kernels)
