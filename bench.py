@@ -293,6 +293,25 @@ def cpu_baseline(frame, budget_s=20.0, one_thread_budget_s=8.0):
                                    seconds_per_frame=t_c))
 
 
+def gather_step_results(res, frames_local, frames_total, world, strong):
+    """The path's only collective: the per-frame result rows (3x4 pose, K+1 keypoints, iteration counts =
+    48 floats per frame) of every rank to every rank, once per batch (RCCL over xGMI on the GPU box, gloo in
+    tests/test_sharding_gloo.py; no-op at world size 1).  strong: ranks own contiguous, possibly unequal
+    blocks of `frames_total` frames (sharding.gather_frame_results -> one (frames_total, D) tensor in frame
+    order); weak: every rank owns `frames_local` frames (plain all_gather -> list of per-rank tensors)."""
+    if world == 1:
+        return None
+    from pvn3d_amd import sharding
+    rows = torch.cat([res["poses"].reshape(frames_local, -1).to(torch.float32),
+                      res["cls_kps"].reshape(frames_local, -1).to(torch.float32),
+                      res["iters"].reshape(frames_local, -1).to(torch.float32)], 1)
+    if strong:
+        return sharding.gather_frame_results(rows, frames_total)
+    bufs = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(bufs, rows)
+    return bufs
+
+
 def _median_ms(fn, reps, warm=2):
     for _ in range(warm):
         fn()
@@ -460,6 +479,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL needs it on this host driver)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
@@ -487,18 +507,7 @@ def main():
     side = torch.cuda.Stream(device=dev)
 
     def gather_results(res):
-        """The path's only collective: per-frame result rows (3x4 pose, K+1 keypoints, iteration counts) of
-        every rank to every rank, once per batch (RCCL over xGMI; no-op at world size 1)."""
-        if world == 1:
-            return None
-        rows = torch.cat([res["poses"].reshape(frames_local, -1).to(torch.float32),
-                          res["cls_kps"].reshape(frames_local, -1).to(torch.float32),
-                          res["iters"].reshape(frames_local, -1).to(torch.float32)], 1)
-        if args.strong:
-            return sharding.gather_frame_results(rows, frames_total)
-        bufs = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(bufs, rows)
-        return bufs
+        return gather_step_results(res, frames_local, frames_total, world, args.strong)
 
     def step(timer):
         if args.serial:

@@ -63,6 +63,22 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def geometry_ahead(self, pointcloud):
+        """Software pipelining across batches: enqueue the xyz-only work (FPS, ball query, three_nn of
+        every level) of `pointcloud` on the geometry stream NOW and return a handle for a later
+        ``forward(pointcloud, geometry=handle)``.  An evaluator calls this for batch s+1 before it runs
+        ``forward`` on batch s: the latency-bound FPS chain (one workgroup per cloud, ~4 ms, 64 of 256 CUs)
+        then runs beside the MFMA kernels of batch s instead of in front of those of batch s+1.  The work is
+        ordered after everything already enqueued on the current stream (the producer of `pointcloud`).
+        (Measured on the 64-frame bench: no throughput gain -- the GPU is already busy with the other island's
+        kernels while FPS runs -- so bench.py does not use it; it shortens the latency of a stream of small
+        batches.)"""
+        xyz = pointcloud[..., 0:3].contiguous()
+        # `xyz` is allocated on the current stream but read by kernels of the geometry stream after this
+        # function has returned and dropped its reference: keep the allocator from recycling it early
+        xyz.record_stream(_geo_stream(xyz.device))
+        return self._geometry_ahead(xyz)
+
     def _geometry_ahead(self, xyz):
         """Run every level's xyz-only work on the geometry stream; returns per-level results and
         the events the feature path has to wait for."""
@@ -89,8 +105,9 @@ class Pointnet2MSG(nn.Module):
                 fp_geo[i] = ((idx, weight), hand_over([idx, weight]))
         return sa_geo, fp_geo
 
-    def forward(self, pointcloud):
-        """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N)."""
+    def forward(self, pointcloud, geometry=None):
+        """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N).
+        geometry: optional handle from ``geometry_ahead(pointcloud)`` (inference fast path only)."""
         xyz, features = self._break_up_pc(pointcloud)
         if features is not None and not self.training and _pm.FUSED_INFERENCE and not torch.is_grad_enabled():
             features = pointcloud[..., 3:].transpose(1, 2)   # same values, point-major in place
@@ -106,7 +123,7 @@ class Pointnet2MSG(nn.Module):
                 l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
             return l_features[0]
         cur = torch.cuda.current_stream(xyz.device)
-        sa_geo, fp_geo = self._geometry_ahead(xyz)
+        sa_geo, fp_geo = geometry if geometry is not None else self._geometry_ahead(xyz)
         for sa, (geom, ev) in zip(self.SA_modules, sa_geo):
             cur.wait_event(ev)
             li_xyz, li_features = sa(l_xyz[-1], l_features[-1], geometry=geom)

@@ -591,3 +591,23 @@ def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     losses = [ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16).item() for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_geometry_ahead_handle_gives_the_same_forward(dev):
+    """Pointnet2MSG.geometry_ahead (xyz-only work of a batch enqueued early, for pipelining across batches)
+    + forward(geometry=handle) returns exactly what the plain forward returns, also when the handle of one
+    batch is produced while another batch's forward is in flight."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    torch.manual_seed(3)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    pcs = []
+    for i in range(2):
+        f = [synth.synth_frame(frame=80 + 2 * i + j, n_pts=12288, n_obj=3072) for j in range(2)]
+        pcs.append(torch.from_numpy(np.stack([np.concatenate([x["pcld"], x["feats"].T], 1) for x in f], 0)).to(dev))
+    with torch.no_grad():
+        want = [net(pc).clone() for pc in pcs]
+        h0 = net.geometry_ahead(pcs[0])
+        h1 = net.geometry_ahead(pcs[1])          # batch 1's geometry in flight beside batch 0's feature path
+        got0 = net(pcs[0], geometry=h0)
+        got1 = net(pcs[1], geometry=h1)
+    assert torch.equal(got0, want[0]) and torch.equal(got1, want[1])

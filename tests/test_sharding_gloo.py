@@ -100,3 +100,54 @@ def test_bucketed_gradient_all_reduce_and_weight_broadcast():
     assert all(ok for _, ok, _, _ in res)
     assert all(nb >= 2 for _, _, nb, _ in res)            # the bucket logic really split
     assert all(same for _, _, _, same in res)
+
+
+def _bench_gather_worker(rank, ws, port, frames_total, strong, q):
+    """bench.py's per-step collective (gather_step_results) on CPU tensors under gloo: the same code the
+    driver's N>1 runs execute over RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    import bench
+    from pvn3d_amd.sharding import shard_range
+    K = 8
+    if strong:
+        lo, hi = shard_range(frames_total, rank, ws)
+    else:
+        lo, hi = rank * frames_total, (rank + 1) * frames_total       # weak: frames_total per rank
+    n = hi - lo
+    fid = torch.arange(lo, hi, dtype=torch.float64)
+    res = dict(poses=fid.view(n, 1, 1).expand(n, 3, 4).clone(),                       # (n,3,4) float64 like the engine
+               cls_kps=(fid.view(n, 1, 1).expand(n, K + 1, 3) + 0.5).float().clone(),
+               iters=torch.full((n, K + 1), 4, dtype=torch.int32))
+    got = bench.gather_step_results(res, n, frames_total, ws, strong)
+    if strong:
+        ok = got.shape == (frames_total, 12 + 3 * (K + 1) + (K + 1)) and \
+            torch.equal(got[:, 0], torch.arange(frames_total, dtype=torch.float32))
+    else:
+        ok = len(got) == ws and all(torch.equal(got[r][:, 0], torch.arange(r * frames_total, (r + 1) * frames_total,
+                                                                         dtype=torch.float32)) for r in range(ws))
+    q.put((rank, bool(ok), 0.0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_bench_gather(frames_total, strong, ws=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_gather_worker, args=(r, ws, port, frames_total, strong, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(ws)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res)
+
+
+def test_bench_step_gather_strong_ragged():
+    _run_bench_gather(7, True)
+
+
+def test_bench_step_gather_weak():
+    _run_bench_gather(4, False)
