@@ -907,7 +907,7 @@ __device__ __forceinline__ void mma_pairs(f32x16 (&acc)[NT][CT], const float2* _
 }
 
 template <bool IS_SA, int NTR>
-__global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR == 1 ? 4 : (NTR == 2 ? 3 : 2)))) void mlp_chain_cols_kernel(
+__global__ __launch_bounds__(128, (!IS_SA ? 1 : (NTR <= 2 ? 4 : 2))) void mlp_chain_cols_kernel(
     MlpDesc d, SaSrc sa, FpSrc fp, int hrows, int bias_floats, int cols_total, OutDesc od) {
   extern __shared__ float s_mem[];
   const int tid = threadIdx.x, lane = tid & 63;
