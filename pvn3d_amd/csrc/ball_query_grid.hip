@@ -190,27 +190,74 @@ __device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int ns
   if (staged && lane < nsample) out[lane] = stage[lane];     // (same wave: LDS ops complete in order)
 }
 
+// ---- rank pass (the common case: <= BQG_CAND candidates) --------------------------------------------
+// The owner-lane extraction above is a nest of per-lane loops: at PVN3D's densities (10-30 hits in a
+// 12288-bit map) it costs ~250 mostly scalar (exec-mask) instructions per bitmap.  The hit-driven form has
+// no divergent loop: (1) every lane counts the bits of its WPL consecutive words and one wave scan turns
+// that into pre[w] = number of hits below word w; (2) the candidates, parked as (k | flags) during the
+// distance pass, are walked again 64 at a time and a hit writes itself to slot
+// pre[k >> 5] + popcount(bm[k >> 5] & bits below k) = its rank in ascending index order.
+constexpr int BQG_CAND = 256;
+constexpr int BQG_FLAG_A = 1 << 30, BQG_FLAG_B = 1 << 31, BQG_KMASK = BQG_FLAG_A - 1;
+
+template <int WPL>
+__device__ __forceinline__ int rank_prefix(unsigned* __restrict__ bm, unsigned short* __restrict__ pre, int lane) {
+  const int w0 = lane * WPL;
+  int below[WPL];
+  int run = 0;
+#pragma unroll
+  for (int i = 0; i < WPL; ++i) {
+    below[i] = run;
+    run += __builtin_popcount(bm[w0 + i]);
+  }
+  int total;
+  const int base = wave_excl_scan_add(run, lane, &total);
+#pragma unroll
+  for (int i = 0; i < WPL; ++i) pre[w0 + i] = (unsigned short)(base + below[i]);   // <= n <= 32768
+  return total;
+}
+
+// slots [0, min(total, nsample)) hold the hits; pad with the first hit (slot BQG_STAGE), no hit -> zeros
+__device__ __forceinline__ void emit_row(const int* __restrict__ stage, int total, int nsample,
+                                         int* __restrict__ out, int lane) {
+  const int filled = total < nsample ? total : nsample;
+  if (nsample <= BQG_STAGE) {
+    if (lane < nsample) out[lane] = total ? stage[lane < filled ? lane : BQG_STAGE] : 0;
+  } else {      // hits went straight to `out`
+    const int first = total ? stage[BQG_STAGE] : 0;
+    for (int l = filled + lane; l < nsample; l += 64) out[l] = first;
+  }
+}
+
 // one wave per centre at a time, 4 waves per workgroup, each wave works through centres
 // j = blockIdx.x*4 + wave, + 4*gridDim.x, ... (its bitmaps are cleared once: the emission leaves them
-// clean).  dynamic LDS: per wave 2 bitmaps of `words` words.
-template <bool PAIR, int AL>
+// clean).  WPL = bitmap words per lane (64 * WPL * 32 >= n).
+// dynamic LDS, per wave: bitmaps [NB][64*WPL] u32 | prefix counts [NB][64*WPL] u16.
+template <bool PAIR, int AL, int WPL>
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(
-    int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb, int words,
+    int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb,
     const float* __restrict__ new_xyz_all, const float* __restrict__ xyz_all, const int* __restrict__ cell_start,
     const float4* __restrict__ sorted, int* __restrict__ idxa, int* __restrict__ idxb) {
-  extern __shared__ unsigned s_bm[];  // [4 waves][PAIR ? 2 : 1][words]
-  __shared__ int s_pref[4][32];
-  __shared__ int s_beg[4][32];
-  __shared__ int s_stage[4][BQG_STAGE];
+  constexpr int WORDS = 64 * WPL;
+  constexpr int NB = PAIR ? 2 : 1;
+  extern __shared__ unsigned s_bm[];  // [4 waves][NB][WORDS] u32, then [4 waves][NB][WORDS] u16
+  __shared__ int2 s_cell[4][32];      // {first flat candidate of the cell, its offset in `sorted`}
+  __shared__ int s_cand[4][BQG_CAND];
+  __shared__ int s_stage[4][NB][BQG_STAGE + 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bi = blockIdx.y;
-  unsigned* bma = s_bm + (size_t)wave * (PAIR ? 2 : 1) * words;
-  unsigned* bmb = bma + words;
-  for (int i = lane; i < (PAIR ? 2 : 1) * words; i += 64) bma[i] = 0u;
+  unsigned* bma = s_bm + (size_t)wave * NB * WORDS;
+  unsigned* bmb = bma + WORDS;
+  unsigned short* prea = reinterpret_cast<unsigned short*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
+  unsigned short* preb = prea + WORDS;
+  int* stga = s_stage[wave][0];
+  int* stgb = s_stage[wave][NB - 1];
+  for (int i = lane; i < NB * WORDS; i += 64) bma[i] = 0u;
   cell_start += (size_t)bi * (grid_t(AL) + 1);
   sorted += (size_t)bi * n;
   const float ox = xyz_all[(size_t)bi * n * 3], oy = xyz_all[(size_t)bi * n * 3 + 1], oz = xyz_all[(size_t)bi * n * 3 + 2];
+  const int dcx = lane % 3 - 1, dcy = (lane / 3) % 3 - 1, dcz = lane / 9 - 1;   // lanes 0..26: one neighbour cell each
   // the centre's coordinates and its 27 bucket ranges are fetched one centre ahead (two dependent
   // global round trips that would otherwise head every centre's latency chain)
   auto fetch_cells = [&](int j, float& cx, float& cy, float& cz, int& beg, int& cnt) {
@@ -218,9 +265,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     cx = c[0]; cy = c[1]; cz = c[2];
     const int gx = (int)floorf((cx - ox) * inv_h), gy = (int)floorf((cy - oy) * inv_h), gz = (int)floorf((cz - oz) * inv_h);
     beg = 0; cnt = 0;
-    if (lane < 27) {      // lanes 0..26: one neighbour cell each
-      const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
-      const int bucket = grid_bucket_c<AL>(gx + ox, gy + oy, gz + oz);
+    if (lane < 27) {
+      const int bucket = grid_bucket_c<AL>(gx + dcx, gy + dcy, gz + dcz);
       beg = cell_start[bucket];
       cnt = cell_start[bucket + 1] - beg;
     }
@@ -234,33 +280,64 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     fetch_cells(j + 4 * gridDim.x, ncx, ncy, ncz, nbeg, ncnt);
     int total;
     const int pref = wave_excl_scan_add(cnt, lane, &total);
-    if (lane < 32) {
-      s_pref[wave][lane] = (lane < 27) ? pref : 0x7fffffff;
-      s_beg[wave][lane] = beg;
-    }
-    // (single wave: LDS writes above are ordered before the reads below by lgkmcnt waits)
+    if (lane < 32) s_cell[wave][lane] = make_int2(lane < 27 ? pref : 0x7fffffff, beg);
+    __builtin_amdgcn_wave_barrier();   // (single wave: its LDS operations complete in program order)
+    // ---- distance pass: candidates 64 at a time, hits set their bit; (k | flags) parked for the rank pass
     for (int f0 = 0; f0 < total; f0 += 64) {
       const int f = f0 + lane;
+      int parked = 0;
       if (f < total) {
-        // owner cell q: largest q with pref[q] <= f  (pref is non-decreasing, 27 entries)
+        // owner cell q: largest q with first[q] <= f (27 non-decreasing entries, padded to 32 with INT_MAX)
         int q = 0;
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) {
-          const int t = q + s;
-          if (t < 27 && s_pref[wave][t] <= f) q = t;
-        }
-        const int qbeg = s_beg[wave][q];   // (LDS, not a shuffle: the owner lane may be inactive here)
-        const int qpref = s_pref[wave][q];
-        const float4 p = sorted[qbeg + (f - qpref)];
+        for (int s = 16; s >= 1; s >>= 1) q = (s_cell[wave][q + s].x <= f) ? q + s : q;
+        const int2 cb = s_cell[wave][q];
+        const float4 p = sorted[cb.y + (f - cb.x)];
         const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         const int k = __float_as_int(p.w);
-        if (d2 < r2a) atomicOr(&bma[k >> 5], 1u << (k & 31));
-        if (PAIR && d2 < r2b) atomicOr(&bmb[k >> 5], 1u << (k & 31));
+        const bool ha = d2 < r2a, hb = PAIR && d2 < r2b;
+        if (ha) atomicOr(&bma[k >> 5], 1u << (k & 31));
+        if (hb) atomicOr(&bmb[k >> 5], 1u << (k & 31));
+        parked = k | (ha ? BQG_FLAG_A : 0) | (hb ? BQG_FLAG_B : 0);
       }
+      if (f0 < BQG_CAND) s_cand[wave][f] = parked;
     }
-    emit_from_bitmap(bma, words, nsa, idxa + ((size_t)bi * m + j) * nsa, s_stage[wave], lane);
-    if (PAIR) emit_from_bitmap(bmb, words, nsb, idxb + ((size_t)bi * m + j) * nsb, s_stage[wave], lane);
+    __builtin_amdgcn_wave_barrier();
+    int* const outa = idxa + ((size_t)bi * m + j) * nsa;
+    int* const outb = PAIR ? idxb + ((size_t)bi * m + j) * nsb : nullptr;
+    if (total <= BQG_CAND) {
+      const int ha_total = rank_prefix<WPL>(bma, prea, lane);
+      const int hb_total = PAIR ? rank_prefix<WPL>(bmb, preb, lane) : 0;
+      __builtin_amdgcn_wave_barrier();
+      int* const da = nsa <= BQG_STAGE ? stga : outa;
+      int* const db = nsb <= BQG_STAGE ? stgb : outb;
+      for (int f0 = 0; f0 < total; f0 += 64) {
+        const int c = s_cand[wave][f0 + lane];
+        const int k = c & BQG_KMASK;
+        const int wd = k >> 5;
+        const unsigned lower = (1u << (k & 31)) - 1u;
+        if (c & BQG_FLAG_A) {
+          const int r = prea[wd] + __builtin_popcount(bma[wd] & lower);
+          if (r < nsa) da[r] = k;
+          if (r == 0) stga[BQG_STAGE] = k;
+        }
+        if (PAIR && (c & BQG_FLAG_B)) {
+          const int r = preb[wd] + __builtin_popcount(bmb[wd] & lower);
+          if (r < nsb) db[r] = k;
+          if (r == 0) stgb[BQG_STAGE] = k;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NB * WPL; ++i) bma[i * 64 + lane] = 0u;   // leave the bitmaps clean for the next centre
+      emit_row(stga, ha_total, nsa, outa, lane);
+      if (PAIR) emit_row(stgb, hb_total, nsb, outb, lane);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      emit_from_bitmap(bma, WORDS, nsa, outa, stga, lane);
+      if (PAIR) emit_from_bitmap(bmb, WORDS, nsb, outb, stgb, lane);
+    }
   }
 }
 
@@ -288,32 +365,46 @@ extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, in
   grid_ws_layout(b, n, (char*)workspace, &ws);
   const float rmax = pair ? fmaxf(radius0, radius1) : radius0;
   const float inv_h = 1.0f / (rmax * 1.001f);
-  const int words = (n + 31) / 32;
-  const size_t qlds = (size_t)4 * (pair ? 2 : 1) * words * sizeof(unsigned);
+  // bitmap words per lane: 64 * wpl * 32 bits >= n, rounded up to an instantiated size
+  const int wpl_need = (n + 2047) / 2048;
+  const int al = grid_al_for(n);
+  const int wpl = al == 5 ? (wpl_need <= 4 ? 4 : wpl_need <= 6 ? 6 : wpl_need <= 8 ? 8 : 16)
+                          : (wpl_need <= 1 ? 1 : wpl_need <= 2 ? 2 : 4);
+  const size_t qlds = (size_t)4 * (pair ? 2 : 1) * 64 * wpl * (sizeof(unsigned) + sizeof(unsigned short));
   // enough workgroups to fill the chip a few times over, then several centres per wave
   int qx = pvn3d_ceil_div(m, 4);
   while (qx > 8 && (long long)qx * b > 8192) qx = (qx + 1) / 2;
   const dim3 qgrid(qx, b);
   const float r2a = radius0 * radius0, r2b = radius1 * radius1;
-#define BQG_RUN(AL)                                                                             \
-  do {                                                                                          \
-    auto bk = grid_build_kernel<AL>;                                                            \
-    const size_t blds = (size_t)(grid_t(AL) + (grid_t(AL) >> 5)) * sizeof(int);                 \
-    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(bk));                                   \
-    hipLaunchKernelGGL(bk, dim3(b), dim3(1024), blds, st, n, inv_h, xyz, ws.cell_start,         \
-                       ws.sorted);                                                              \
-    PVN3D_LAUNCH_CHECK();                                                                       \
-    if (pair)                                                                                   \
-      hipLaunchKernelGGL((ball_query_grid_kernel<true, AL>), qgrid, dim3(256), qlds, st, n, m,  \
-                         inv_h, r2a, nsample0, r2b, nsample1, words, new_xyz, xyz, ws.cell_start, \
-                         ws.sorted, idx0, idx1);                                                \
-    else                                                                                        \
-      hipLaunchKernelGGL((ball_query_grid_kernel<false, AL>), qgrid, dim3(256), qlds, st, n, m, \
-                         inv_h, r2a, nsample0, 0.f, 0, words, new_xyz, xyz, ws.cell_start,      \
-                         ws.sorted, idx0, nullptr);                                             \
+#define BQG_QUERY(AL, WPL)                                                                        \
+  do {                                                                                            \
+    if (pair)                                                                                     \
+      hipLaunchKernelGGL((ball_query_grid_kernel<true, AL, WPL>), qgrid, dim3(256), qlds, st, n,  \
+                         m, inv_h, r2a, nsample0, r2b, nsample1, new_xyz, xyz, ws.cell_start,     \
+                         ws.sorted, idx0, idx1);                                                  \
+    else                                                                                          \
+      hipLaunchKernelGGL((ball_query_grid_kernel<false, AL, WPL>), qgrid, dim3(256), qlds, st, n, \
+                         m, inv_h, r2a, nsample0, 0.f, 0, new_xyz, xyz, ws.cell_start, ws.sorted, \
+                         idx0, nullptr);                                                          \
   } while (0)
-  if (grid_al_for(n) == 5) BQG_RUN(5); else BQG_RUN(4);
-#undef BQG_RUN
+#define BQG_BUILD(AL)                                                                             \
+  do {                                                                                            \
+    auto bk = grid_build_kernel<AL>;                                                              \
+    const size_t blds = (size_t)(grid_t(AL) + (grid_t(AL) >> 5)) * sizeof(int);                   \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(bk));                                     \
+    hipLaunchKernelGGL(bk, dim3(b), dim3(1024), blds, st, n, inv_h, xyz, ws.cell_start,           \
+                       ws.sorted);                                                                \
+    PVN3D_LAUNCH_CHECK();                                                                         \
+  } while (0)
+  if (al == 5) {
+    BQG_BUILD(5);
+    if (wpl == 4) BQG_QUERY(5, 4); else if (wpl == 6) BQG_QUERY(5, 6); else if (wpl == 8) BQG_QUERY(5, 8); else BQG_QUERY(5, 16);
+  } else {
+    BQG_BUILD(4);
+    if (wpl == 1) BQG_QUERY(4, 1); else if (wpl == 2) BQG_QUERY(4, 2); else BQG_QUERY(4, 4);
+  }
+#undef BQG_QUERY
+#undef BQG_BUILD
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
