@@ -13,10 +13,10 @@
 //          the candidate set is a superset of the ball; aliased far cells only add candidates
 //          that the distance test rejects.
 //   query  (one wave per centre): the 27 bucket ranges are flattened, lanes evaluate
-//          candidates 64 at a time with EXACTLY the brute-force arithmetic
+//          candidates with EXACTLY the brute-force arithmetic
 //          (d2 = ((dx*dx + dy*dy) + dz*dz), dx = centre - point, -ffp-contract=off), and a hit
-//          sets bit k of a per-wave LDS bitmap over the index space.  Reading the bitmap back
-//          in word order yields the hits in ascending k -- no sort, any hit count.
+//          sets bit k of a per-wave LDS bitmap over the index space.  A hit's rank in ascending k is
+//          the number of set bits below bit k (prefix popcounts) -- no sort, any hit count.
 //
 // With the PVN3D level-0 shapes (n = 12288, m = 2048) ~100 candidates per centre are examined
 // instead of 12288.  Scratch (bucket offsets + the bucket-ordered copy of the cloud) is
@@ -68,7 +68,11 @@ __device__ __forceinline__ int grid_bucket(float x, float y, float z, float ox, 
 __device__ __forceinline__ int pad32(int c) { return c + (c >> 5); }
 
 // one workgroup (1024 threads) per cloud; dynamic LDS = padded bucket table (132 KiB at AL=5)
-template <int AL>
+// PPT > 0: n <= 1024 * PPT and every thread keeps its PPT points (and their buckets) in registers between
+// the histogram and the scatter pass -- all loads of a pass are then in flight together (with a
+// run-time trip count each of the two passes was a chain of n/1024 dependent global round trips:
+// 29 us for n = 12288); PPT == 0: any n, two passes over global memory.
+template <int AL, int PPT>
 __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
                                                           const float* __restrict__ xyz,
                                                           int* __restrict__ cell_start,
@@ -84,8 +88,23 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
   for (int i = tid; i < T + (T >> 5); i += 1024) s_cnt[i] = 0;
   const float ox = xyz[0], oy = xyz[1], oz = xyz[2];
   __syncthreads();
-  for (int k = tid; k < n; k += 1024)
-    atomicAdd(&s_cnt[pad32(grid_bucket<AL>(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2], ox, oy, oz, inv_h))], 1);
+  float px[PPT > 0 ? PPT : 1], py[PPT > 0 ? PPT : 1], pz[PPT > 0 ? PPT : 1];
+  int pb[PPT > 0 ? PPT : 1];
+  if (PPT > 0) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = min(tid + 1024 * i, n - 1);
+      px[i] = xyz[k * 3]; py[i] = xyz[k * 3 + 1]; pz[i] = xyz[k * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      pb[i] = pad32(grid_bucket<AL>(px[i], py[i], pz[i], ox, oy, oz, inv_h));
+      if (tid + 1024 * i < n) atomicAdd(&s_cnt[pb[i]], 1);
+    }
+  } else {
+    for (int k = tid; k < n; k += 1024)
+      atomicAdd(&s_cnt[pad32(grid_bucket<AL>(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2], ox, oy, oz, inv_h))], 1);
+  }
   __syncthreads();
   // exclusive scan: each thread owns PER consecutive buckets
   int local = 0;
@@ -113,18 +132,45 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(int n, float inv_h,
   }
   if (tid == 1023) cell_start[T] = run;
   __syncthreads();
-  for (int k = tid; k < n; k += 1024) {
-    const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const int pos = atomicAdd(&s_cnt[pad32(grid_bucket<AL>(x, y, z, ox, oy, oz, inv_h))], 1);
-    sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+  if (PPT > 0) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = tid + 1024 * i;
+      if (k < n) {
+        const int pos = atomicAdd(&s_cnt[pb[i]], 1);
+        sorted[pos] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+      }
+    }
+  } else {
+    for (int k = tid; k < n; k += 1024) {
+      const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+      const int pos = atomicAdd(&s_cnt[pad32(grid_bucket<AL>(x, y, z, ox, oy, oz, inv_h))], 1);
+      sorted[pos] = make_float4(x, y, z, __int_as_float(k));
+    }
   }
 }
+
+// ---- query ---------------------------------------------------------------------------------------------
+// One wave per centre at a time.  Per centre: (1) lanes 0..26 fetch the 27 bucket ranges (one centre ahead),
+// a wave scan flattens them; (2) distance pass: candidates 128 at a time (two per lane, both loads in flight
+// together) with EXACTLY the brute-force arithmetic, a hit sets bit k of the wave's LDS bitmap over the index
+// space and the first 128 candidates are parked as (k | flags); (3) rank pass: every lane counts the bits of
+// its WPL consecutive bitmap words and one wave scan turns that into pre[w] = number of hits below word w; the
+// candidates are walked again (parked ones from LDS, the rest evaluated again) and a hit writes itself to
+// slot pre[k >> 5] + popcount(bm[k >> 5] & bits below k) = its rank in ascending index order -- no sort, no
+// per-lane loop, any hit count.
+// The kernel is latency-bound (a chain of dependent LDS and L2 round trips per centre, LDS-limited occupancy),
+// which is why the batches are paired; measured alternatives: pulling the bits out of the bitmap with per-lane
+// loops (round 1: ~250 mostly scalar exec-mask instructions per bitmap, 170 us at level 0), half a wave per
+// centre (fewer instructions, twice the LDS per wave: 120 us against 78 us for the unpaired full wave).
+constexpr int BQG_CAND = 128;         // parked candidates per centre (one pair of batches)
+constexpr int BQG_STAGE = 64;         // rows up to this length are assembled in LDS and leave coalesced
+constexpr int BQG_FLAG_A = 1 << 30, BQG_FLAG_B = 1 << 31, BQG_KMASK = BQG_FLAG_A - 1;
 
 // exclusive prefix sum over the wave on the DPP path (row shifts, then row_bcast 15 / 31): six VALU
 // instructions, no LDS traffic (a __shfl_up ladder is six dependent ds_bpermute round trips, and a
 // centre needs three scans)
-__device__ __forceinline__ int wave_excl_scan_add(int v, int lane, int* total) {
-  (void)lane;
+__device__ __forceinline__ int wave_excl_scan_add(int v, int* total) {
   int x = v;
   x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
   x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
@@ -136,84 +182,74 @@ __device__ __forceinline__ int wave_excl_scan_add(int v, int lane, int* total) {
   return x - v;
 }
 
-// Pull the hits of one bitmap out in ascending index order.  words = ceil(n/32) <= 1024.
-// The row is assembled in a wave-private LDS staging line `stage` (BQG_STAGE ints) and leaves with one
-// coalesced store per 64 slots: the lanes find their hits at different times, and 4-byte stores issued
-// one lane at a time cost a memory transaction each.
-constexpr int BQG_STAGE = 64;
-__device__ __forceinline__ void emit_from_bitmap(unsigned* bm, int words, int nsample,
-                                                 int* __restrict__ out, int* __restrict__ stage, int lane) {
-  // lane owns WPL consecutive words
-  const int wpl = (words + 63) >> 6;
-  const int w0 = lane * wpl;
-  int mine = 0;
-  for (int i = 0; i < wpl; ++i) {
-    const int w = w0 + i;
-    if (w < words) mine += __builtin_popcount(bm[w]);
+// Candidates f and f + 64 of the centre (total >= 1): owner cell q = largest q with first[q] <= f (27
+// non-decreasing entries, padded to 32 with INT_MAX), then the brute-force distance test(s).  Both searches
+// and both loads are independent, so their LDS / L2 round trips overlap; lanes past the end evaluate the last
+// candidate and drop the result.  Returns k | flags (0 past the end).
+template <bool PAIR>
+__device__ __forceinline__ void eval_pair(int f, int total, const int2* __restrict__ cell,
+                                          const float4* __restrict__ sorted, float cx, float cy, float cz,
+                                          float r2a, float r2b, int (&parked)[2]) {
+  int fc[2], q[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) { fc[x] = min(f + 64 * x, total - 1); q[x] = 0; }
+#pragma unroll
+  for (int s = 16; s >= 1; s >>= 1) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) q[x] = (cell[q[x] + s].x <= fc[x]) ? q[x] + s : q[x];
   }
-  int total;
-  int rank = wave_excl_scan_add(mine, lane, &total);
-  // first hit (smallest index) = first set bit overall
-  const unsigned long long has = __ballot(mine > 0);
-  int first = 0;
-  if (has) {
-    const int fl = __builtin_ctzll(has);
-    int f = 0;
-    if (lane == fl) {
-      for (int i = 0; i < wpl; ++i) {
-        const unsigned v = bm[w0 + i];
-        if (v) { f = (w0 + i) * 32 + __builtin_ctz(v); break; }
-      }
-    }
-    first = __builtin_amdgcn_readlane(f, fl);
+  float4 p[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int2 cb = cell[q[x]];
+    p[x] = sorted[cb.y + (fc[x] - cb.x)];
   }
-  const bool staged = nsample <= BQG_STAGE;
-  int* dst = staged ? stage : out;
-  if (mine > 0) {
-    for (int i = 0; i < wpl; ++i) {
-      const int w = w0 + i;
-      if (w >= words) break;
-      unsigned v = bm[w];
-      if (!v) continue;
-      bm[w] = 0u;  // leave the bitmap clean for the next centre
-      while (v && rank < nsample) {
-        const int bit = __builtin_ctz(v);
-        v &= v - 1;
-        dst[rank++] = w * 32 + bit;
-      }
-      if (v) rank += __builtin_popcount(v);
-    }
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const float dx = cx - p[x].x, dy = cy - p[x].y, dz = cz - p[x].z;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const int c = __float_as_int(p[x].w) | (d2 < r2a ? BQG_FLAG_A : 0) | ((PAIR && d2 < r2b) ? BQG_FLAG_B : 0);
+    parked[x] = (f + 64 * x < total) ? c : 0;
   }
-  // pad slots [min(total, nsample), nsample) with the first hit; no hit -> zeros
-  const int filled = total < nsample ? total : nsample;
-  for (int l = filled + lane; l < nsample; l += 64) dst[l] = first;
-  if (staged && lane < nsample) out[lane] = stage[lane];     // (same wave: LDS ops complete in order)
 }
 
-// ---- rank pass (the common case: <= BQG_CAND candidates) --------------------------------------------
-// The owner-lane extraction above is a nest of per-lane loops: at PVN3D's densities (10-30 hits in a
-// 12288-bit map) it costs ~250 mostly scalar (exec-mask) instructions per bitmap.  The hit-driven form has
-// no divergent loop: (1) every lane counts the bits of its WPL consecutive words and one wave scan turns
-// that into pre[w] = number of hits below word w; (2) the candidates, parked as (k | flags) during the
-// distance pass, are walked again 64 at a time and a hit writes itself to slot
-// pre[k >> 5] + popcount(bm[k >> 5] & bits below k) = its rank in ascending index order.
-constexpr int BQG_CAND = 256;
-constexpr int BQG_FLAG_A = 1 << 30, BQG_FLAG_B = 1 << 31, BQG_KMASK = BQG_FLAG_A - 1;
-
 template <int WPL>
-__device__ __forceinline__ int rank_prefix(unsigned* __restrict__ bm, unsigned short* __restrict__ pre, int lane) {
+__device__ __forceinline__ int rank_prefix(const unsigned* __restrict__ bm, unsigned short* __restrict__ pre, int lane) {
   const int w0 = lane * WPL;
+  unsigned w[WPL];
+  if constexpr (WPL % 4 == 0) {
+#pragma unroll
+    for (int g = 0; g < WPL / 4; ++g) {
+      const uint4 v = reinterpret_cast<const uint4*>(bm + w0)[g];
+      w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+    }
+  } else if constexpr (WPL % 2 == 0) {
+#pragma unroll
+    for (int g = 0; g < WPL / 2; ++g) {
+      const uint2 v = reinterpret_cast<const uint2*>(bm + w0)[g];
+      w[2 * g] = v.x; w[2 * g + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) w[i] = bm[w0 + i];
+  }
   int below[WPL];
   int run = 0;
 #pragma unroll
   for (int i = 0; i < WPL; ++i) {
     below[i] = run;
-    run += __builtin_popcount(bm[w0 + i]);
+    run += __builtin_popcount(w[i]);
   }
   int total;
-  const int base = wave_excl_scan_add(run, lane, &total);
+  const int base = wave_excl_scan_add(run, &total);
+  if constexpr (WPL % 2 == 0) {        // counts <= n <= 32768 fit 16 bits
 #pragma unroll
-  for (int i = 0; i < WPL; ++i) pre[w0 + i] = (unsigned short)(base + below[i]);   // <= n <= 32768
+    for (int g = 0; g < WPL / 2; ++g)
+      reinterpret_cast<unsigned*>(pre + w0)[g] = (unsigned)(base + below[2 * g]) | ((unsigned)(base + below[2 * g + 1]) << 16);
+  } else {
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) pre[w0 + i] = (unsigned short)(base + below[i]);
+  }
   return total;
 }
 
@@ -223,16 +259,15 @@ __device__ __forceinline__ void emit_row(const int* __restrict__ stage, int tota
   const int filled = total < nsample ? total : nsample;
   if (nsample <= BQG_STAGE) {
     if (lane < nsample) out[lane] = total ? stage[lane < filled ? lane : BQG_STAGE] : 0;
-  } else {      // hits went straight to `out`
+  } else {      // the hits went straight to `out`
     const int first = total ? stage[BQG_STAGE] : 0;
     for (int l = filled + lane; l < nsample; l += 64) out[l] = first;
   }
 }
 
-// one wave per centre at a time, 4 waves per workgroup, each wave works through centres
-// j = blockIdx.x*4 + wave, + 4*gridDim.x, ... (its bitmaps are cleared once: the emission leaves them
-// clean).  WPL = bitmap words per lane (64 * WPL * 32 >= n).
-// dynamic LDS, per wave: bitmaps [NB][64*WPL] u32 | prefix counts [NB][64*WPL] u16.
+// 4 waves per workgroup, each wave works through centres j = blockIdx.x*4 + wave, + 4*gridDim.x, ... (its
+// bitmaps are cleared once: every centre leaves them clean).  WPL = bitmap words per lane (64 * WPL * 32 >= n).
+// dynamic LDS: per wave bitmaps [NB][64*WPL] u32, then (after all waves) prefix counts [NB][64*WPL] u16.
 template <bool PAIR, int AL, int WPL>
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     int n, int m, float inv_h, float r2a, int nsa, float r2b, int nsb,
@@ -240,20 +275,23 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
     const float4* __restrict__ sorted, int* __restrict__ idxa, int* __restrict__ idxb) {
   constexpr int WORDS = 64 * WPL;
   constexpr int NB = PAIR ? 2 : 1;
-  extern __shared__ unsigned s_bm[];  // [4 waves][NB][WORDS] u32, then [4 waves][NB][WORDS] u16
+  extern __shared__ __align__(16) unsigned s_bm[];
   __shared__ int2 s_cell[4][32];      // {first flat candidate of the cell, its offset in `sorted`}
   __shared__ int s_cand[4][BQG_CAND];
   __shared__ int s_stage[4][NB][BQG_STAGE + 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bi = blockIdx.y;
-  unsigned* bma = s_bm + (size_t)wave * NB * WORDS;
-  unsigned* bmb = bma + WORDS;
-  unsigned short* prea = reinterpret_cast<unsigned short*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
-  unsigned short* preb = prea + WORDS;
-  int* stga = s_stage[wave][0];
-  int* stgb = s_stage[wave][NB - 1];
-  for (int i = lane; i < NB * WORDS; i += 64) bma[i] = 0u;
+  unsigned* const bma = s_bm + (size_t)wave * NB * WORDS;
+  unsigned* const bmb = bma + (NB - 1) * WORDS;
+  unsigned short* const prea = reinterpret_cast<unsigned short*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
+  unsigned short* const preb = prea + (NB - 1) * WORDS;
+  const int2* const cell = s_cell[wave];
+  int* const cand = s_cand[wave];
+  int* const stga = s_stage[wave][0];
+  int* const stgb = s_stage[wave][NB - 1];
+#pragma unroll
+  for (int i = 0; i < NB * WPL; ++i) bma[i * 64 + lane] = 0u;
   cell_start += (size_t)bi * (grid_t(AL) + 1);
   sorted += (size_t)bi * n;
   const float ox = xyz_all[(size_t)bi * n * 3], oy = xyz_all[(size_t)bi * n * 3 + 1], oz = xyz_all[(size_t)bi * n * 3 + 2];
@@ -271,73 +309,68 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
       cnt = cell_start[bucket + 1] - beg;
     }
   };
+  const int stride = 4 * gridDim.x;
   float ncx, ncy, ncz;
   int nbeg, ncnt;
   fetch_cells(blockIdx.x * 4 + wave, ncx, ncy, ncz, nbeg, ncnt);
-  for (int j = blockIdx.x * 4 + wave; j < m; j += 4 * gridDim.x) {
+  for (int j = blockIdx.x * 4 + wave; j < m; j += stride) {
     const float cx = ncx, cy = ncy, cz = ncz;
     const int beg = nbeg, cnt = ncnt;
-    fetch_cells(j + 4 * gridDim.x, ncx, ncy, ncz, nbeg, ncnt);
+    fetch_cells(j + stride, ncx, ncy, ncz, nbeg, ncnt);
     int total;
-    const int pref = wave_excl_scan_add(cnt, lane, &total);
+    const int pref = wave_excl_scan_add(cnt, &total);
     if (lane < 32) s_cell[wave][lane] = make_int2(lane < 27 ? pref : 0x7fffffff, beg);
     __builtin_amdgcn_wave_barrier();   // (single wave: its LDS operations complete in program order)
-    // ---- distance pass: candidates 64 at a time, hits set their bit; (k | flags) parked for the rank pass
-    for (int f0 = 0; f0 < total; f0 += 64) {
-      const int f = f0 + lane;
-      int parked = 0;
-      if (f < total) {
-        // owner cell q: largest q with first[q] <= f (27 non-decreasing entries, padded to 32 with INT_MAX)
-        int q = 0;
+    // ---- distance pass
+    for (int f0 = 0; f0 < total; f0 += 128) {
+      int parked[2];
+      eval_pair<PAIR>(f0 + lane, total, cell, sorted, cx, cy, cz, r2a, r2b, parked);
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) q = (s_cell[wave][q + s].x <= f) ? q + s : q;
-        const int2 cb = s_cell[wave][q];
-        const float4 p = sorted[cb.y + (f - cb.x)];
-        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        const int k = __float_as_int(p.w);
-        const bool ha = d2 < r2a, hb = PAIR && d2 < r2b;
-        if (ha) atomicOr(&bma[k >> 5], 1u << (k & 31));
-        if (hb) atomicOr(&bmb[k >> 5], 1u << (k & 31));
-        parked = k | (ha ? BQG_FLAG_A : 0) | (hb ? BQG_FLAG_B : 0);
+      for (int x = 0; x < 2; ++x) {
+        const int k = parked[x] & BQG_KMASK;
+        if (parked[x] & BQG_FLAG_A) atomicOr(&bma[k >> 5], 1u << (k & 31));
+        if (PAIR && (parked[x] & BQG_FLAG_B)) atomicOr(&bmb[k >> 5], 1u << (k & 31));
       }
-      if (f0 < BQG_CAND) s_cand[wave][f] = parked;
+      if (f0 == 0) { cand[lane] = parked[0]; cand[64 + lane] = parked[1]; }
     }
+    __builtin_amdgcn_wave_barrier();
+    // ---- rank pass
+    const int ha_total = rank_prefix<WPL>(bma, prea, lane);
+    const int hb_total = PAIR ? rank_prefix<WPL>(bmb, preb, lane) : 0;
     __builtin_amdgcn_wave_barrier();
     int* const outa = idxa + ((size_t)bi * m + j) * nsa;
     int* const outb = PAIR ? idxb + ((size_t)bi * m + j) * nsb : nullptr;
-    if (total <= BQG_CAND) {
-      const int ha_total = rank_prefix<WPL>(bma, prea, lane);
-      const int hb_total = PAIR ? rank_prefix<WPL>(bmb, preb, lane) : 0;
-      __builtin_amdgcn_wave_barrier();
-      int* const da = nsa <= BQG_STAGE ? stga : outa;
-      int* const db = nsb <= BQG_STAGE ? stgb : outb;
-      for (int f0 = 0; f0 < total; f0 += 64) {
-        const int c = s_cand[wave][f0 + lane];
-        const int k = c & BQG_KMASK;
-        const int wd = k >> 5;
-        const unsigned lower = (1u << (k & 31)) - 1u;
-        if (c & BQG_FLAG_A) {
-          const int r = prea[wd] + __builtin_popcount(bma[wd] & lower);
-          if (r < nsa) da[r] = k;
-          if (r == 0) stga[BQG_STAGE] = k;
-        }
-        if (PAIR && (c & BQG_FLAG_B)) {
-          const int r = preb[wd] + __builtin_popcount(bmb[wd] & lower);
-          if (r < nsb) db[r] = k;
-          if (r == 0) stgb[BQG_STAGE] = k;
+    int* const da = nsa <= BQG_STAGE ? stga : outa;
+    int* const db = nsb <= BQG_STAGE ? stgb : outb;
+    for (int f0 = 0; f0 < total; f0 += 128) {
+      int c[2];
+      if (f0 == 0) { c[0] = cand[lane]; c[1] = cand[64 + lane]; }
+      else eval_pair<PAIR>(f0 + lane, total, cell, sorted, cx, cy, cz, r2a, r2b, c);
+      int k[2], ra[2], rb[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {     // (all reads first: the two candidates' LDS round trips overlap)
+        k[x] = c[x] & BQG_KMASK;
+        const int wd = k[x] >> 5;
+        const unsigned lower = (1u << (k[x] & 31)) - 1u;
+        ra[x] = (c[x] & BQG_FLAG_A) ? (int)prea[wd] + __builtin_popcount(bma[wd] & lower) : 0x7fffffff;
+        rb[x] = (PAIR && (c[x] & BQG_FLAG_B)) ? (int)preb[wd] + __builtin_popcount(bmb[wd] & lower) : 0x7fffffff;
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        if (ra[x] < nsa) da[ra[x]] = k[x];
+        if (ra[x] == 0) stga[BQG_STAGE] = k[x];
+        if (PAIR) {
+          if (rb[x] < nsb) db[rb[x]] = k[x];
+          if (rb[x] == 0) stgb[BQG_STAGE] = k[x];
         }
       }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < NB * WPL; ++i) bma[i * 64 + lane] = 0u;   // leave the bitmaps clean for the next centre
-      emit_row(stga, ha_total, nsa, outa, lane);
-      if (PAIR) emit_row(stgb, hb_total, nsb, outb, lane);
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      emit_from_bitmap(bma, WORDS, nsa, outa, stga, lane);
-      if (PAIR) emit_from_bitmap(bmb, WORDS, nsb, outb, stgb, lane);
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < NB * WPL; ++i) bma[i * 64 + lane] = 0u;   // leave the bitmaps clean for the next centre
+    emit_row(stga, ha_total, nsa, outa, lane);
+    if (PAIR) emit_row(stgb, hb_total, nsb, outb, lane);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -378,18 +411,21 @@ extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, in
   const float r2a = radius0 * radius0, r2b = radius1 * radius1;
 #define BQG_QUERY(AL, WPL)                                                                        \
   do {                                                                                            \
-    if (pair)                                                                                     \
-      hipLaunchKernelGGL((ball_query_grid_kernel<true, AL, WPL>), qgrid, dim3(256), qlds, st, n,  \
-                         m, inv_h, r2a, nsample0, r2b, nsample1, new_xyz, xyz, ws.cell_start,     \
-                         ws.sorted, idx0, idx1);                                                  \
-    else                                                                                          \
-      hipLaunchKernelGGL((ball_query_grid_kernel<false, AL, WPL>), qgrid, dim3(256), qlds, st, n, \
-                         m, inv_h, r2a, nsample0, 0.f, 0, new_xyz, xyz, ws.cell_start, ws.sorted, \
-                         idx0, nullptr);                                                          \
+    if (pair) {                                                                                   \
+      auto qk = ball_query_grid_kernel<true, AL, WPL>;                                            \
+      if (qlds > 48 * 1024) PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(qk));             \
+      hipLaunchKernelGGL(qk, qgrid, dim3(256), qlds, st, n, m, inv_h, r2a, nsample0, r2b,         \
+                         nsample1, new_xyz, xyz, ws.cell_start, ws.sorted, idx0, idx1);           \
+    } else {                                                                                      \
+      auto qk = ball_query_grid_kernel<false, AL, WPL>;                                           \
+      if (qlds > 48 * 1024) PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(qk));             \
+      hipLaunchKernelGGL(qk, qgrid, dim3(256), qlds, st, n, m, inv_h, r2a, nsample0, 0.f, 0,      \
+                         new_xyz, xyz, ws.cell_start, ws.sorted, idx0, nullptr);                  \
+    }                                                                                             \
   } while (0)
-#define BQG_BUILD(AL)                                                                             \
+#define BQG_BUILD(AL, PPT)                                                                        \
   do {                                                                                            \
-    auto bk = grid_build_kernel<AL>;                                                              \
+    auto bk = grid_build_kernel<AL, PPT>;                                                         \
     const size_t blds = (size_t)(grid_t(AL) + (grid_t(AL) >> 5)) * sizeof(int);                   \
     PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(bk));                                     \
     hipLaunchKernelGGL(bk, dim3(b), dim3(1024), blds, st, n, inv_h, xyz, ws.cell_start,           \
@@ -397,10 +433,10 @@ extern "C" int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, in
     PVN3D_LAUNCH_CHECK();                                                                         \
   } while (0)
   if (al == 5) {
-    BQG_BUILD(5);
+    if (n <= 12288) BQG_BUILD(5, 12); else BQG_BUILD(5, 0);
     if (wpl == 4) BQG_QUERY(5, 4); else if (wpl == 6) BQG_QUERY(5, 6); else if (wpl == 8) BQG_QUERY(5, 8); else BQG_QUERY(5, 16);
   } else {
-    BQG_BUILD(4);
+    if (n <= 2048) BQG_BUILD(4, 2); else BQG_BUILD(4, 8);
     if (wpl == 1) BQG_QUERY(4, 1); else if (wpl == 2) BQG_QUERY(4, 2); else BQG_QUERY(4, 4);
   }
 #undef BQG_QUERY

@@ -209,7 +209,7 @@ def test_sa_fp_modules_run_and_match_unfused_composition(dev, orc):
     assert up.shape == (b, 32, n) and torch.isfinite(up).all()
 
 
-@pytest.mark.parametrize("case", ["scene", "dense", "negative_far", "dups", "tiny_radius", "single"])
+@pytest.mark.parametrize("case", ["scene", "dense", "negative_far", "dups", "tiny_radius", "single", "large_n", "mid_n", "n6000_odd_m"])
 def test_ball_query_grid_path_index_exact(ext, orc, dev, case):
     """Clouds with n >= _ext.GRID_MIN_N go through the uniform-grid kernel: identical to the oracle,
     including >64 hits per ball, toroidal aliasing (points > 32 cells away), negative coordinates,
@@ -229,6 +229,18 @@ def test_ball_query_grid_path_index_exact(ext, orc, dev, case):
         base = (g.normal(size=(1, n // 4, 3)) * 0.2).astype(np.float32)
         xyz = np.tile(base, (1, 4, 1))
         r0, ns0, r1, ns1 = 0.01, 16, 0.05, 32
+    elif case == "large_n":                   # 16 bitmap words per lane, two-pass grid build, rows longer than a wave
+        n = 20000
+        xyz = clouds(8, 1, n, 0.1)
+        r0, ns0, r1, ns1 = 0.02, 16, 0.06, 100
+    elif case == "mid_n":                     # 8 bitmap words per lane; sparse and crowded balls in one cloud
+        n = 16000
+        xyz = np.concatenate([clouds(9, 1, n // 2, 0.1), (g.normal(size=(1, n // 2, 3)) * 0.02).astype(np.float32)], 1)
+        r0, ns0, r1, ns1 = 0.015, 16, 0.03, 32
+    elif case == "n6000_odd_m":               # small-table grid with 8 bitmap words per lane; odd number of centres
+        n, m = 6000, 333
+        xyz = clouds(10, 2, n, 0.1)
+        r0, ns0, r1, ns1 = 0.03, 16, 0.06, 48
     elif case == "tiny_radius":               # most balls contain only the centre itself
         xyz = clouds(6, 1, n, 0.0)
         r0, ns0, r1, ns1 = 1e-4, 4, 2e-4, 4
