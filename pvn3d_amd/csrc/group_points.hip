@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(
 // more row blocks (gridDim.y = ceil(c/CPB) + 3), block ceil(c/CPB) + k stages coordinate k of the cloud
 // (AoS (b,n,3), strided read) and writes out[b][k][p] = xyz[idx[p]][k] - new_xyz[p / nsample][k]; the
 // feature rows then start at channel 3 (pointnet2_utils.py:311-321: grouped_xyz -= new_xyz; cat).
-template <int CPB>
-__global__ __launch_bounds__(256) void group_points_rows_kernel(
+template <int CPB, int NTHR>
+__global__ __launch_bounds__(NTHR) void group_points_rows_kernel(
     int c, int n, int P, int pchunk, const float* __restrict__ points,
     const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride,
     const float* __restrict__ xyz, const float* __restrict__ new_xyz, int nsample) {
@@ -79,13 +79,13 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
   if (by >= feat_rows) {          // relative-xyz channel k (only launched with xyz != nullptr)
     const int k = by - feat_rows;
     const float* xb = xyz + (size_t)bi * n * 3 + k;
-    for (int q = tid; q < n; q += 256) s_row[q] = xb[(size_t)q * 3];
+    for (int q = tid; q < n; q += NTHR) s_row[q] = xb[(size_t)q * 3];
     __syncthreads();
     const int* ip = idx + (size_t)bi * P;
     const float* cb = new_xyz + (size_t)bi * (P / nsample) * 3 + k;
     float* o = out + (size_t)bi * out_batch_stride + (size_t)k * P;
     const int p_end = min(bx * pchunk + pchunk, P);
-    for (int p = bx * pchunk + tid * 4; p < p_end; p += 1024) {
+    for (int p = bx * pchunk + tid * 4; p < p_end; p += 4 * NTHR) {
       const int4 id = *reinterpret_cast<const int4*>(ip + p);
       v4f val;
       if ((nsample & 3) == 0) {      // the four positions share one centre
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
   const int n4 = n >> 2;
   const float4* row = reinterpret_cast<const float4*>(points + ((size_t)bi * c + c0) * n);
   float4* s4 = reinterpret_cast<float4*>(s_row);
-  for (int q = tid; q < nc * n4; q += 256) s4[q] = row[q];
+  for (int q = tid; q < nc * n4; q += NTHR) s4[q] = row[q];
   __syncthreads();
   const int p_begin = bx * pchunk;
   const int p_end = min(p_begin + pchunk, P);
@@ -115,7 +115,41 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
   // for their write acknowledgements too; issued before them it only needs vmcnt(#stores).
   int p = p_begin + tid * 4;
   int4 id = *reinterpret_cast<const int4*>(ip + min(p, P - 4));
-  if (nc == CPB) {
+  if (CPB == 1) {
+    // One row of a large cloud (48 KiB of LDS at n = 12288).  gfx950 counts loads and stores in one in-order
+    // vmcnt, so waiting for the idx vectors requested ahead also waits for the PREVIOUS trip's stores to be
+    // acknowledged by HBM (~2.5 us per trip, measured): the bytes a CU keeps in flight are what bounds this
+    // kernel, hence 1024 threads on the staged row (two workgroups = 32 waves per CU) and two position vectors
+    // per thread and trip.
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr int U = 2, STEP = 4 * NTHR;
+    v4i idv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) idv[u] = *reinterpret_cast<const v4i*>(ip + min(p + STEP * u, P - 4));
+    while (p + STEP * (U - 1) < p_end) {
+      const int pn = p + STEP * U;
+      v4i idn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int* nptr = ip + min(pn + STEP * u, P - 4);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(idn[u]) : "v"(nptr) : "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v4f val = {s_row[idv[u].x], s_row[idv[u].y], s_row[idv[u].z], s_row[idv[u].w]};
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + p + STEP * u));
+      }
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(idn[0]), "+v"(idn[1]) : : "memory");
+#pragma unroll
+      for (int u = 0; u < U; ++u) idv[u] = idn[u];
+      p = pn;
+    }
+    for (; p < p_end; p += STEP) {
+      id = *reinterpret_cast<const int4*>(ip + p);
+      v4f val = {s_row[id.x], s_row[id.y], s_row[id.z], s_row[id.w]};
+      __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + p));
+    }
+  } else if (nc == CPB) {
     // Full row group: the next idx vector is requested BEFORE this iteration's stores and awaited
     // after them with s_waitcnt vmcnt(CPB) -- loads and stores share one in-order counter on
     // gfx950, so "CPB younger operations may be outstanding" is exactly "the idx load has
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
     typedef int v4i __attribute__((ext_vector_type(4)));
     v4i idv = {id.x, id.y, id.z, id.w};
     while (p < p_end) {
-      const int pn = p + 1024;
+      const int pn = p + 4 * NTHR;
       const int* nptr = ip + min(pn, P - 4);
       v4i idn;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(idn) : "v"(nptr) : "memory");
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(256) void group_points_rows_kernel(
       p = pn;
     }
   } else {
-    for (; p < p_end; p += 1024) {
+    for (; p < p_end; p += 4 * NTHR) {
       id = *reinterpret_cast<const int4*>(ip + p);
       for (int u = 0; u < nc; ++u) {
         const float* sr = s_row + u * n;
@@ -258,29 +292,24 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     while (cpb > 1 && (size_t)cpb * n * 4 > 16 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb) + (xyz ? 3 : 0);
-    // split the position range until there are a few thousand workgroups
-    int pch = pvn3d_ceil_div(4096, rows * b);
+    // split the position range until there are a few thousand workgroups (of 256 threads; the single-row
+    // kernel runs 1024 threads on a row and wants long position spans per staged row)
+    const int nthr = cpb == 1 ? 1024 : 256;
+    int pch = pvn3d_ceil_div(cpb == 1 ? 1024 : 4096, rows * b);
     if (pch < 1) pch = 1;
-    int pchunk = pvn3d_ceil_div(pvn3d_ceil_div(P, pch), 1024) * 1024;
-    if (pchunk < 4096) pchunk = 4096;
+    int pchunk = pvn3d_ceil_div(pvn3d_ceil_div(P, pch), 4 * nthr) * 4 * nthr;
+    if (pchunk < 16 * nthr) pchunk = 16 * nthr;
     pch = pvn3d_ceil_div(P, pchunk);
     const size_t lds = (size_t)cpb * n * sizeof(float);
-#define GP_ARGS c, n, P, pchunk, points, idx, out, out_batch_stride, xyz, new_xyz, nsample
-    switch (cpb) {
-      case 4:
-        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<4>));
-        hipLaunchKernelGGL(group_points_rows_kernel<4>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
-        break;
-      case 2:
-        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<2>));
-        hipLaunchKernelGGL(group_points_rows_kernel<2>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
-        break;
-      default:
-        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(group_points_rows_kernel<1>));
-        hipLaunchKernelGGL(group_points_rows_kernel<1>, dim3(pch, rows, b), dim3(256), lds, st, GP_ARGS);
-        break;
-    }
-#undef GP_ARGS
+#define GP_LAUNCH(CPB, NTHR)                                                                      \
+  do {                                                                                            \
+    auto gk = group_points_rows_kernel<CPB, NTHR>;                                                \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(gk));                                     \
+    hipLaunchKernelGGL(gk, dim3(pch, rows, b), dim3(NTHR), lds, st, c, n, P, pchunk, points, idx, \
+                       out, out_batch_stride, xyz, new_xyz, nsample);                             \
+  } while (0)
+    if (cpb == 4) GP_LAUNCH(4, 256); else if (cpb == 2) GP_LAUNCH(2, 256); else GP_LAUNCH(1, 1024);
+#undef GP_LAUNCH
   } else if (xyz) {
     return 1;
   } else if (aligned) {
