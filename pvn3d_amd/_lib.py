@@ -70,3 +70,19 @@ def check(rc, what):
     """Non-zero return (a hipError_t) -> RuntimeError, like AT_CHECK in the reference glue."""
     if rc != 0:
         raise RuntimeError("%s failed: hipError %d" % (what, rc))
+
+
+import contextlib as _contextlib
+
+_NO_SWITCH = _contextlib.nullcontext()
+
+
+def on_device(dev):
+    """Context for a library call on `dev`: torch.cuda.device(dev) only when `dev` is not already the
+    current device (entering / leaving that context costs two driver calls, ~10 us of host time per
+    operator -- more than the short kernels of the small pyramid levels take)."""
+    import torch
+    idx = dev.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(dev)

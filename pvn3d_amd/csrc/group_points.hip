@@ -288,7 +288,7 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     // rows per workgroup: measured best (MI355X, 64 clouds) with ~16 KiB of LDS per workgroup,
     // at most 4 rows: n=2048 -> 2 (4.2 TB/s), n=1024 -> 4 (4.6 TB/s), n=512 -> 4 (4.3 TB/s);
     // tile-owner and direct-gather variants measured 1.8-3.0 TB/s and were removed
-    int cpb = 4;
+    int cpb = 8;
     while (cpb > 1 && (size_t)cpb * n * 4 > 16 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb) + (xyz ? 3 : 0);
@@ -308,7 +308,7 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     hipLaunchKernelGGL(gk, dim3(pch, rows, b), dim3(NTHR), lds, st, c, n, P, pchunk, points, idx, \
                        out, out_batch_stride, xyz, new_xyz, nsample);                             \
   } while (0)
-    if (cpb == 4) GP_LAUNCH(4, 256); else if (cpb == 2) GP_LAUNCH(2, 256); else GP_LAUNCH(1, 1024);
+    if (cpb == 8) GP_LAUNCH(8, 256); else if (cpb == 4) GP_LAUNCH(4, 256); else if (cpb == 2) GP_LAUNCH(2, 256); else GP_LAUNCH(1, 1024);
 #undef GP_LAUNCH
   } else if (xyz) {
     return 1;

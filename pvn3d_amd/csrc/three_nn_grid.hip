@@ -127,10 +127,13 @@ __global__ __launch_bounds__(1024) void nn_grid_build_kernel(int m, float h_scal
   for (int i = 0; i < PER; ++i) {
     const int c = s_cnt[pad(tid * PER + i)];
     s_cnt[pad(tid * PER + i)] = run;      // becomes the scatter cursor
-    cell_start[tid * PER + i] = run;
     run += c;
   }
   if (tid == 1023) cell_start[NG_T] = run;
+  __syncthreads();
+  // (bucket order = coalesced stores; see grid_build_kernel in ball_query_grid.hip)
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cell_start[tid + 1024 * i] = s_cnt[pad(tid + 1024 * i)];
   __syncthreads();
   for (int k = tid; k < m; k += 1024) {
     const float x = known[k * 3], y = known[k * 3 + 1], z = known[k * 3 + 2];

@@ -8,7 +8,7 @@ import torch
 from torch.amp import custom_bwd, custom_fwd
 from torch.nn.modules.loss import _Loss
 
-from .._lib import lib, check
+from .._lib import lib, check, on_device
 
 
 def _stream(t):
@@ -24,7 +24,7 @@ class _OfL1Loss(torch.autograd.Function):
         targ = kp_targ_ofst.contiguous()
         loss = torch.empty((bs, n_kpts), dtype=torch.float32, device=pred.device)
         wsum = torch.empty((bs, n_kpts), dtype=torch.float32, device=pred.device)
-        with torch.cuda.device(pred.device):
+        with on_device(pred.device):
             check(lib.pvn3d_of_l1_loss(bs, n_kpts, n_pts, pred.data_ptr(), targ.data_ptr(), w_labels.data_ptr(),
                                        loss.data_ptr(), wsum.data_ptr(), _stream(pred)), "of_l1_loss")
         ctx.save_for_backward(pred, targ, w_labels, wsum)
@@ -37,7 +37,7 @@ class _OfL1Loss(torch.autograd.Function):
         bs, n_kpts, n_pts, c = pred.shape
         grad_pred = torch.empty_like(pred)
         g = grad_loss.contiguous().float()
-        with torch.cuda.device(pred.device):
+        with on_device(pred.device):
             check(lib.pvn3d_of_l1_loss_grad(bs, n_kpts, n_pts, pred.data_ptr(), targ.data_ptr(),
                                             w_labels.data_ptr(), wsum.data_ptr(), g.data_ptr(),
                                             grad_pred.data_ptr(), _stream(pred)), "of_l1_loss_grad")

@@ -13,7 +13,7 @@ grouped at the bottom.
 """
 import torch
 
-from ..._lib import lib, check
+from ..._lib import lib, check, on_device
 
 # Reproduce what the reference BINARY returns from three_interpolate_grad (it calls the forward
 # kernel with swapped sizes, pvn3d/_ext-src/src/interpolate.cpp:89-93).  Default: the
@@ -49,7 +49,7 @@ def furthest_point_sampling(points, nsamples):
     out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
     # the reference's (B,N) 1e10 scratch is only needed beyond the register-resident sizes
     tmp = torch.empty((B, N), dtype=torch.float32, device=points.device) if N > 16384 else None
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         check(lib.pvn3d_furthest_point_sampling(B, N, int(nsamples), points.data_ptr(),
                                                 tmp.data_ptr() if tmp is not None else None,
                                                 out.data_ptr(), _stream(points)),
@@ -65,7 +65,7 @@ def gather_points(points, idx):
     B, C, N = points.shape
     m = idx.size(1)
     out = torch.empty((B, C, m), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         check(lib.pvn3d_gather_points(B, C, N, m, points.data_ptr(), idx.data_ptr(), out.data_ptr(),
                                       _stream(points)), "gather_points")
     return out
@@ -90,12 +90,12 @@ def gather_points_grad(grad_out, idx, n):
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
     if DETERMINISTIC_GRADS:
         ws, nbytes = _det_ws(B, C, n, grad_out.device)
-        with torch.cuda.device(grad_out.device):
+        with on_device(grad_out.device):
             check(lib.pvn3d_group_points_grad_det(B, C, int(n), m, 1, grad_out.data_ptr(), idx.data_ptr(),
                                                   out.data_ptr(), ws.data_ptr(), nbytes, _stream(grad_out)),
                   "gather_points_grad_det")
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         check(lib.pvn3d_gather_points_grad(B, C, int(n), m, grad_out.data_ptr(), idx.data_ptr(),
                                            out.data_ptr(), _stream(grad_out)), "gather_points_grad")
     return out
@@ -121,7 +121,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     B, m = new_xyz.size(0), new_xyz.size(1)
     N = xyz.size(1)
     idx = torch.empty((B, m, int(nsample)), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with on_device(new_xyz.device):
         if GRID_MIN_N <= N <= GRID_MAX_N and radius > 0 and m > 0:
             ws, nbytes = _grid_ws(B, N, new_xyz.device)
             check(lib.pvn3d_ball_query_pair_grid(B, N, m, float(radius), int(nsample), 0.0, 0,
@@ -142,7 +142,7 @@ def group_points(points, idx):
     B, C, N = points.shape
     npoint, nsample = idx.size(1), idx.size(2)
     out = torch.empty((B, C, npoint, nsample), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         check(lib.pvn3d_group_points(B, C, N, npoint, nsample, points.data_ptr(), idx.data_ptr(),
                                      out.data_ptr(), _stream(points)), "group_points")
     return out
@@ -157,12 +157,12 @@ def group_points_grad(grad_out, idx, n):
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
     if DETERMINISTIC_GRADS:
         ws, nbytes = _det_ws(B, C, n, grad_out.device)
-        with torch.cuda.device(grad_out.device):
+        with on_device(grad_out.device):
             check(lib.pvn3d_group_points_grad_det(B, C, int(n), npoint, nsample, grad_out.data_ptr(),
                                                   idx.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes,
                                                   _stream(grad_out)), "group_points_grad_det")
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         check(lib.pvn3d_group_points_grad(B, C, int(n), npoint, nsample, grad_out.data_ptr(),
                                           idx.data_ptr(), out.data_ptr(), _stream(grad_out)),
               "group_points_grad")
@@ -183,7 +183,7 @@ def three_nn(unknowns, knows):
     m = knows.size(1)
     idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
     dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
-    with torch.cuda.device(unknowns.device):
+    with on_device(unknowns.device):
         if NN_GRID and NN_GRID_MIN_M <= m <= NN_GRID_MAX_M and n >= NN_GRID_MIN_N:
             # identical output; ~30x fewer distance evaluations for evenly sampled surfaces
             nbytes = int(lib.pvn3d_three_nn_grid_workspace_bytes(B, m))
@@ -207,7 +207,7 @@ def three_interpolate(points, idx, weight):
     B, C, m = points.shape
     n = idx.size(1)
     out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with on_device(points.device):
         check(lib.pvn3d_three_interpolate(B, C, m, n, points.data_ptr(), idx.data_ptr(),
                                           weight.data_ptr(), out.data_ptr(), _stream(points)),
               "three_interpolate")
@@ -225,12 +225,12 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     out = torch.empty((B, C, int(m)), dtype=torch.float32, device=grad_out.device)
     if DETERMINISTIC_GRADS and not REFERENCE_BUG_COMPAT:
         ws, nbytes = _det_ws(B, C, m, grad_out.device)
-        with torch.cuda.device(grad_out.device):
+        with on_device(grad_out.device):
             check(lib.pvn3d_three_interpolate_grad_det(B, C, n, int(m), grad_out.data_ptr(), idx.data_ptr(),
                                                        weight.data_ptr(), out.data_ptr(), ws.data_ptr(), nbytes,
                                                        _stream(grad_out)), "three_interpolate_grad_det")
         return out
-    with torch.cuda.device(grad_out.device):
+    with on_device(grad_out.device):
         check(lib.pvn3d_three_interpolate_grad(B, C, n, int(m), grad_out.data_ptr(), idx.data_ptr(),
                                                weight.data_ptr(), out.data_ptr(),
                                                1 if REFERENCE_BUG_COMPAT else 0, _stream(grad_out)),
@@ -251,7 +251,7 @@ def ball_query_pair(new_xyz, xyz, radius0, nsample0, radius1, nsample1):
     N = xyz.size(1)
     idx0 = torch.empty((B, m, int(nsample0)), dtype=torch.int32, device=new_xyz.device)
     idx1 = torch.empty((B, m, int(nsample1)), dtype=torch.int32, device=new_xyz.device)
-    with torch.cuda.device(new_xyz.device):
+    with on_device(new_xyz.device):
         if GRID_MIN_N <= N <= GRID_MAX_N and radius0 > 0 and radius1 > 0 and m > 0:
             ws, nbytes = _grid_ws(B, N, new_xyz.device)
             check(lib.pvn3d_ball_query_pair_grid(B, N, m, float(radius0), int(nsample0),
@@ -283,7 +283,7 @@ def group_xyz_features(xyz, new_xyz, features, idx, use_xyz=True):
     m, nsample = idx.size(1), idx.size(2)
     c_out = (3 if use_xyz else 0) + C
     out = torch.empty((B, c_out, m, nsample), dtype=torch.float32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         check(lib.pvn3d_group_xyz_features(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
                                            new_xyz.data_ptr(),
                                            features.data_ptr() if features is not None else None,
@@ -303,7 +303,7 @@ def _point_major(t):
     src = t if t.is_contiguous() else t.contiguous()
     ld = (C + 3) // 4 * 4
     out = torch.empty((B, n, ld), dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
+    with on_device(t.device):
         check(lib.pvn3d_transpose_bcn_to_bnc(B, C, n, src.data_ptr(), out.data_ptr(), ld, _stream(t)),
               "transpose_bcn_to_bnc")
     return out, ld
@@ -336,7 +336,7 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
         out_pm = torch.empty((B, m, (M + 3) // 4 * 4), dtype=torch.float32, device=xyz.device)
         out_coff = 0
     ld_out = out_pm.size(2)
-    with torch.cuda.device(xyz.device):
+    with on_device(xyz.device):
         check(lib.pvn3d_sa_mlp_maxpool(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
                                        new_xyz.data_ptr(), feat.data_ptr() if feat is not None else None,
                                        ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, packed.w_c,
@@ -375,7 +375,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     else:
         ld_out = 0
         out = torch.empty((B, M, n), dtype=torch.float32, device=known_feats.device)
-    with torch.cuda.device(known_feats.device):
+    with on_device(known_feats.device):
         check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                       uf.data_ptr() if uf is not None else None, ld_u,
                                       idx.data_ptr(), weight.data_ptr(), packed.n_layers,

@@ -13,7 +13,7 @@ import threading
 import numpy as np
 import torch
 
-from ..._lib import lib, check
+from ..._lib import lib, check, on_device
 
 _tls = threading.local()
 
@@ -68,7 +68,7 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     ws_bytes = int(lib.pvn3d_meanshift_workspace_bytes(n_seg, total, int(max_iter)))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     poll = _poll_buf() if poll_every > 0 else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.pvn3d_meanshift_fit_batch(
             pts4.data_ptr(), seg_off.data_ptr(), seg_cnt.data_ptr(), n_seg, total, int(max_cnt),
             float(bandwidth), int(max_iter), ctr.data_ptr(), labels.data_ptr(), iters.data_ptr(),
@@ -93,7 +93,7 @@ def vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, v_first, 
         seg_cnt = torch.zeros((n_seg,), dtype=torch.int32, device=dev)
     else:
         votes, seg_off, seg_cnt = out
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.pvn3d_vote_compact(
             F, n_pts, n_kps, n_inst, int(v_first), int(v_count), pcld.data_ptr(), mask.data_ptr(),
             ctr_of.data_ptr(), pred_kp_of.data_ptr(), inst_frame.data_ptr(), inst_cls.data_ptr(),
@@ -107,7 +107,7 @@ def best_fit_transform_batch(A, B, valid=None):
     dev = A.device
     S, npts = A.size(0), A.size(1)
     T = torch.empty((S, 3, 4), dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.pvn3d_best_fit_transform(S, npts, A.data_ptr(), B.data_ptr(),
                                            valid.data_ptr() if valid is not None else None,
                                            T.data_ptr(), _stream(dev)), "best_fit_transform")
@@ -178,7 +178,7 @@ def relabel_by_centre(pcld, ctr_of0, mask, ctrs, present, thr_lst):
     C = ctrs.size(1)
     new_mask = torch.empty_like(mask)
     present_new = torch.empty((F, C), dtype=torch.int32, device=mask.device)
-    with torch.cuda.device(mask.device):
+    with on_device(mask.device):
         check(lib.pvn3d_relabel_by_centre(F, N, C, pcld.data_ptr(), ctr_of0.contiguous().data_ptr(), mask.data_ptr(),
                                           ctrs.contiguous().data_ptr(), present.to(torch.int32).contiguous().data_ptr(),
                                           thr_lst.contiguous().data_ptr(), new_mask.data_ptr(),
@@ -285,7 +285,7 @@ def add_adds_batch(pts_list, pred_RT, gt_RT):
         return add, adds
     wsb = lib.pvn3d_add_adds_workspace_bytes(n_inst, max_pts)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.pvn3d_add_adds_batch(n_inst, max_pts, pts.data_ptr(), off.data_ptr(), pred_RT.data_ptr(),
                                        gt_RT.data_ptr(), ws.data_ptr(), wsb, add.data_ptr(), adds.data_ptr(),
                                        _stream(dev)), "add_adds_batch")
