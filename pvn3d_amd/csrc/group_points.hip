@@ -285,11 +285,13 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
   // direct-gather kernel below was measured there too and is slower still: 66 + 104 us vs 49 + 62 us)
   const bool rows_ok = aligned && (n % 4 == 0) && (size_t)n * 4 <= 128 * 1024 && (((uintptr_t)points & 15) == 0);
   if (rows_ok) {
-    // rows per workgroup: measured best (MI355X, 64 clouds) with ~16 KiB of LDS per workgroup,
-    // at most 4 rows: n=2048 -> 2 (4.2 TB/s), n=1024 -> 4 (4.6 TB/s), n=512 -> 4 (4.3 TB/s);
-    // tile-owner and direct-gather variants measured 1.8-3.0 TB/s and were removed
+    // rows per workgroup: up to 8 rows in at most 32 KiB of LDS (idx is re-read once per row group, so
+    // more rows per group = less L2 traffic per output byte; past 32 KiB the lost occupancy costs more).
+    // Measured on MI355X, 64 clouds, out bytes / time: n=2048 -> 4 rows 5.3 TB/s (2 rows: 5.0-5.1),
+    // n=1024 -> 8 rows 5.4-5.7 (4 rows: 5.1-5.5), n=512 -> 8 rows 4.4-5.2; tile-owner and direct-gather
+    // variants measured 1.8-3.0 TB/s and were removed
     int cpb = 8;
-    while (cpb > 1 && (size_t)cpb * n * 4 > 16 * 1024) cpb >>= 1;
+    while (cpb > 1 && (size_t)cpb * n * 4 > 32 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb) + (xyz ? 3 : 0);
     // split the position range until there are a few thousand workgroups (of 256 threads; the single-row
