@@ -18,10 +18,18 @@ def shard_range(n_items, rank, world_size):
     return lo, hi
 
 
-def gather_frame_results(local, n_items, group=None):
+def _single(group, skip_single):
+    """No process group, or a group of one with nothing to exchange.  skip_single=False runs the collective
+    path even then (tests/test_gpu_rccl.py drives RCCL on a one-GPU box that way)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return skip_single and dist.get_world_size(group) == 1
+
+
+def gather_frame_results(local, n_items, group=None, skip_single=True):
     """All-gather per-frame result rows: `local` (n_local, D) on every rank -> (n_items, D) in
     frame order on every rank.  Ranks may own different numbers of frames (padded exchange)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, skip_single):
         return local
     ws = dist.get_world_size(group)
     sizes = [shard_range(n_items, r, ws) for r in range(ws)]
@@ -44,11 +52,11 @@ def gather_frame_results(local, n_items, group=None):
 # (the order backward produces them) so the first buckets fly while later ones are still packed.
 # ---------------------------------------------------------------------------------------------
 
-def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=True):
+def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=True, skip_single=True):
     """Average (or sum) `.grad` of `parameters` over the process group in place.
     Returns the number of buckets used.  Parameters without a gradient are skipped on every rank
     alike (the model is the same on all ranks)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, skip_single):
         return 0
     ws = dist.get_world_size(group)
     params = [p for p in parameters if p.grad is not None]
@@ -80,10 +88,10 @@ def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=
     return len(buckets)
 
 
-def broadcast_parameters(module, src=0, group=None):
+def broadcast_parameters(module, src=0, group=None, skip_single=True):
     """Make every rank start from rank `src`'s weights and buffers (what DataParallel's per-step
     replication guarantees implicitly)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single(group, skip_single):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):

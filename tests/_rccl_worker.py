@@ -1,0 +1,58 @@
+"""Worker of tests/test_gpu_rccl.py: one rank on cuda:0 in a "nccl" (= RCCL) process group of one.
+A one-GPU box cannot host two RCCL ranks (duplicate-device check), so this drives every collective of the
+sharded path -- padded all_gather of per-frame rows, bucketed asynchronous gradient all-reduce, parameter
+broadcast, barrier + MAX all-reduce of the step time -- through RCCL with device tensors at world size 1;
+the world-size-2 arithmetic of the same helpers is covered on gloo (tests/test_sharding_gloo.py)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    from pvn3d_amd import sharding
+    from pvn3d_amd.train_step import PointVoteNet
+
+    # per-frame result rows (3x4 pose + 9 keypoints x 3 + iteration counts = 48 floats), ragged-capable gather
+    rows = torch.randn(7, 48, device=dev)
+    full = sharding.gather_frame_results(rows, 7, skip_single=False)
+    assert full.is_cuda and torch.equal(full, rows)
+
+    # bucketed asynchronous all-reduce of a real model's gradients (several buckets)
+    net = PointVoteNet().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for p in net.parameters():
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    want = [p.grad.clone() for p in net.parameters()]
+    n_buckets = sharding.all_reduce_gradients(net.parameters(), bucket_bytes=1 << 20, skip_single=False)
+    assert n_buckets > 1
+    for p, w in zip(net.parameters(), want):
+        assert torch.equal(p.grad, w)          # sum over one rank / 1
+
+    before = [t.clone() for t in net.parameters()]
+    sharding.broadcast_parameters(net, src=0, skip_single=False)
+    for p, w in zip(net.parameters(), before):
+        assert torch.equal(p, w)
+
+    # bench.py's timing reduction
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([1.25], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t.item()) == 1.25
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_WORLD1_OK buckets=%d" % n_buckets)
+
+
+if __name__ == "__main__":
+    main()
