@@ -52,10 +52,12 @@ class Pointnet2MSG(nn.Module):
         self.FP_modules.append(PointnetFPModule(mlp=[512 + c_out_1, 512, 512]))
         self.FP_modules.append(PointnetFPModule(mlp=[c_out_3 + c_out_2, 512, 512]))
 
-        # inference: intermediate FP levels hand point-major buffers (as transposed views) to the
-        # next level; the last one (FP_modules[0]) returns the reference's contiguous (B, 128, N)
+        # inference: the SA levels and the intermediate FP levels hand point-major buffers (as transposed
+        # views) to the next level; the last one (FP_modules[0]) returns the reference's contiguous (B, 128, N)
         for fp in list(self.FP_modules)[1:]:
             fp._point_major_out = True
+        for sa in self.SA_modules:
+            sa._point_major_out = True
 
     @staticmethod
     def _break_up_pc(pc):

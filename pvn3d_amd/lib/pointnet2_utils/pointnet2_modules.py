@@ -110,9 +110,8 @@ class _PointnetSAModuleBase(nn.Module):
 
     def _forward_fused(self, xyz, new_xyz, features, idxs):
         """Every scale as one fp32-MFMA kernel writing its slice of ONE point-major
-        (B, npoint, sum(mlp[-1])) buffer; returns its (B, C_out, npoint) transposed view (same
-        values as torch.cat(pooled, 1); the next fused level gathers rows from it in place), or
-        None when a scale cannot be fused."""
+        (B, npoint, sum(mlp[-1])) buffer; returns (B, C_out, npoint) with the values of
+        torch.cat(pooled, 1), or None when a scale cannot be fused."""
         packs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             if not isinstance(grouper, pointnet2_utils.QueryAndGroup):
@@ -138,7 +137,11 @@ class _PointnetSAModuleBase(nn.Module):
                     idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
             with _stage("sa_mlp"):
                 _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
-        return out_pm[:, :, :sum(widths)].transpose(1, 2)
+        out = out_pm[:, :, :sum(widths)].transpose(1, 2)
+        # Stand-alone the module returns what the reference returns: a contiguous (B, C_out, npoint) tensor
+        # (a caller may .view() it).  Pointnet2MSG marks its own levels `_point_major_out`: the next fused
+        # level gathers rows from the point-major buffer in place, so the transposed view is handed over.
+        return out if getattr(self, "_point_major_out", False) else out.contiguous()
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

@@ -299,6 +299,13 @@ def test_fused_sa_mlp_matches_unfused_modules(dev, c_in, mlps, nsamples, npoint,
     scale = out_u.abs().max().item()
     assert (out_f - out_u).abs().max().item() < 1e-4 * max(scale, 1.0)
     assert getattr(sa.mlps[0], "_pvn3d_packed")[1] is not None      # the fused path really ran
+    # stand-alone the module returns the reference's layout (a caller may .view() it); inside Pointnet2MSG the
+    # levels hand each other the point-major buffer as a transposed view
+    assert out_f.is_contiguous() and out_f.view(2, -1).shape[1] == out_f.size(1) * out_f.size(2)
+    sa._point_major_out = True
+    with torch.no_grad():
+        _, out_v = sa(xyz, feats)
+    assert not out_v.is_contiguous() and torch.equal(out_v, out_f)
 
 
 def test_fused_fp_mlp_and_full_pointnet2msg(dev):
