@@ -260,6 +260,30 @@ def test_ball_query_grid_path_index_exact(ext, orc, dev, case):
     assert np.array_equal(i1.cpu().numpy(), orc.ball_query(new_xyz, xyz, r1, ns1))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_ball_query_grid_random_shapes_index_exact(ext, orc, dev, seed):
+    """Random (n, m, radii, nsample) through the grid kernel -- n not a multiple of 32 / 64 / 1024, every bitmap
+    width, 1..130 slots per row, sparse and crowded balls, one and two radii -- against the oracle."""
+    g = np.random.default_rng(100 + seed)
+    for _ in range(3):
+        n = int(g.choice([1024, 1025, 1999, 2048, 3001, 4097, 7777, 8192, 9999, 12288, 13001, 17000, 24999, 32768]))
+        m = int(g.integers(1, 400))
+        spread = float(g.choice([0.02, 0.08, 0.3]))
+        xyz = (g.normal(size=(1, n, 3)) * spread).astype(np.float32) + g.uniform(-2, 2, size=(1, 1, 3)).astype(np.float32)
+        sel = g.permutation(n)[:m]
+        new_xyz = np.ascontiguousarray(xyz[:, sel]) + (g.normal(size=(1, m, 3)) * 1e-3).astype(np.float32)
+        r0 = float(g.uniform(0.2, 1.5)) * spread * 0.3
+        r1 = r0 * float(g.uniform(1.0, 2.5))
+        ns0, ns1 = int(g.integers(1, 131)), int(g.integers(1, 131))
+        if g.random() < 0.3:
+            got = ext.ball_query(T(new_xyz, dev), T(xyz, dev), r0, ns0).cpu().numpy()
+            assert np.array_equal(got, orc.ball_query(new_xyz, xyz, r0, ns0)), (n, m, r0, ns0)
+        else:
+            i0, i1 = ext.ball_query_pair(T(new_xyz, dev), T(xyz, dev), r0, ns0, r1, ns1)
+            assert np.array_equal(i0.cpu().numpy(), orc.ball_query(new_xyz, xyz, r0, ns0)), (n, m, r0, ns0)
+            assert np.array_equal(i1.cpu().numpy(), orc.ball_query(new_xyz, xyz, r1, ns1)), (n, m, r1, ns1)
+
+
 def _randomize_bn(module):
     g = torch.Generator().manual_seed(5)
     for m in module.modules():
