@@ -136,21 +136,46 @@ __global__ __launch_bounds__(256) void three_interpolate_rows_kernel(
   const int j_begin = blockIdx.x * jchunk;
   const int j_end = min(j_begin + jchunk, n);
   float* o = out + ((size_t)bi * c + c0) * n;
-  for (int j0 = j_begin + tid * 4; j0 < j_end; j0 += 1024) {
-    int id[12];
-    float w[12];
-    const int4* ip = reinterpret_cast<const int4*>(idx + ((size_t)bi * n + j0) * 3);
-    const float4* wp = reinterpret_cast<const float4*>(weight + ((size_t)bi * n + j0) * 3);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int* const ibase = idx + (size_t)bi * n * 3;
+  const float* const wbase = weight + (size_t)bi * n * 3;
+  int j0 = j_begin + tid * 4;
+  if (nc == CPB && j_end - j_begin > 2048) {      // (a span of one or two trips has nothing to overlap)
+    // Full row group: the next four points' idx / weight vectors (6 x 16 B) are requested BEFORE this trip's
+    // stores and awaited after them with s_waitcnt vmcnt(CPB) -- loads and stores share one in-order counter
+    // on gfx950 (see group_points.hip); left to the compiler every trip waited for the previous trip's write
+    // acknowledgements.
+    v4i ic[3], in_[3];
+    v4f wc[3], wn[3];
+    {
+      const int jc = min(j0, n - 4);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int4 a = ip[u];
-      const float4 f = wp[u];
-      id[u * 4 + 0] = a.x; id[u * 4 + 1] = a.y; id[u * 4 + 2] = a.z; id[u * 4 + 3] = a.w;
-      w[u * 4 + 0] = f.x; w[u * 4 + 1] = f.y; w[u * 4 + 2] = f.z; w[u * 4 + 3] = f.w;
+      for (int u = 0; u < 3; ++u) {
+        ic[u] = reinterpret_cast<const v4i*>(ibase + (size_t)jc * 3)[u];
+        wc[u] = reinterpret_cast<const v4f*>(wbase + (size_t)jc * 3)[u];
+      }
+      // (the compiler's own wait for these six loads stays outside the loop)
+      asm volatile("" : "+v"(ic[0]), "+v"(ic[1]), "+v"(ic[2]), "+v"(wc[0]), "+v"(wc[1]), "+v"(wc[2]));
     }
+    while (j0 < j_end) {
+      const int jn = min(j0 + 1024, n - 4);
+      const v4i* ipn = reinterpret_cast<const v4i*>(ibase + (size_t)jn * 3);
+      const v4f* wpn = reinterpret_cast<const v4f*>(wbase + (size_t)jn * 3);
 #pragma unroll
-    for (int ch = 0; ch < CPB; ++ch) {
-      if (ch < nc) {
+      for (int u = 0; u < 3; ++u) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(in_[u]) : "v"(ipn + u) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wn[u]) : "v"(wpn + u) : "memory");
+      }
+      int id[12];
+      float w[12];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        id[u * 4 + 0] = ic[u].x; id[u * 4 + 1] = ic[u].y; id[u * 4 + 2] = ic[u].z; id[u * 4 + 3] = ic[u].w;
+        w[u * 4 + 0] = wc[u].x; w[u * 4 + 1] = wc[u].y; w[u * 4 + 2] = wc[u].z; w[u * 4 + 3] = wc[u].w;
+      }
+#pragma unroll
+      for (int ch = 0; ch < CPB; ++ch) {
         const float* sr = s_row + ch * m;
         float r[4];
 #pragma unroll
@@ -158,10 +183,40 @@ __global__ __launch_bounds__(256) void three_interpolate_rows_kernel(
           r[u] = sr[id[u * 3 + 0]] * w[u * 3 + 0] + sr[id[u * 3 + 1]] * w[u * 3 + 1] +
                  sr[id[u * 3 + 2]] * w[u * 3 + 2];
         // streaming output (written once, not re-read here): non-temporal 16-byte store
-        typedef float v4f __attribute__((ext_vector_type(4)));
         v4f val = {r[0], r[1], r[2], r[3]};
         __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (size_t)ch * n + j0));
       }
+      asm volatile("s_waitcnt vmcnt(%6)"
+                   : "+v"(in_[0]), "+v"(in_[1]), "+v"(in_[2]), "+v"(wn[0]), "+v"(wn[1]), "+v"(wn[2])
+                   : "n"(CPB)
+                   : "memory");
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { ic[u] = in_[u]; wc[u] = wn[u]; }
+      j0 += 1024;
+    }
+    return;
+  }
+  for (; j0 < j_end; j0 += 1024) {
+    int id[12];
+    float w[12];
+    const int4* ip = reinterpret_cast<const int4*>(ibase + (size_t)j0 * 3);
+    const float4* wp = reinterpret_cast<const float4*>(wbase + (size_t)j0 * 3);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int4 a = ip[u];
+      const float4 f = wp[u];
+      id[u * 4 + 0] = a.x; id[u * 4 + 1] = a.y; id[u * 4 + 2] = a.z; id[u * 4 + 3] = a.w;
+      w[u * 4 + 0] = f.x; w[u * 4 + 1] = f.y; w[u * 4 + 2] = f.z; w[u * 4 + 3] = f.w;
+    }
+    for (int ch = 0; ch < nc; ++ch) {
+      const float* sr = s_row + ch * m;
+      float r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        r[u] = sr[id[u * 3 + 0]] * w[u * 3 + 0] + sr[id[u * 3 + 1]] * w[u * 3 + 1] +
+               sr[id[u * 3 + 2]] * w[u * 3 + 2];
+      v4f val = {r[0], r[1], r[2], r[3]};
+      __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + (size_t)ch * n + j0));
     }
   }
 }
@@ -265,7 +320,7 @@ extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* 
   if (rows_ok) {
     // 4 rows per workgroup measured best (idx/weight are 24 B per point, read once per 4 rows);
     // tile-owner and direct-gather variants measured slower and were removed
-    int cpb = 4;
+    int cpb = 8;
     while (cpb > 1 && (size_t)cpb * m * 4 > 64 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;
     const int rows = pvn3d_ceil_div(c, cpb);
@@ -276,6 +331,11 @@ extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* 
     jch = pvn3d_ceil_div(n, jchunk);
     const size_t lds = (size_t)cpb * m * sizeof(float);
     switch (cpb) {
+      case 8:
+        PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_rows_kernel<8>));
+        hipLaunchKernelGGL(three_interpolate_rows_kernel<8>, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk,
+                           points, idx, weight, out);
+        break;
       case 4:
         PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(three_interpolate_rows_kernel<4>));
         hipLaunchKernelGGL(three_interpolate_rows_kernel<4>, dim3(jch, rows, b), dim3(256), lds, st, c, m, n, jchunk,
