@@ -234,20 +234,27 @@ __device__ __forceinline__ void eval_pair(int f, int total, const int2* __restri
   }
 }
 
+// (the prefix counts are stored packed two per word and read back as 16-bit values, the bitmap is read in
+// 8- / 16-byte pieces: may_alias types, so that type-based alias analysis never reorders those accesses)
+typedef unsigned short __attribute__((may_alias)) bq_u16;
+typedef unsigned __attribute__((may_alias)) bq_u32;
+typedef unsigned bq_u32x4 __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned bq_u32x2 __attribute__((ext_vector_type(2), may_alias));
+
 template <int WPL>
-__device__ __forceinline__ int rank_prefix(const unsigned* __restrict__ bm, unsigned short* __restrict__ pre, int lane) {
+__device__ __forceinline__ int rank_prefix(const unsigned* bm, bq_u16* pre, int lane) {
   const int w0 = lane * WPL;
   unsigned w[WPL];
   if constexpr (WPL % 4 == 0) {
 #pragma unroll
     for (int g = 0; g < WPL / 4; ++g) {
-      const uint4 v = reinterpret_cast<const uint4*>(bm + w0)[g];
+      const bq_u32x4 v = reinterpret_cast<const bq_u32x4*>(bm + w0)[g];
       w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
     }
   } else if constexpr (WPL % 2 == 0) {
 #pragma unroll
     for (int g = 0; g < WPL / 2; ++g) {
-      const uint2 v = reinterpret_cast<const uint2*>(bm + w0)[g];
+      const bq_u32x2 v = reinterpret_cast<const bq_u32x2*>(bm + w0)[g];
       w[2 * g] = v.x; w[2 * g + 1] = v.y;
     }
   } else {
@@ -266,7 +273,7 @@ __device__ __forceinline__ int rank_prefix(const unsigned* __restrict__ bm, unsi
   if constexpr (WPL % 2 == 0) {        // counts <= n <= 32768 fit 16 bits
 #pragma unroll
     for (int g = 0; g < WPL / 2; ++g)
-      reinterpret_cast<unsigned*>(pre + w0)[g] = (unsigned)(base + below[2 * g]) | ((unsigned)(base + below[2 * g + 1]) << 16);
+      reinterpret_cast<bq_u32*>(pre + w0)[g] = (unsigned)(base + below[2 * g]) | ((unsigned)(base + below[2 * g + 1]) << 16);
   } else {
 #pragma unroll
     for (int i = 0; i < WPL; ++i) pre[w0 + i] = (unsigned short)(base + below[i]);
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
   const int bi = blockIdx.y;
   unsigned* const bma = s_bm + (size_t)wave * NB * WORDS;
   unsigned* const bmb = bma + (NB - 1) * WORDS;
-  unsigned short* const prea = reinterpret_cast<unsigned short*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
-  unsigned short* const preb = prea + (NB - 1) * WORDS;
+  bq_u16* const prea = reinterpret_cast<bq_u16*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
+  bq_u16* const preb = prea + (NB - 1) * WORDS;
   const int2* const cell = s_cell[wave];
   int* const cand = s_cand[wave];
   int* const stga = s_stage[wave][0];
