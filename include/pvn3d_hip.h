@@ -46,6 +46,25 @@ int pvn3d_opt_n_threads(int work_size);
 int pvn3d_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
                                   int* idxs, void* stream);
 
+/* Nested sampling for PointNet++ pyramids (no reference counterpart; the reference runs
+ * furthest_point_sampling_kernel_wrapper once per level, pointnet2_modules.py:47-55).  Level l+1 samples
+ * the points level l selected, in the order it selected them; FPS is greedy, so that run returns
+ * 0, 1, ..., m-1 unless a tie is broken differently under the next level's block shape.
+ *   pvn3d_furthest_point_sampling_nested: as pvn3d_furthest_point_sampling, plus
+ *     dmax_out (b,m) or NULL: the winning squared distance of every round (fp32 bit pattern; < 0: none);
+ *     nest_flags (b,3) or NULL with nest_level in [0,3): R = nest_flags[cloud][nest_level] says that the
+ *     cloud is in FPS order for its first R picks; rounds below R are not run (R >= m: idxs = 0..m-1 without
+ *     a single round).  Index-exact either way.
+ *   pvn3d_fps_nest_verify: ordered_xyz (b,n0,3) = the cloud gathered in the order of a run whose dmax is
+ *     given; m_levels[l] (host array) = samples of the l-th following level (its cloud = the first
+ *     m_levels[l-1], or n0, points).  flags[cloud][l] = the first round of that level's run that does NOT
+ *     select its own number (a tie broken differently under that level's block shape, or a degenerate
+ *     round); >= m_levels[l] if there is none; 1 if an earlier level already differs. */
+int pvn3d_furthest_point_sampling_nested(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                         int* dmax_out, const int* nest_flags, int nest_level, void* stream);
+int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_levels, const float* ordered_xyz,
+                          const int* dmax, int* flags, void* stream);
+
 /* replaces gather_points_kernel_wrapper, sampling_gpu.cu:22-29.
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int pvn3d_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,

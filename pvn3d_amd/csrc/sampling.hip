@@ -104,10 +104,27 @@ __device__ __forceinline__ bool fps_skipped(float x, float y, float z) {
 #define FPS_T(i)
 #endif
 
+// Nesting (see fps_nest_verify_kernel): `dmax` != nullptr -> the winning distance of every round is
+// written to dmax[cloud][j] (bit pattern; < 0 = no valid point); `nest` != nullptr -> nest[cloud][nest_level]
+// = R >= 1 says that the cloud is in FPS order for the first R picks: rounds 1 .. R-1 of this run are known
+// to select 1 .. R-1, so they are not run (R >= m: no round at all).
+struct FpsNest {
+  int* dmax;           // [b][m] or nullptr
+  const int* nest;     // [b][FPS_NEST_LEVELS] first round that has to be run, or nullptr
+  int nest_level;
+};
+constexpr int FPS_NEST_LEVELS = 3;
+
+__device__ __forceinline__ int fps_first_round(const FpsNest& nz, int m) {
+  if (!nz.nest) return 1;
+  const int r = nz.nest[(size_t)blockIdx.x * FPS_NEST_LEVELS + nz.nest_level];
+  return r < 1 ? 1 : (r > m ? m : r);
+}
+
 template <int THREADS, int PPT, bool lds_xyz>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, int Q,
                                                           const float* __restrict__ dataset,
-                                                          int* __restrict__ idxs FPS_PROBE_ARG) {
+                                                          int* __restrict__ idxs, FpsNest nz FPS_PROBE_ARG) {
   constexpr int NW = THREADS / 64;
   constexpr int SLOTS = THREADS * PPT;
   extern __shared__ float s_dyn[];
@@ -116,6 +133,12 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, i
   const int tid = threadIdx.x;
   dataset += (size_t)blockIdx.x * n * 3;
   idxs += (size_t)blockIdx.x * m;
+  const int first = fps_first_round(nz, m);          // (workgroup-uniform)
+  if (first >= m) {
+    for (int j = tid; j < m; j += THREADS) idxs[j] = j;
+    return;
+  }
+  int* const dmax = nz.dmax ? nz.dmax + (size_t)blockIdx.x * m : nullptr;
   const unsigned n_prio = (unsigned)Q << L;  // priorities in use: [0, bs*Q)
 
   float px[PPT], py[PPT], pz[PPT], tmp[PPT];
@@ -141,8 +164,22 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, i
     }
   }
   const unsigned prio0 = fps_prio(0, L, Q);  // == 0
-  if (tid == 0) idxs[0] = lds_xyz ? (int)prio0 : 0;
-  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  // picks 0 .. first-1 are points 0 .. first-1 (first == 1: only the seed)
+  for (int j = tid; j < first; j += THREADS) idxs[j] = lds_xyz ? (int)fps_prio(j, L, Q) : j;
+  if (first > 1) {
+    // the distance state those rounds would have left: the same min() chain in the same order, without the
+    // per-round arg-max and exchange
+    for (int q = 0; q + 1 < first; ++q) {
+      const float xq = dataset[q * 3], yq = dataset[q * 3 + 1], zq = dataset[q * 3 + 2];   // (uniform)
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float dx = px[i] - xq, dy = py[i] - yq, dz = pz[i] - zq;
+        const float d = dx * dx + dy * dy + dz * dz;
+        tmp[i] = __builtin_fminf(d, tmp[i]);
+      }
+    }
+  }
+  float x1 = dataset[(first - 1) * 3], y1 = dataset[(first - 1) * 3 + 1], z1 = dataset[(first - 1) * 3 + 2];
   if (NW > 1 || lds_xyz) __syncthreads();
 
   // In the loop only LDS traffic is ever waited for: the per-round index store stays in
@@ -153,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, i
   long long last_ = __builtin_readcyclecounter();
   const long long w0_ = wall_clock64();
 #endif
-  for (int j = 1; j < m; ++j) {
+  for (int j = first; j < m; ++j) {
     int v[PPT], ix[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -200,6 +237,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, i
     // all keep (best=-1, besti=0) and its tree returns index 0
     unsigned win = (gmax < 0) ? prio0 : wprio;
     win = (unsigned)__builtin_amdgcn_readfirstlane((int)win);
+    if (dmax && tid == 0) dmax[j] = gmax;
     FPS_T(3)
     if (lds_xyz) {
       if (tid == 0) idxs[j] = (int)win;   // priority for now; converted after the loop
@@ -234,13 +272,18 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(int n, int m, int L, i
 __global__ __launch_bounds__(1024) void fps_global_kernel(int n, int m, int L, int Q,
                                                           const float* __restrict__ dataset,
                                                           float* __restrict__ temp,
-                                                          int* __restrict__ idxs) {
+                                                          int* __restrict__ idxs, FpsNest nz) {
   __shared__ long long s_slot[2][16];
   if (m <= 0) return;
   const int tid = threadIdx.x;
   dataset += (size_t)blockIdx.x * n * 3;
   temp += (size_t)blockIdx.x * n;
   idxs += (size_t)blockIdx.x * m;
+  if (fps_first_round(nz, m) >= m) {      // (large clouds: all or nothing)
+    for (int j = tid; j < m; j += 1024) idxs[j] = j;
+    return;
+  }
+  int* const dmax = nz.dmax ? nz.dmax + (size_t)blockIdx.x * m : nullptr;
   for (int k = tid; k < n; k += 1024)
     temp[k] = fps_skipped(dataset[k * 3], dataset[k * 3 + 1], dataset[k * 3 + 2])
                   ? -__builtin_inff() : 1e10f;
@@ -273,11 +316,88 @@ __global__ __launch_bounds__(1024) void fps_global_kernel(int n, int m, int L, i
     old = (b2 == -1LL) ? 0 : fps_prio_to_k(~(unsigned)(b2 & 0xffffffffLL), L, Q);
     old = __builtin_amdgcn_readfirstlane(old);
     if (tid == 0) idxs[j] = old;
+    if (dmax && tid == 0) dmax[j] = (b2 == -1LL) ? -1 : (int)(b2 >> 32);
+  }
+}
+
+// ---- nested sampling --------------------------------------------------------------------------------
+// PointNet++ samples a pyramid: level l+1 runs FPS on the m_l points level l selected, in the order it
+// selected them.  FPS is greedy, so the first m' picks of a run ARE the run for m' samples: on the cloud
+// S = (p_0 .. p_{n'-1}) of level-l picks, round t of the next level looks for the point of S farthest from
+// {p_0 .. p_{t-1}} -- and p_t is the farthest point of the WHOLE cloud, computed with the same arithmetic.
+// The next level therefore selects t in round t unless a tie is broken differently: some k > t in S with
+// exactly the same distance D_t and a smaller tie-break priority under the NEXT level's block shape (it
+// happens: about one 12288-point cloud in 64 has such a pair among its first 1024 picks), or a degenerate
+// round (D_t <= 0).  The first such round R of every cloud and level is found here for all (k, t) at once,
+// without any per-round synchronisation: thread k keeps its running minimum distance to the picks while t
+// advances.  The FPS kernels of the later levels take R (FpsNest): picks below R are the identity, the
+// distance state of round R is rebuilt by the same min() chain, and only rounds >= R are run -- index-exact
+// in every case, and no round at all for the clouds without such a tie.
+struct NestLevels {
+  int n[FPS_NEST_LEVELS], m[FPS_NEST_LEVELS], L[FPS_NEST_LEVELS], Q[FPS_NEST_LEVELS];
+  int count, tmax;
+};
+
+// grid (ceil(n0/256), b): thread k = candidate k of the FPS-ordered cloud `pts` (b, n0, 3); dmax (b, n0) = the
+// winning distances of the run that produced the order.  dynamic LDS: tmax x (x, y, z, D).
+__global__ __launch_bounds__(256) void fps_nest_verify_kernel(int n0, NestLevels lv, const float* __restrict__ pts,
+                                                              const int* __restrict__ dmax, int* __restrict__ first_bad) {
+  extern __shared__ float4 s_pick[];      // [tmax]: pick t and (bits of) the winning distance of round t
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  pts += (size_t)blockIdx.y * n0 * 3;
+  dmax += (size_t)blockIdx.y * n0;
+  first_bad += (size_t)blockIdx.y * FPS_NEST_LEVELS;
+  for (int t = threadIdx.x; t < lv.tmax; t += 256)
+    s_pick[t] = make_float4(pts[t * 3], pts[t * 3 + 1], pts[t * 3 + 2], __int_as_float(dmax[t]));
+  __syncthreads();
+  const int kc = min(k, n0 - 1);
+  const float x = pts[kc * 3], y = pts[kc * 3 + 1], z = pts[kc * 3 + 2];
+  const bool candidate = k < n0 && !fps_skipped(x, y, z);
+  unsigned pk[FPS_NEST_LEVELS];
+#pragma unroll
+  for (int l = 0; l < FPS_NEST_LEVELS; ++l) pk[l] = l < lv.count ? fps_prio(kc, lv.L[l], lv.Q[l]) : 0u;
+  // a violation needs k > t: the wave stops at its largest k
+  const int t_end = min(lv.tmax, (int)(blockIdx.x * 256 + (threadIdx.x | 63)) + 1);
+  float run = 1e10f;
+  int bad[FPS_NEST_LEVELS];
+#pragma unroll
+  for (int l = 0; l < FPS_NEST_LEVELS; ++l) bad[l] = 0x7fffffff;
+  for (int t = 1; t < t_end; ++t) {
+    const float4 prev = s_pick[t - 1];
+    const int dt = __float_as_int(s_pick[t].w);
+    const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
+    const float d = dx * dx + dy * dy + dz * dz;
+    run = __builtin_fminf(d, run);
+    const int rb = __float_as_int(run);
+    if (dt <= 0 || (candidate && k > t && rb >= dt)) {      // (rare: the priorities are only computed here)
+#pragma unroll
+      for (int l = 0; l < FPS_NEST_LEVELS; ++l) {
+        if (l < lv.count && t < lv.m[l]) {
+          const bool tie_lost = rb == dt && pk[l] < fps_prio(t, lv.L[l], lv.Q[l]);
+          if (dt <= 0 || (k < lv.n[l] && (rb > dt || tie_lost))) bad[l] = min(bad[l], t);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < FPS_NEST_LEVELS; ++l)
+    if (bad[l] != 0x7fffffff) atomicMin(&first_bad[l], bad[l]);
+}
+
+// A level whose predecessor did not come out as the identity samples a different cloud: it runs in full.
+__global__ void fps_nest_finalize_kernel(int b, NestLevels lv, int* __restrict__ first_bad) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= b) return;
+  int* f = first_bad + (size_t)c * FPS_NEST_LEVELS;
+  bool prefix = true;
+  for (int l = 0; l < FPS_NEST_LEVELS; ++l) {
+    if (l >= lv.count || !prefix) { f[l] = 1; continue; }
+    if (f[l] < lv.m[l]) prefix = false;
   }
 }
 
 template <int THREADS, int PPT>
-int launch_fps_reg(int b, int n, int m, int L, int Q, const float* dataset, int* idxs,
+int launch_fps_reg(int b, int n, int m, int L, int Q, const float* dataset, int* idxs, const FpsNest& nz,
                    hipStream_t st) {
   size_t lds = (size_t)THREADS * PPT * 3 * sizeof(float);
   int use_lds = lds + 1024 <= 160 * 1024;
@@ -286,10 +406,10 @@ int launch_fps_reg(int b, int n, int m, int L, int Q, const float* dataset, int*
     auto kern = fps_reg_kernel<THREADS, PPT, true>;
     PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(kern));
     hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, st, n, m, L, Q, dataset,
-                       idxs FPS_PROBE_NULL);
+                       idxs, nz FPS_PROBE_NULL);
   } else {
     hipLaunchKernelGGL((fps_reg_kernel<THREADS, PPT, false>), dim3(b), dim3(THREADS), 0, st, n, m,
-                       L, Q, dataset, idxs FPS_PROBE_NULL);
+                       L, Q, dataset, idxs, nz FPS_PROBE_NULL);
   }
   PVN3D_LAUNCH_CHECK();
   return 0;
@@ -330,29 +450,81 @@ extern "C" int pvn3d_opt_n_threads(int work_size) {
 
 extern "C" int pvn3d_abi_version(void) { return PVN3D_ABI_VERSION; }
 
+static void fps_block_shape(int n, int* L, int* Q) {
+  const int bs = pvn3d_opt_n_threads(n);
+  *L = 0;
+  while ((1 << *L) < bs) ++*L;
+  *Q = (n + bs - 1) / bs;
+}
+
+static int fps_launch(int b, int n, int m, const float* dataset, float* temp, int* idxs, const FpsNest& nz,
+                      hipStream_t st) {
+  int L, Q;
+  fps_block_shape(n, &L, &Q);
+  const int slots = (1 << L) * Q;  // priority slots to cover (>= n)
+  if (slots <= 64) return launch_fps_reg<64, 1>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 128) return launch_fps_reg<64, 2>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 256) return launch_fps_reg<64, 4>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 512) return launch_fps_reg<64, 8>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 1024) return launch_fps_reg<256, 4>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 2048) return launch_fps_reg<256, 8>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 4096) return launch_fps_reg<256, 16>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 8192) return launch_fps_reg<256, 32>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 12288) return launch_fps_reg<256, 48>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (slots <= 16384) return launch_fps_reg<256, 64>(b, n, m, L, Q, dataset, idxs, nz, st);
+  if (!temp) return (int)hipErrorInvalidValue;  // large clouds need the caller's scratch
+  hipLaunchKernelGGL(fps_global_kernel, dim3(b), dim3(1024), 0, st, n, m, L, Q, dataset, temp,
+                     idxs, nz);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pvn3d_furthest_point_sampling(int b, int n, int m, const float* dataset,
                                              float* temp, int* idxs, void* stream) {
   if (b <= 0 || m <= 0) return 0;
   if (n <= 0 || !dataset || !idxs) return (int)hipErrorInvalidValue;
+  return fps_launch(b, n, m, dataset, temp, idxs, FpsNest{nullptr, nullptr, 0}, (hipStream_t)stream);
+}
+
+extern "C" int pvn3d_furthest_point_sampling_nested(int b, int n, int m, const float* dataset, float* temp,
+                                                    int* idxs, int* dmax_out, const int* nest_flags,
+                                                    int nest_level, void* stream) {
+  if (b <= 0 || m <= 0) return 0;
+  if (n <= 0 || !dataset || !idxs || nest_level < 0 || nest_level >= FPS_NEST_LEVELS)
+    return (int)hipErrorInvalidValue;
+  return fps_launch(b, n, m, dataset, temp, idxs, FpsNest{dmax_out, nest_flags, nest_level}, (hipStream_t)stream);
+}
+
+extern "C" int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_levels, const float* ordered_xyz,
+                                     const int* dmax, int* flags, void* stream) {
+  if (b <= 0) return 0;
+  if (n0 <= 0 || n_levels < 1 || n_levels > FPS_NEST_LEVELS || !m_levels || !ordered_xyz || !dmax || !flags)
+    return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  const int bs = pvn3d_opt_n_threads(n);
-  int L = 0;
-  while ((1 << L) < bs) ++L;
-  const int Q = (n + bs - 1) / bs;
-  const int slots = bs * Q;  // priority slots to cover (>= n)
-  if (slots <= 64) return launch_fps_reg<64, 1>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 128) return launch_fps_reg<64, 2>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 256) return launch_fps_reg<64, 4>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 512) return launch_fps_reg<64, 8>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 1024) return launch_fps_reg<256, 4>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 2048) return launch_fps_reg<256, 8>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 4096) return launch_fps_reg<256, 16>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 8192) return launch_fps_reg<256, 32>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 12288) return launch_fps_reg<256, 48>(b, n, m, L, Q, dataset, idxs, st);
-  if (slots <= 16384) return launch_fps_reg<256, 64>(b, n, m, L, Q, dataset, idxs, st);
-  if (!temp) return (int)hipErrorInvalidValue;  // large clouds need the caller's scratch
-  hipLaunchKernelGGL(fps_global_kernel, dim3(b), dim3(1024), 0, st, n, m, L, Q, dataset, temp,
-                     idxs);
+  NestLevels lv;
+  lv.count = n_levels;
+  int n = n0;
+  for (int l = 0; l < FPS_NEST_LEVELS; ++l) {
+    lv.n[l] = lv.m[l] = lv.L[l] = 0;
+    lv.Q[l] = 1;
+    if (l < n_levels) {
+      if (m_levels[l] <= 0 || m_levels[l] > n) return (int)hipErrorInvalidValue;
+      lv.n[l] = n;
+      lv.m[l] = m_levels[l];
+      fps_block_shape(n, &lv.L[l], &lv.Q[l]);
+      n = m_levels[l];
+    }
+  }
+  lv.tmax = 0;
+  for (int l = 0; l < n_levels; ++l) lv.tmax = lv.m[l] > lv.tmax ? lv.m[l] : lv.tmax;
+  if ((size_t)lv.tmax * sizeof(float4) > 128 * 1024) return (int)hipErrorInvalidValue;
+  // 0x7f7f7f7f = "no round has to be run"
+  PVN3D_RETURN_IF_ERR(hipMemsetAsync(flags, 0x7f, (size_t)b * FPS_NEST_LEVELS * sizeof(int), st));
+  PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(fps_nest_verify_kernel));
+  hipLaunchKernelGGL(fps_nest_verify_kernel, dim3(pvn3d_ceil_div(n0, 256), b), dim3(256),
+                     (size_t)lv.tmax * sizeof(float4), st, n0, lv, ordered_xyz, dmax, flags);
+  PVN3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fps_nest_finalize_kernel, dim3(pvn3d_ceil_div(b, 64)), dim3(64), 0, st, b, lv, flags);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

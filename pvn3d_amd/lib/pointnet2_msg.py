@@ -98,8 +98,12 @@ class Pointnet2MSG(nn.Module):
             return ev
 
         with torch.cuda.stream(geo):
-            for sa in self.SA_modules:
-                new_xyz, idxs = sa.sample_and_query(l_xyz[-1])
+            nest = None
+            for li, sa in enumerate(self.SA_modules):
+                # every level samples the previous level's centres in the order they were picked: one FPS run
+                # (the first level's) plus one verification pass decide the whole pyramid
+                plan = [m.npoint for m in list(self.SA_modules)[1:]] if li == 0 else None
+                new_xyz, idxs, nest = sa.sample_and_query_nested(l_xyz[-1], nest=nest, plan=plan)
                 sa_geo.append(((new_xyz, idxs), hand_over([new_xyz] + list(idxs))))
                 l_xyz.append(new_xyz)
             for i in range(-1, -(len(self.FP_modules) + 1), -1):
@@ -117,8 +121,11 @@ class Pointnet2MSG(nn.Module):
                  and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]
         if not ahead:
-            for sa in self.SA_modules:
-                li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+            nest = None
+            for li, sa in enumerate(self.SA_modules):
+                plan = [m.npoint for m in list(self.SA_modules)[1:]] if li == 0 else None
+                new_xyz, idxs, nest = sa.sample_and_query_nested(l_xyz[-1], nest=nest, plan=plan)
+                li_xyz, li_features = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idxs))
                 l_xyz.append(li_xyz)
                 l_features.append(li_features)
             for i in range(-1, -(len(self.FP_modules) + 1), -1):

@@ -57,6 +57,57 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
+def furthest_point_sampling_nested(points, nsamples, want_dmax=False, nest=None):
+    """furthest_point_sampling for the levels of a PointNet++ pyramid (not a reference entry point).
+    want_dmax: also return the winning squared distance of every round, (B, nsamples) int32 bit patterns --
+    the input of fps_nest_verify.  nest = (first_rounds (B,3) int32 from fps_nest_verify, level): cloud b is
+    known to be in FPS order for its first R = first_rounds[b][level] picks, so rounds below R are not run
+    (R >= nsamples: the result is 0..nsamples-1 without a single round).  Returns (idx, dmax or None); idx is
+    index-exact either way."""
+    _chk(points, "points", torch.float32)
+    _same_dev(points, points, "points")
+    B, N = points.size(0), points.size(1)
+    out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
+    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device) if N > 16384 else None
+    dmax = torch.empty((B, nsamples), dtype=torch.int32, device=points.device) if want_dmax else None
+    flags, level = nest if nest is not None else (None, 0)
+    if flags is not None:
+        _chk(flags, "nest first_rounds", torch.int32)
+        _same_dev(points, flags, "nest first_rounds")
+        if tuple(flags.shape) != (B, 3):
+            raise RuntimeError("nest first_rounds must be (B, 3)")
+    with on_device(points.device):
+        check(lib.pvn3d_furthest_point_sampling_nested(
+            B, N, int(nsamples), points.data_ptr(), tmp.data_ptr() if tmp is not None else None, out.data_ptr(),
+            dmax.data_ptr() if dmax is not None else None, flags.data_ptr() if flags is not None else None,
+            int(level), _stream(points)), "furthest_point_sampling_nested")
+    return out, dmax
+
+
+def fps_nest_verify(ordered_xyz, dmax, m_levels):
+    """ordered_xyz (B,n0,3): a cloud gathered in the order of the FPS run whose per-round winning distances
+    are `dmax` (B,n0); m_levels: samples of the (up to 3) following pyramid levels.  -> first_rounds (B,3)
+    int32: level l's run on cloud b selects 0, 1, ..., R-1 in its first R = first_rounds[b][l] rounds
+    (R >= m_l: the whole run is the identity; R = the first round in which a tie is broken differently under
+    that level's block shape, or a degenerate round; 1 = the level samples a different cloud, run it all)."""
+    import ctypes
+    _chk(ordered_xyz, "ordered_xyz", torch.float32)
+    _chk(dmax, "dmax", torch.int32)
+    _same_dev(ordered_xyz, dmax, "dmax")
+    B, n0 = ordered_xyz.size(0), ordered_xyz.size(1)
+    if tuple(dmax.shape) != (B, n0):
+        raise RuntimeError("dmax must be (B, n0)")
+    ms = [int(m) for m in m_levels]
+    if not 1 <= len(ms) <= 3:
+        raise RuntimeError("1 to 3 following levels")
+    flags = torch.empty((B, 3), dtype=torch.int32, device=ordered_xyz.device)
+    arr = (ctypes.c_int * len(ms))(*ms)
+    with on_device(ordered_xyz.device):
+        check(lib.pvn3d_fps_nest_verify(B, n0, len(ms), arr, ordered_xyz.data_ptr(), dmax.data_ptr(),
+                                        flags.data_ptr(), _stream(ordered_xyz)), "fps_nest_verify")
+    return flags
+
+
 def gather_points(points, idx):
     """points (B,C,N), idx (B,npoint) -> (B,C,npoint).  sampling.cpp:15-39"""
     _chk(points, "points", torch.float32)

@@ -22,6 +22,9 @@ from ..utils import pytorch_utils as pt_utils
 # fp32-MFMA kernel each (csrc/sa_mlp.hip).  Used when the module is in eval mode and autograd
 # is not recording; set to False to force the reference's op-by-op composition.
 FUSED_INFERENCE = True
+# Pyramid levels after the first take their FPS result from the first level's run when it is provably the
+# same (sample_and_query_nested); False = every level runs its own FPS.
+FPS_NESTING = True
 
 
 # Optional measurement hook: a callable ``name -> context manager`` bracketing each stage of the
@@ -83,6 +86,38 @@ class _PointnetSAModuleBase(nn.Module):
         with _stage("ball_query"):
             idxs = self._shared_idx(xyz, new_xyz)
         return new_xyz, idxs
+
+    def sample_and_query_nested(self, xyz, nest=None, plan=None):
+        """sample_and_query for the levels of a pyramid whose next level samples THIS level's centres in the
+        order they were picked (Pointnet2MSG): FPS is greedy, so the next level's run is the identity prefix
+        unless a tie breaks differently -- checked once, for up to three following levels, by
+        _ext.fps_nest_verify right after the first level (csrc/sampling.hip).  `plan` (first level): npoint of
+        the following levels; `nest` (later levels): the state the previous level returned.
+        -> (new_xyz, idxs, state for the next level or None).  Index-exact with sample_and_query."""
+        if self.npoint is None or not (FPS_NESTING and xyz.is_cuda):
+            return self.sample_and_query(xyz) + (None,)
+        state = None
+        with _stage("fps"):
+            if nest is not None:
+                flags, level = nest
+                sel, _ = _ext.furthest_point_sampling_nested(xyz, self.npoint, nest=(flags, level))
+                state = (flags, level + 1) if level + 1 < 3 else None
+            else:
+                follow = []
+                for m in (plan or [])[:3]:
+                    if m is None or m > (follow[-1] if follow else self.npoint):
+                        break
+                    follow.append(int(m))
+                sel, dmax = _ext.furthest_point_sampling_nested(xyz, self.npoint, want_dmax=bool(follow))
+        with _stage("gather"):
+            xyz_t = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
+        if nest is None and follow:
+            with _stage("fps"):
+                state = (_ext.fps_nest_verify(new_xyz, dmax, follow), 0)
+        with _stage("ball_query"):
+            idxs = self._shared_idx(xyz, new_xyz)
+        return new_xyz, idxs, state
 
     def forward(self, xyz, features=None, geometry=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum(mlp[-1]),npoint)"""

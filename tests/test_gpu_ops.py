@@ -38,6 +38,69 @@ def test_fps_index_exact(ext, orc, dev, b, n, m, wrap):
     assert np.array_equal(got, orc.furthest_point_sampling(xyz, m))
 
 
+def _lattice_cloud(n, seed):
+    """Points on a coarse lattice (many exactly equal distances) in random order, some repeated."""
+    g = np.random.default_rng(seed)
+    side = int(np.ceil(n ** (1 / 3.0))) + 1
+    grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pts = grid[g.permutation(len(grid))[:n]] * np.float32(0.03125) + np.float32(0.25)
+    pts[n // 2:n // 2 + n // 20] = pts[:n // 20]          # duplicates
+    return pts[None]
+
+
+@pytest.mark.parametrize("case", ["scene", "wrap_dups", "lattice_ties", "few_unique", "skipped", "small_pyramid",
+                                  "two_levels"])
+def test_fps_nested_pyramid_index_exact(ext, orc, dev, case):
+    """The levels of a pyramid through furthest_point_sampling_nested + fps_nest_verify == one independent FPS
+    run per level (oracle), whether the whole run is the identity prefix (generic clouds) or only its first R
+    rounds (exact ties between lattice points, exhausted clouds, degenerate rounds)."""
+    sizes = [12288, 2048, 1024, 512, 128]
+    if case == "scene":
+        xyz = clouds(31, 2, sizes[0], 0.0)
+    elif case == "wrap_dups":
+        xyz = clouds(32, 2, sizes[0], 0.4)                 # 40 % of the points are wrap-padding repeats
+    elif case == "lattice_ties":
+        xyz = np.concatenate([_lattice_cloud(sizes[0], 5), clouds(33, 1, sizes[0], 0.1)], 0)
+    elif case == "few_unique":                             # fewer distinct points than samples: rounds with D = 0
+        base = clouds(34, 1, 700, 0.0)
+        xyz = np.tile(base, (1, 18, 1))[:, :sizes[0]]
+    elif case == "skipped":
+        xyz = clouds(35, 2, sizes[0], 0.1)
+        xyz[0, 5:3000] *= np.float32(1e-3)                 # |p|^2 <= 1e-3: never sampled, never a candidate
+    elif case == "small_pyramid":
+        sizes = [3000, 700, 300, 100, 40]
+        xyz = clouds(36, 3, sizes[0], 0.1)
+    else:
+        sizes = [2048, 1000, 999]
+        xyz = clouds(37, 2, sizes[0], 0.2)
+    cloud_np = xyz
+    sel, dmax = ext.furthest_point_sampling_nested(T(cloud_np, dev), sizes[1], want_dmax=True)
+    sel = sel.cpu().numpy()
+    assert np.array_equal(sel, orc.furthest_point_sampling(cloud_np, sizes[1]))
+    cloud_np = np.take_along_axis(cloud_np, sel[..., None].astype(np.int64).repeat(3, -1), 1)
+    flags = ext.fps_nest_verify(T(cloud_np, dev), dmax, sizes[2:])
+    fl = flags.cpu().numpy()
+    taken = []
+    for level, m in enumerate(sizes[2:]):
+        got, _ = ext.furthest_point_sampling_nested(T(cloud_np, dev), m, nest=(flags, level))
+        got = got.cpu().numpy()
+        want = orc.furthest_point_sampling(cloud_np, m)
+        assert np.array_equal(got, want), (case, level)
+        ok = fl[:, level] >= m                             # no round had to be run
+        for b in range(len(ok)):                           # the rounds that were skipped are the identity prefix
+            r = min(int(fl[b, level]), m)
+            assert np.array_equal(want[b][:r], np.arange(r))
+            assert r >= m or want[b][r] != r or fl[b, level] == 1      # ... and R is where it first differs
+        taken.append(ok)
+        cloud_np = np.take_along_axis(cloud_np, got[..., None].astype(np.int64).repeat(3, -1), 1)
+    if case in ("scene", "small_pyramid", "two_levels"):
+        assert all(t.all() for t in taken)                 # generic clouds: no FPS round after the first level
+    if case == "lattice_ties":
+        assert not taken[0][0] and taken[0][1]             # per cloud: the lattice is refused, the scene is not
+    if case == "few_unique":
+        assert not taken[0].any()
+
+
 def test_fps_skip_rule_duplicates_and_degenerate(ext, orc, dev):
     xyz = clouds(11, 2, 777, 0.5)
     xyz[0, 100:200] = 0.0                      # skipped points (|p|^2 <= 1e-3)

@@ -23,7 +23,7 @@ void probe(int b, int n, int m) {
   for (int rep = 0; rep < 3; ++rep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, 0, n, m, L, Q, d, idx, dbg);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(THREADS), lds, 0, n, m, L, Q, d, idx, FpsNest{nullptr, nullptr, 0}, dbg);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long hd[6]; hipMemcpy(hd, dbg, 48, hipMemcpyDeviceToHost);
