@@ -51,3 +51,58 @@ def test_group_grad_is_the_transpose_of_group(orc, seed, n, c, m, ns):
     lhs = float((orc.group_points(pts, idx).astype(np.float64) * g).sum())
     rhs = float((pts.astype(np.float64) * orc.group_points_grad(g, idx, n)).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+# ---- the property behind the nested sampling of csrc/sampling.hip, on the CPU oracle ----------
+def _fps_prio(k, n, orc):
+    """Tie-break priority of point k in the reference's block of opt_n_threads(n) threads (smaller wins)."""
+    bs = orc.opt_n_threads(n)
+    L = bs.bit_length() - 1
+    Q = (n + bs - 1) // bs
+    r = int(format(k & (bs - 1), "0%db" % L)[::-1], 2) if L else 0
+    return r * Q + (k >> L)
+
+
+def _first_differing_round(S, m, orc):
+    """numpy restatement of fps_nest_verify_kernel for one following level: S = a cloud in the order an FPS run
+    picked it; the first round t < m of a run ON S that does not select t (m if there is none)."""
+    n = len(S)
+    skipped = ((S[:, 0] * S[:, 0] + S[:, 1] * S[:, 1]) + S[:, 2] * S[:, 2]).astype(np.float64) <= 1e-3
+    run = np.full(n, 1e10, np.float32)
+    for t in range(1, m):
+        d = S - S[t - 1]
+        run = np.minimum(((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32), run)
+        dt = run[t]
+        if not dt > 0 or skipped[t]:
+            return t
+        for k in np.nonzero((run[t + 1:] >= dt) & ~skipped[t + 1:])[0] + t + 1:
+            if run[k] > dt or _fps_prio(int(k), n, orc) < _fps_prio(t, n, orc):
+                return t
+    return m
+
+
+def test_fps_of_an_fps_ordered_cloud_is_the_identity_up_to_the_first_broken_tie(orc):
+    """FPS is greedy: on the picks of a run, in pick order, the next pyramid level's run selects 0, 1, 2, ...
+    until a tie is broken differently under its own block shape -- the round the verification predicts."""
+    g = np.random.default_rng(7)
+    side = 14
+    lattice = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    lattice = lattice[g.permutation(len(lattice))[:2048]] * np.float32(0.03125) + np.float32(0.25)
+    generic = (g.normal(size=(2048, 3)) * 0.2).astype(np.float32) + np.float32(0.7)
+    dups = generic.copy()
+    dups[1024:1536] = dups[:512]
+    seen_identity = seen_partial = False
+    for cloud in (generic, dups, lattice):
+        sel = orc.furthest_point_sampling(cloud[None], 700)[0]
+        S = np.ascontiguousarray(cloud[sel])
+        for m in (300, 128):
+            want = orc.furthest_point_sampling(S[None], m)[0]
+            r = _first_differing_round(S, m, orc)
+            assert np.array_equal(want[:r], np.arange(r))
+            if r < m:
+                assert want[r] != r
+                seen_partial = True
+            else:
+                seen_identity = True
+            S = np.ascontiguousarray(S[want])
+    assert seen_identity and seen_partial

@@ -153,3 +153,26 @@ def test_fma_build_differs_only_in_distances():
     # lattice coordinates are exact in fp32 (multiples of 0.25), so contraction cannot change anything there;
     # on continuous clouds a flip needs two candidates within one ulp, i.e. it is rare but legal -- bounded, not zero
     assert tot["fps"] <= 4 and tot["bq"] <= 8 and tot["nn"] <= 8
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", ["normal", "lattice", "dups"])
+def test_reference_fps_kernel_on_its_own_picks_is_the_identity_up_to_the_predicted_round(kind):
+    """The property the nested sampling of csrc/sampling.hip relies on, shown on the REFERENCE'S OWN
+    kernel (sampling_gpu.cu:69-173 compiled for the CPU): run on a cloud given in the order an earlier run picked
+    it, furthest_point_sampling selects 0, 1, 2, ... up to the first round in which a tie is broken differently
+    under the new block shape -- exactly the round the verification pass computes."""
+    from test_oracle_properties import _first_differing_round
+    from oracle import native
+    rng = np.random.default_rng(3)
+    cloud = _clouds(rng, 1, 1536, kind)[0]
+    if kind == "lattice":
+        cloud = cloud + rng.integers(0, 2, size=cloud.shape).astype(np.float32) * np.float32(0.0625)
+    sel = ref.furthest_point_sampling(cloud[None], 600)[0]
+    S = np.ascontiguousarray(cloud[sel])
+    for m in (256, 100):
+        want = ref.furthest_point_sampling(S[None], m)[0]
+        r = _first_differing_round(S, m, native)
+        assert np.array_equal(want[:r], np.arange(r))
+        assert r >= m or want[r] != r
+        S = np.ascontiguousarray(S[want])
