@@ -65,6 +65,17 @@ int pvn3d_furthest_point_sampling_nested(int b, int n, int m, const float* datas
 int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_levels, const float* ordered_xyz,
                           const int* dmax, int* flags, void* stream);
 
+/* The same sampling with a caller-provided workspace (no reference counterpart: the reference's `temp` is
+ * (b,n) floats and too small).  pvn3d_fps_ws_words(n) = 4-byte words per cloud that `ws` must hold (0: none
+ * needed, ws may be NULL).  For 4096 < n <= 12288 the workspace lets the run use the spatially culled kernel
+ * (csrc/fps_cells.hip: 64 equal-count cells per cloud, a round only recomputes the cells whose bounding box
+ * is closer to the new sample than the cell's largest running distance -- index-exact, same tie order);
+ * dmax_out / nest_flags / nest_level as in pvn3d_furthest_point_sampling_nested (a run with nest_flags uses
+ * the register-resident kernel). */
+int pvn3d_fps_ws_words(int n);
+int pvn3d_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, void* ws, int* idxs,
+                                     int* dmax_out, const int* nest_flags, int nest_level, void* stream);
+
 /* replaces gather_points_kernel_wrapper, sampling_gpu.cu:22-29.
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int pvn3d_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,

@@ -22,6 +22,8 @@ SIGNATURES = {
     "pvn3d_furthest_point_sampling": (_i, [_i, _i, _i, _p, _p, _p, _p]),
     "pvn3d_furthest_point_sampling_nested": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "pvn3d_fps_nest_verify": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_fps_ws_words": (_i, [_i]),
+    "pvn3d_furthest_point_sampling_ws": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
     "pvn3d_gather_points": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
     "pvn3d_gather_points_grad": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
     "pvn3d_ball_query": (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _p]),

@@ -25,22 +25,50 @@ static inline int pvn3d_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // One-time opt-in of a kernel to > 48 KiB of dynamic LDS (a property of the loaded function on a
 // device, not of a launch).  The only process-wide state of the library is this idempotent
-// "already done on device d" bit per kernel.
+// "already done on device d" bit PER KERNEL ADDRESS: the cache is keyed on the function pointer's
+// value (two instantiations of one template share a pointer TYPE, so a per-type static would let
+// the first instantiation's opt-in mask the others').  Lock-free open-addressed table; a slot is
+// claimed once with a CAS on its key and never released, a full table only costs the (idempotent)
+// runtime calls again.
+struct pvn3d_big_lds_slot {
+  std::atomic<const void*> key;
+  std::atomic<unsigned long long> done;
+};
+inline pvn3d_big_lds_slot* pvn3d_big_lds_table() {
+  static pvn3d_big_lds_slot table[256];  // zero-initialised; shared by every TU of the library
+  return table;
+}
+inline std::atomic<unsigned long long>* pvn3d_big_lds_find(const void* fn) {
+  pvn3d_big_lds_slot* t = pvn3d_big_lds_table();
+  size_t h = ((uintptr_t)fn >> 4) * 0x9E3779B97F4A7C15ull >> 56;
+  for (int probe = 0; probe < 256; ++probe) {
+    pvn3d_big_lds_slot& s = t[(h + probe) & 255];
+    const void* k = s.key.load(std::memory_order_acquire);
+    if (k == fn) return &s.done;
+    if (k == nullptr) {
+      const void* expect = nullptr;
+      if (s.key.compare_exchange_strong(expect, fn, std::memory_order_acq_rel)) return &s.done;
+      if (expect == fn) return &s.done;
+    }
+  }
+  return nullptr;
+}
 template <typename K>
 static inline int pvn3d_allow_big_lds(K kern) {
-  static std::atomic<unsigned long long> done{0};
+  const void* fn = reinterpret_cast<const void*>(kern);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  if (dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return 0;
+  std::atomic<unsigned long long>* done = pvn3d_big_lds_find(fn);
+  if (done && dev < 64 && ((done->load(std::memory_order_acquire) >> dev) & 1ull)) return 0;
   hipFuncAttributes fa;
-  e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+  e = hipFuncGetAttributes(&fa, fn);
   if (e != hipSuccess) return (int)e;
   // the CU has 160 KiB; the kernel's static __shared__ arrays come out of the same budget
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                           160 * 1024 - (int)fa.sharedSizeBytes);
   if (e != hipSuccess) return (int)e;
-  if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
+  if (done && dev < 64) done->fetch_or(1ull << dev, std::memory_order_release);
   return 0;
 }
 

@@ -1,0 +1,603 @@
+// fps_cells.hip -- furthest point sampling with exact spatial culling, one WAVE per cloud (gfx950).
+//
+// Replaces, for 4096 < n <= 12288, the serial scan of furthest_point_sampling_kernel
+// (pvn3d/_ext-src/src/sampling_gpu.cu:69-173): every round of the reference (and of
+// sampling.hip::fps_reg_kernel) recomputes the distance of ALL n points to the newest sample,
+// although a sample only lowers the running minimum of the points near it.  Here the cloud is
+// cut into 64 spatially compact cells of <= 192 points (8 slabs along the widest axis x 8 along
+// the second widest, equal counts: two counting sorts in LDS), and a round
+//   1. tests all 64 cells at once, one lane per cell: LB = squared distance from the sample to the
+//      cell's bounding box, evaluated with the SAME unfused fp32 expression as the point
+//      distance; rounding is monotone, so LB <= d(k) holds exactly for every point k of the cell,
+//      and LB > max_k temp[k] proves that min(d, temp) leaves the whole cell unchanged;
+//   2. updates only the touched cells (2.1 of 64 on average on the BASELINE clouds): coordinates
+//      from LDS, running minima from a VGPR array indexed through M0 (s_set_gpr_idx), one DPP
+//      wave reduction per touched cell refreshes its cached (max, arg-max position);
+//   3. takes the arg-max over the 64 cached cell maxima (one more DPP reduction), no barrier, no
+//      cross-wave exchange: the serial chain lives in ONE wave.
+// Ties (equal maxima inside a cell or across cells) are detected with ballots and resolved with
+// the reference block's order -- smallest bit-reversed (k mod bs), then smallest k, i.e. the
+// smallest fps_prio(k) of sampling.hip -- by looking the candidates' indices up in the scratch
+// table; rare on real clouds, every round on exhausted / duplicated clouds (still exact).
+// Non-finite input: a non-finite sample changes nothing in the reference either (every d is inf or
+// NaN, fminf keeps temp), so such a round touches no cell; non-finite points only widen a box.
+//
+// Arithmetic: -ffp-contract=off; d = ((dx*dx + dy*dy) + dz*dz), one rounding per operation.
+#include "common.h"
+
+// FC_PROBE (tools/fps_cells_probe.hip only): per-phase s_memtime accounting of the serial rounds.
+#ifdef FC_PROBE
+#define FC_PROBE_ARG , long long* __restrict__ dbg
+#define FC_PROBE_NULL , (long long*)nullptr
+#define FC_T(i) { const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; }
+#define FC_COUNT(i, v) { acc_[i] += (v); }
+#else
+#define FC_PROBE_ARG
+#define FC_PROBE_NULL
+#define FC_T(i)
+#define FC_COUNT(i, v)
+#endif
+
+namespace {
+
+// wave64 reductions on the DPP path, one instruction per step (v_max_i32 with the DPP modifier on src0; the
+// compiler's own lowering of update_dpp is v_mov + s_nop + v_mov_dpp + v_max per step, and in a wave that
+// runs alone on its SIMD every dependent instruction costs 8-10 cycles).  s_nop 1 = the two wait states a DPP
+// read needs after the VALU write of its source; rows outside row_mask keep their value; lane 63 ends up
+// with the result.  The trailing s_nop covers "VALU wrote an SGPR" for whatever the compiler puts next.
+__device__ __forceinline__ int fc_wave_max_i32(int v) {
+  int r;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %1, %0, 63\n\t"
+      "s_nop 3"
+      : "+v"(v), "=s"(r));
+  return r;
+}
+
+__device__ __forceinline__ unsigned fc_wave_min_u32(unsigned v) {
+  unsigned r;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %1, %0, 63\n\t"
+      "s_nop 3"
+      : "+v"(v), "=s"(r));
+  return r;
+}
+
+// order-preserving float <-> int (for LDS atomicMin / atomicMax on coordinates)
+__device__ __forceinline__ int fc_ord(float f) {
+  const int i = __float_as_int(f);
+  return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float fc_unord(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+
+// tie-break priority of point k in the reference block (see sampling.hip::fps_prio)
+__device__ __forceinline__ unsigned fc_prio(int k, int L, int Q) {
+  const unsigned r = L ? (__brev((unsigned)k & ((1u << L) - 1u)) >> (32 - L)) : 0u;
+  return r * (unsigned)Q + ((unsigned)k >> L);
+}
+
+// mag <= 1e-3 with mag fp32 and the literal double (sampling_gpu.cu:100-101)
+__device__ __forceinline__ bool fc_skipped(float x, float y, float z) {
+  const float mag = (x * x) + (y * y) + (z * z);
+  return (double)mag <= 1e-3;
+}
+
+__device__ __forceinline__ int fc_wave_incl_scan(int v, int lane, int width) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if ((lane & (width - 1)) >= d) v += o;
+    if (d * 2 >= width) break;
+  }
+  return v;
+}
+
+constexpr int FC_BINS1 = 2048;   // level-1 histogram (whole cloud, widest axis)
+constexpr int FC_BINS2 = 256;    // level-2 histogram per slab (second widest axis)
+constexpr int FC_AUX_INTS = 4096;  // hist (2048) + misc (2048)
+
+// misc region (ints), after the histogram
+constexpr int MI_BBOX = 0;       // [6]  ordered ints: min x,y,z, max x,y,z
+constexpr int MI_SLABR = 8;      // [8][2] ordered ints: min / max of the level-2 coordinate per slab
+constexpr int MI_WSCAN = 32;     // [8]  wave totals of the scans
+constexpr int MI_SLABLO = 48;    // [8]  float: level-2 origin per slab
+constexpr int MI_SLABSC = 56;    // [8]  float: level-2 scale per slab
+constexpr int MI_CBOX = 64;      // [64][6] floats: cell boxes
+
+template <int SPC>
+__global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int Q,
+                                                        const float* __restrict__ dataset,
+                                                        int* __restrict__ ws, int* __restrict__ idxs,
+                                                        int* __restrict__ dmax FC_PROBE_ARG) {
+  constexpr int CELL = SPC * 64;      // positions per cell
+  constexpr int NPOS = 64 * CELL;     // positions in LDS
+  constexpr int PPT = 16 * SPC;       // points per thread during the build
+  extern __shared__ float s_dyn[];
+  float* const X = s_dyn;          // x, y by position (cell * CELL + q)
+  float* const Y = X + NPOS;
+  float* const T = Y + NPOS;       // running minimum distance ("temp" of the reference) by position
+  int* const hist = reinterpret_cast<int*>(T + NPOS);
+  int* const misc = hist + FC_BINS1;
+  float* const miscf = reinterpret_cast<float*>(misc);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FC_PROBE
+  const long long t_build0_ = __builtin_readcyclecounter();
+#endif
+  dataset += (size_t)blockIdx.x * n * 3;
+  // workspace of the cloud: z by position (NPOS floats; LDS holds x, y and temp), then the point index by
+  // rank (n ints; rank = position with the pads of the cells squeezed out)
+  ws += (size_t)blockIdx.x * (NPOS + n);
+  float* const Zg = reinterpret_cast<float*>(ws);
+  int* const sorted_k = ws + NPOS;
+  idxs += (size_t)blockIdx.x * m;
+  if (dmax) dmax += (size_t)blockIdx.x * m;
+
+  // ------------------------------------------------------------------ build: points in registers
+  float px[PPT], py[PPT], pz[PPT];
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+  float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * 256 + tid;
+    if (k < n) {
+      px[i] = dataset[k * 3 + 0];
+      py[i] = dataset[k * 3 + 1];
+      pz[i] = dataset[k * 3 + 2];
+      lo[0] = __builtin_fminf(lo[0], px[i]); hi[0] = __builtin_fmaxf(hi[0], px[i]);
+      lo[1] = __builtin_fminf(lo[1], py[i]); hi[1] = __builtin_fmaxf(hi[1], py[i]);
+      lo[2] = __builtin_fminf(lo[2], pz[i]); hi[2] = __builtin_fmaxf(hi[2], pz[i]);
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+    }
+  }
+  for (int i = tid; i < FC_BINS1; i += 256) hist[i] = 0;
+  if (tid < 3) { misc[MI_BBOX + tid] = 0x7fffffff; misc[MI_BBOX + 3 + tid] = (int)0x80000000; }
+  if (tid < 8) { misc[MI_SLABR + tid * 2] = 0x7fffffff; misc[MI_SLABR + tid * 2 + 1] = (int)0x80000000; }
+  // pads (and skipped points) never update temp and never win: temp = -inf keeps d2 = -inf whatever
+  // coordinates the pad position holds
+  if (n < NPOS)
+    for (int i = tid; i < NPOS; i += 256) T[i] = -__builtin_inff();
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], s, 64));
+      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], s, 64));
+    }
+    if (lane == 0) {
+      atomicMin(&misc[MI_BBOX + a], fc_ord(lo[a]));
+      atomicMax(&misc[MI_BBOX + 3 + a], fc_ord(hi[a]));
+    }
+  }
+  __syncthreads();
+  // widest (a1) and second widest (a2) axis of the cloud's box; scale = bins / extent (0 when degenerate)
+  int a1, a2;
+  float lo1, sc1;
+  {
+    float e[3], l[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      l[a] = fc_unord(misc[MI_BBOX + a]);
+      e[a] = fc_unord(misc[MI_BBOX + 3 + a]) - l[a];
+      if (!(e[a] >= 0.f && e[a] <= 3.0e38f)) e[a] = 0.f;   // empty / infinite / NaN extent: one bin
+    }
+    a1 = (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);
+    const int b = a1 == 0 ? 1 : 0, c = a1 == 2 ? 1 : 2;    // the two other axes
+    a2 = e[b] >= e[c] ? b : c;
+    lo1 = l[a1];
+    sc1 = e[a1] > 0.f ? (float)FC_BINS1 / e[a1] : 0.f;
+  }
+  // slab boundaries (ranks along a1): slab s = [s*n/8, (s+1)*n/8)
+  int bnd[9];
+#pragma unroll
+  for (int s = 0; s <= 8; ++s) bnd[s] = (int)(((long long)s * n) >> 3);
+
+  // level 1: counting sort along a1
+#define FC_COORD(a, i) ((a) == 0 ? +px[i] : ((a) == 1 ? +py[i] : +pz[i]))
+#define FC_BIN1(i) min(max((int)((FC_COORD(a1, i) - lo1) * sc1), 0), FC_BINS1 - 1) /* NaN -> 0 */
+#pragma unroll
+  for (int i = 0; i < PPT; ++i)
+    if (i * 256 + tid < n) atomicAdd(&hist[FC_BIN1(i)], 1);
+  __syncthreads();
+  {
+    int v[8], run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = run; run += hist[tid * 8 + i]; }
+    const int incl = fc_wave_incl_scan(run, lane, 64);
+    if (lane == 63) misc[MI_WSCAN + wave] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < wave; ++w) base += misc[MI_WSCAN + w];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hist[tid * 8 + i] = base + v[i];
+  }
+  __syncthreads();
+  int slab[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    slab[i] = 0;
+    if (i * 256 + tid < n) {
+      const int r1 = atomicAdd(&hist[FC_BIN1(i)], 1);
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) s += (r1 >= bnd[q]) ? 1 : 0;
+      slab[i] = s;
+      const float c2 = FC_COORD(a2, i);
+      if (c2 == c2) {
+        atomicMin(&misc[MI_SLABR + s * 2], fc_ord(c2));
+        atomicMax(&misc[MI_SLABR + s * 2 + 1], fc_ord(c2));
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < FC_BINS1; i += 256) hist[i] = 0;
+  if (tid < 8) {
+    const float l = fc_unord(misc[MI_SLABR + tid * 2]);
+    float e = fc_unord(misc[MI_SLABR + tid * 2 + 1]) - l;
+    if (!(e >= 0.f && e <= 3.0e38f)) e = 0.f;
+    miscf[MI_SLABLO + tid] = l;
+    miscf[MI_SLABSC + tid] = e > 0.f ? (float)FC_BINS2 / e : 0.f;
+  }
+  __syncthreads();
+  // level 2: counting sort along a2 inside every slab
+#define FC_BIN2(i)                                                                                        \
+  (slab[i] * FC_BINS2 +                                                                                   \
+   min(max((int)((FC_COORD(a2, i) - miscf[MI_SLABLO + slab[i]]) * miscf[MI_SLABSC + slab[i]]), 0), FC_BINS2 - 1))
+#pragma unroll
+  for (int i = 0; i < PPT; ++i)
+    if (i * 256 + tid < n) atomicAdd(&hist[FC_BIN2(i)], 1);
+  __syncthreads();
+  {
+    // thread t: slab t/32, bins (t%32)*8 .. +7; 32-lane exclusive scan per slab
+    int v[8], run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = run; run += hist[tid * 8 + i]; }
+    const int incl = fc_wave_incl_scan(run, lane, 32);
+    const int base = incl - run;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hist[tid * 8 + i] = base + v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * 256 + tid;
+    if (k < n) {
+      const int s = slab[i];
+      const int r2 = atomicAdd(&hist[FC_BIN2(i)], 1);      // rank inside the slab
+      int b0 = 0, b1 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
+      const int sl = b1 - b0;
+      int t = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += (r2 >= ((q * sl) >> 3)) ? 1 : 0;
+      const int qq = r2 - ((t * sl) >> 3);
+      const int pos = (s * 8 + t) * CELL + qq;
+      X[pos] = px[i];
+      Y[pos] = py[i];
+      Zg[pos] = pz[i];
+      T[pos] = fc_skipped(px[i], py[i], pz[i]) ? -__builtin_inff() : 1e10f;
+      sorted_k[b0 + r2] = k;
+    }
+  }
+  __syncthreads();
+  // cell (s, t): ranks [bnd[s] + t*len/8, bnd[s] + (t+1)*len/8), positions cell*CELL + [0, cnt)
+  auto cell_start = [&](int c) {
+    const int s = c >> 3, t = c & 7;
+    int b0 = 0, b1 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
+    return b0 + ((t * (b1 - b0)) >> 3);
+  };
+  auto cell_cnt = [&](int c) {
+    const int s = c >> 3, t = c & 7;
+    int b0 = 0, b1 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
+    const int sl = b1 - b0;
+    return (((t + 1) * sl) >> 3) - ((t * sl) >> 3);
+  };
+  // cell boxes: wave w reduces cells w*16 .. w*16+15
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = wave * 16 + cc;
+    const int cnt = cell_cnt(c);
+    float bl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float bh[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int sl = 0; sl < SPC; ++sl) {
+      const int q = sl * 64 + lane;
+      if (q < cnt) {
+        const float x = X[c * CELL + q], y = Y[c * CELL + q], z = Zg[c * CELL + q];
+        bl[0] = __builtin_fminf(bl[0], x); bh[0] = __builtin_fmaxf(bh[0], x);
+        bl[1] = __builtin_fminf(bl[1], y); bh[1] = __builtin_fmaxf(bh[1], y);
+        bl[2] = __builtin_fminf(bl[2], z); bh[2] = __builtin_fmaxf(bh[2], z);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) {
+        bl[a] = __builtin_fminf(bl[a], __shfl_xor(bl[a], s, 64));
+        bh[a] = __builtin_fmaxf(bh[a], __shfl_xor(bh[a], s, 64));
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { miscf[MI_CBOX + c * 6 + a] = bl[a]; miscf[MI_CBOX + c * 6 + 3 + a] = bh[a]; }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+
+  // ------------------------------------------------------------------ the serial rounds: wave 0 alone
+  // lane c = cell c
+  const float lox = miscf[MI_CBOX + lane * 6 + 0], loy = miscf[MI_CBOX + lane * 6 + 1],
+              loz = miscf[MI_CBOX + lane * 6 + 2];
+  const float hix = miscf[MI_CBOX + lane * 6 + 3], hiy = miscf[MI_CBOX + lane * 6 + 4],
+              hiz = miscf[MI_CBOX + lane * 6 + 5];
+  const int cstart = cell_start(lane);      // rank of the cell's position 0
+  int cmax = __float_as_int(1e10f);         // cached cell maximum (bit pattern; < 0: no valid point)
+  int cpos = 0;                             // position (cell*CELL + q) of its arg-max under the tie order
+  float cwx = 0.f, cwy = 0.f, cwz = 0.f;    // ... and that point's coordinates
+
+  const float p0x = dataset[0], p0y = dataset[1], p0z = dataset[2];   // (uniform) point 0 = the seed
+  float sx = p0x, sy = p0y, sz = p0z;
+  int res = -1;          // lane (j & 63): rank of pick j, -1 = "index 0" (the seed / no valid point)
+  int resd = 0;          // lane (j & 63): winning distance of round j
+
+  struct CellRegs { float x[SPC], y[SPC], z[SPC], t[SPC]; };
+  auto load_cell = [&](int c, CellRegs& r) {
+#pragma unroll
+    for (int sl = 0; sl < SPC; ++sl) {
+      const int p = c * CELL + sl * 64 + lane;
+      r.x[sl] = X[p];
+      r.y[sl] = Y[p];
+      r.t[sl] = T[p];
+      r.z[sl] = Zg[p];
+    }
+  };
+
+#ifdef FC_PROBE
+  long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long last_ = __builtin_readcyclecounter();
+  const long long w0_ = last_;
+#endif
+  // One touched cell.  `full` (uniform): the cell's cached arg-max may have been lowered, so its maximum and
+  // arg-max are recomputed (wave reduction + locate); otherwise only the running minima are updated.
+  auto process = [&](int c, const CellRegs& r, bool full) {
+    int vi[SPC];
+#pragma unroll
+    for (int sl = 0; sl < SPC; ++sl) {
+      const float dx = r.x[sl] - sx, dy = r.y[sl] - sy, dz = r.z[sl] - sz;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = __builtin_fminf(d, r.t[sl]);
+      T[c * CELL + sl * 64 + lane] = d2;
+      vi[sl] = __float_as_int(d2);
+    }
+    if (!full) return;
+    // per lane: its largest value, the (lowest) slot that holds it, that point's coordinates, and whether a
+    // second slot holds the same value -- all before the wave reduction, off its dependency chain
+    int mloc = vi[0];
+    bool ltie = false;
+    if (SPC == 2) {
+      mloc = max(vi[0], vi[SPC - 1]);
+      ltie = vi[0] == vi[SPC - 1];
+    } else if (SPC == 3) {
+      const int a = vi[0], b = vi[SPC > 1 ? 1 : 0], cc = vi[SPC - 1];
+      mloc = max(max(a, b), cc);
+      ltie = max(min(a, b), min(max(a, b), cc)) == mloc;     // median == max
+    }
+    int lslot = SPC - 1;
+    float lx = r.x[SPC - 1], ly = r.y[SPC - 1], lz = r.z[SPC - 1];
+#pragma unroll
+    for (int sl = SPC - 2; sl >= 0; --sl) {      // (descending: the lowest slot wins among equals)
+      const bool here = vi[sl] == mloc;
+      lslot = here ? sl : lslot;
+      lx = here ? r.x[sl] : lx;
+      ly = here ? r.y[sl] : ly;
+      lz = here ? r.z[sl] : lz;
+    }
+    const int M = fc_wave_max_i32(mloc);
+    int q = 0;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (M >= 0) {
+      const unsigned long long e = __ballot(mloc == M);
+      const unsigned long long et = __ballot(mloc == M && ltie);
+      if (!(e & (e - 1)) && !et) {
+        const int wl = __builtin_ctzll(e);
+        q = __builtin_amdgcn_readlane(lslot, wl) * 64 + wl;
+        wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx), wl));
+        wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly), wl));
+        wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lz), wl));
+      } else {
+        // equal maxima inside the cell: the reference's order = smallest priority
+        const int cs = __builtin_amdgcn_readlane(cstart, c);
+        unsigned key = 0xffffffffu;
+#pragma unroll
+        for (int sl = 0; sl < SPC; ++sl) {
+          if (vi[sl] == M) {
+            const int qq = sl * 64 + lane;
+            const unsigned p = fc_prio(sorted_k[cs + qq], L, Q);
+            key = min(key, (p << 8) | (unsigned)qq);
+          }
+        }
+        key = fc_wave_min_u32(key);
+        q = (int)(key & 255u);
+        const int wl = q & 63, ws = q >> 6;      // (uniform)
+        float tx = r.x[0], ty = r.y[0], tz = r.z[0];
+#pragma unroll
+        for (int sl = 1; sl < SPC; ++sl) {
+          tx = ws == sl ? r.x[sl] : tx;
+          ty = ws == sl ? r.y[sl] : ty;
+          tz = ws == sl ? r.z[sl] : tz;
+        }
+        wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tx), wl));
+        wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty), wl));
+        wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz), wl));
+      }
+    }
+    // the arg-max's coordinates ride in the cell's cache: no memory access between two rounds
+    const bool me = lane == c;
+    cmax = me ? M : cmax;
+    cpos = me ? c * CELL + q : cpos;
+    cwx = me ? wx : cwx;
+    cwy = me ? wy : cwy;
+    cwz = me ? wz : cwz;
+  };
+
+  int cw = -1;           // the previous round's winning cell: always touched, its data already requested (ra)
+  CellRegs ra, rb;
+  for (int j = 1; j < m; ++j) {
+    FC_T(7)
+    // 1. one lane per cell: (a) cull test; (b) does the sample lower the cell's cached arg-max?  Only then
+    // can the cell's cached (max, arg-max) change: values never grow, and the arg-max keeps its value and its
+    // rank among equals.  Same unfused expression as the point distance, so the test is exact.
+    const float ax = __builtin_fmaxf(__builtin_fmaxf(lox - sx, sx - hix), 0.f);
+    const float ay = __builtin_fmaxf(__builtin_fmaxf(loy - sy, sy - hiy), 0.f);
+    const float az = __builtin_fmaxf(__builtin_fmaxf(loz - sz, sz - hiz), 0.f);
+    const float lb = ax * ax + ay * ay + az * az;
+    const float ex = cwx - sx, ey = cwy - sy, ez = cwz - sz;
+    const float dw = ex * ex + ey * ey + ez * ez;
+    // lb is NaN only for a sample with a NaN coordinate, and such a sample changes no running minimum
+    // (every d is NaN, fminf keeps temp): "<=" leaves every cell alone then.  An infinite coordinate gives
+    // lb = inf; a cell without valid points has cmax = -inf.
+    unsigned long long mask = __ballot(lb <= __int_as_float(cmax));
+    unsigned long long fullm = __ballot(dw < __int_as_float(cmax));
+    if (j == 1) { mask = ~0ull; fullm = ~0ull; }     // the caches are not valid yet
+    FC_COUNT(8, __builtin_popcountll(mask | (cw >= 0 ? 1ull << cw : 0ull)))
+    FC_T(0)
+    // 2. touched cells, the next one's data requested while this one is processed.  The sample's own cell
+    // comes first: its data was requested as soon as the arg-max of the previous round was known.
+    int c = cw;
+    if (c >= 0) {
+      mask &= ~(1ull << c);
+      fullm |= 1ull << c;
+    } else if (mask) {
+      c = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      load_cell(c, ra);
+    }
+    while (c >= 0) {
+      int cn = -1;
+      if (mask) {
+        cn = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        load_cell(cn, rb);
+      }
+      process(c, ra, (fullm >> c) & 1);
+      FC_T(1)
+      if (cn < 0) break;
+      c = -1;
+      if (mask) {
+        c = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        load_cell(c, ra);
+      }
+      process(cn, rb, (fullm >> cn) & 1);
+      FC_T(2)
+    }
+    // 3. arg-max over the cells
+    const int G = fc_wave_max_i32(cmax);
+    int wrank;
+    if (G < 0) {
+      // no valid point at all: the reference's threads keep (best = -1, besti = 0) -> index 0
+      wrank = -1;
+      cw = -1;
+      sx = p0x; sy = p0y; sz = p0z;
+    } else {
+      const unsigned long long g = __ballot(cmax == G);
+      cw = __builtin_ctzll(g);
+      if (g & (g - 1)) {
+        // tie across cells
+        unsigned key = 0xffffffffu;
+        if (cmax == G) key = (fc_prio(sorted_k[cstart + (cpos - lane * CELL)], L, Q) << 6) | (unsigned)lane;
+        key = fc_wave_min_u32(key);
+        cw = (int)(key & 63u);
+      }
+      if (j + 1 < m) load_cell(cw, ra);      // the next sample lies in this cell: it will be touched
+      const int wpos = __builtin_amdgcn_readlane(cpos, cw);
+      wrank = __builtin_amdgcn_readlane(cstart, cw) + (wpos - cw * CELL);
+      sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwx), cw));
+      sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwy), cw));
+      sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwz), cw));
+    }
+    FC_T(5)
+    // 4. results: 64 rounds per coalesced store
+    res = lane == (j & 63) ? wrank : res;
+    resd = lane == (j & 63) ? G : resd;
+    if ((j & 63) == 63 || j == m - 1) {
+      const int jj = (j & ~63) + lane;
+      if (jj <= j) {
+        idxs[jj] = res < 0 ? 0 : sorted_k[res];
+        if (dmax && jj >= 1) dmax[jj] = resd;
+      }
+    }
+    FC_T(6)
+  }
+#ifdef FC_PROBE
+  if (lane == 0 && blockIdx.x == 0 && dbg) {
+    for (int i = 0; i < 9; ++i) dbg[i] = acc_[i];
+    dbg[9] = __builtin_readcyclecounter() - w0_;
+    dbg[10] = w0_ - t_build0_;
+  }
+#endif
+  if (m == 1 && lane == 0) idxs[0] = 0;
+}
+
+}  // namespace
+
+// Workspace words (4 bytes each) per cloud for n points; 0 = this size is not served by the cell kernel.
+int pvn3d_fps_cells_ws_words(int n) {
+  if (n <= 64 || n > 12288) return 0;
+  const int spc = (n + 4095) / 4096;
+  return 64 * spc * 64 + n;
+}
+
+// b clouds of n points (64 < n <= 12288), ws = b * pvn3d_fps_cells_ws_words(n) words.  Returns -1 when the
+// shape is not served.
+int pvn3d_fps_cells_launch(int b, int n, int m, int L, int Q, const float* dataset, int* ws, int* idxs,
+                           int* dmax, hipStream_t st) {
+  if (n <= 64 || n > 12288 || !ws) return -1;
+  const int spc = (n + 4095) / 4096;
+  const size_t lds = (size_t)(3 * 64 * spc * 64 + FC_AUX_INTS) * sizeof(float);
+#define FC_LAUNCH(SPC)                                                                         \
+  do {                                                                                         \
+    auto kern = fps_cells_kernel<SPC>;                                                         \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(kern));                                \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, n, m, L, Q, dataset, ws, idxs, dmax FC_PROBE_NULL); \
+  } while (0)
+  if (spc == 1) FC_LAUNCH(1);
+  else if (spc == 2) FC_LAUNCH(2);
+  else FC_LAUNCH(3);
+#undef FC_LAUNCH
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

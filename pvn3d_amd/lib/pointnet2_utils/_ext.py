@@ -41,19 +41,35 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+# False: every size runs the register-resident kernel (one workgroup scans the whole cloud every round);
+# True: 4096 < N <= 12288 runs the spatially culled kernel (csrc/fps_cells.hip).  Same indices either way.
+FPS_CULLED = True
+
+
+def _fps_ws(B, N, dev):
+    words = lib.pvn3d_fps_ws_words(N) if FPS_CULLED else (N if N > 16384 else 0)
+    return torch.empty((B, words), dtype=torch.int32, device=dev) if words > 0 else None
+
+
 def furthest_point_sampling(points, nsamples):
     """points (B,N,3) -> (B,nsamples) int32.  sampling.cpp:65-86"""
     _chk(points, "points", torch.float32)
     _same_dev(points, points, "points")
     B, N = points.size(0), points.size(1)
     out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
-    # the reference's (B,N) 1e10 scratch is only needed beyond the register-resident sizes
-    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device) if N > 16384 else None
+    # the reference's (B,N) 1e10 scratch is replaced by the workspace the library asks for
+    ws = _fps_ws(B, N, points.device)
     with on_device(points.device):
-        check(lib.pvn3d_furthest_point_sampling(B, N, int(nsamples), points.data_ptr(),
-                                                tmp.data_ptr() if tmp is not None else None,
-                                                out.data_ptr(), _stream(points)),
-              "furthest_point_sampling")
+        if FPS_CULLED:
+            check(lib.pvn3d_furthest_point_sampling_ws(B, N, int(nsamples), points.data_ptr(),
+                                                       ws.data_ptr() if ws is not None else None,
+                                                       out.data_ptr(), None, None, 0, _stream(points)),
+                  "furthest_point_sampling")
+        else:
+            check(lib.pvn3d_furthest_point_sampling(B, N, int(nsamples), points.data_ptr(),
+                                                    ws.data_ptr() if ws is not None else None,
+                                                    out.data_ptr(), _stream(points)),
+                  "furthest_point_sampling")
     return out
 
 
@@ -68,7 +84,6 @@ def furthest_point_sampling_nested(points, nsamples, want_dmax=False, nest=None)
     _same_dev(points, points, "points")
     B, N = points.size(0), points.size(1)
     out = torch.zeros((B, nsamples), dtype=torch.int32, device=points.device)
-    tmp = torch.empty((B, N), dtype=torch.float32, device=points.device) if N > 16384 else None
     dmax = torch.empty((B, nsamples), dtype=torch.int32, device=points.device) if want_dmax else None
     flags, level = nest if nest is not None else (None, 0)
     if flags is not None:
@@ -76,11 +91,12 @@ def furthest_point_sampling_nested(points, nsamples, want_dmax=False, nest=None)
         _same_dev(points, flags, "nest first_rounds")
         if tuple(flags.shape) != (B, 3):
             raise RuntimeError("nest first_rounds must be (B, 3)")
+    ws = _fps_ws(B, N, points.device)
     with on_device(points.device):
-        check(lib.pvn3d_furthest_point_sampling_nested(
-            B, N, int(nsamples), points.data_ptr(), tmp.data_ptr() if tmp is not None else None, out.data_ptr(),
-            dmax.data_ptr() if dmax is not None else None, flags.data_ptr() if flags is not None else None,
-            int(level), _stream(points)), "furthest_point_sampling_nested")
+        fn = lib.pvn3d_furthest_point_sampling_ws if FPS_CULLED else lib.pvn3d_furthest_point_sampling_nested
+        check(fn(B, N, int(nsamples), points.data_ptr(), ws.data_ptr() if ws is not None else None, out.data_ptr(),
+                 dmax.data_ptr() if dmax is not None else None, flags.data_ptr() if flags is not None else None,
+                 int(level), _stream(points)), "furthest_point_sampling_nested")
     return out, dmax
 
 

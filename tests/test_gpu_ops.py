@@ -38,6 +38,62 @@ def test_fps_index_exact(ext, orc, dev, b, n, m, wrap):
     assert np.array_equal(got, orc.furthest_point_sampling(xyz, m))
 
 
+@pytest.mark.parametrize("case", ["odd_sizes", "lattice", "few_unique", "skipped_most", "all_skipped", "nonfinite",
+                                  "collinear", "far_offset", "full_run"])
+def test_fps_culled_kernel_index_exact(ext, orc, dev, case):
+    """csrc/fps_cells.hip (4096 < n <= 12288: 64 equal-count cells, exact bounding-box culling, one wave per
+    cloud) against the oracle and against the register-resident kernel, on the inputs that stress its three
+    exactness arguments: the cull bound (monotone rounding), the tie order (priorities looked up only when a
+    ballot finds equal maxima) and degenerate boxes / pads (n not a multiple of 4096, empty cells, NaN / inf)."""
+    g = np.random.default_rng(7)
+    if case == "odd_sizes":
+        runs = [(clouds(41, 2, 4097, 0.1), 300), (clouds(42, 1, 5000, 0.0), 700), (clouds(43, 3, 6145, 0.2), 129),
+                (clouds(44, 1, 8192, 0.1), 1024), (clouds(45, 2, 9999, 0.05), 513), (clouds(46, 1, 12287, 0.0), 64)]
+    elif case == "lattice":
+        runs = [(_lattice_cloud(12288, 5), 2048), (_lattice_cloud(7000, 6), 1500)]
+    elif case == "few_unique":                      # fewer distinct points than samples: rounds with D = 0
+        runs = [(np.tile(clouds(47, 1, 300, 0.0), (1, 41, 1))[:, :12288], 1000),
+                (np.tile(clouds(48, 1, 5, 0.0), (1, 1000, 1)), 64)]
+    elif case == "skipped_most":
+        x = clouds(49, 2, 12288, 0.1)
+        x[0, 5:12000] *= np.float32(1e-3)           # |p|^2 <= 1e-3: never sampled, never a candidate
+        x[1, ::2] *= np.float32(1e-3)
+        runs = [(x, 600)]
+    elif case == "all_skipped":
+        x = (g.normal(size=(2, 6000, 3)) * 1e-3).astype(np.float32)
+        x[1, 17] = (0.5, 0.2, 0.9)                  # one valid point in the second cloud
+        runs = [(x, 50)]
+    elif case == "nonfinite":
+        x = clouds(50, 2, 12288, 0.0)
+        x[0, 100, 1] = np.nan
+        x[0, 5000] = (np.inf, 0.1, 0.9)
+        x[0, 7000, 2] = -np.inf
+        x[1, 0, 0] = np.nan                         # the seed itself
+        runs = [(x, 300)]
+    elif case == "collinear":                       # zero extent along two axes: one histogram bin
+        t = g.random(8000).astype(np.float32)
+        x = np.stack([t, np.full_like(t, 0.25), np.full_like(t, 0.9)], -1)[None]
+        runs = [(x, 400)]
+    elif case == "far_offset":                      # millimetres, far from the origin
+        runs = [(clouds(51, 1, 12288, 0.1) * np.float32(1000.0) + np.float32(50000.0), 512)]
+    else:                                           # m == n: the run exhausts the cloud
+        runs = [(clouds(52, 1, 4500, 0.3), 4500)]
+    for xyz, m in runs:
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        want = orc.furthest_point_sampling(xyz, m)
+        got = ext.furthest_point_sampling(T(xyz, dev), m).cpu().numpy()
+        assert np.array_equal(got, want), (case, xyz.shape, m, np.argwhere(got != want)[:4])
+        sel, dmax = ext.furthest_point_sampling_nested(T(xyz, dev), m, want_dmax=True)
+        assert np.array_equal(sel.cpu().numpy(), want)
+        ext.FPS_CULLED = False
+        try:
+            sel0, dmax0 = ext.furthest_point_sampling_nested(T(xyz, dev), m, want_dmax=True)
+        finally:
+            ext.FPS_CULLED = True
+        assert np.array_equal(sel0.cpu().numpy(), want)
+        assert np.array_equal(dmax.cpu().numpy()[:, 1:], dmax0.cpu().numpy()[:, 1:])      # per-round winning distances
+
+
 def _lattice_cloud(n, seed):
     """Points on a coarse lattice (many exactly equal distances) in random order, some repeated."""
     g = np.random.default_rng(seed)
