@@ -10,11 +10,18 @@
 //      cell's bounding box, evaluated with the SAME unfused fp32 expression as the point
 //      distance; rounding is monotone, so LB <= d(k) holds exactly for every point k of the cell,
 //      and LB > max_k temp[k] proves that min(d, temp) leaves the whole cell unchanged;
-//   2. updates only the touched cells (2.1 of 64 on average on the BASELINE clouds): coordinates
-//      from LDS, running minima from a VGPR array indexed through M0 (s_set_gpr_idx), one DPP
-//      wave reduction per touched cell refreshes its cached (max, arg-max position);
+//   2. updates only the touched cells (2.15 of 64 on average on the BASELINE clouds): coordinates and
+//      running minima from LDS.  A second lane-parallel test -- does the sample lower the cell's CACHED
+//      arg-max point? -- decides whether the cell's cached (max, arg-max) can change at all (values never
+//      grow, the arg-max keeps its value and its rank among equals): only then (1.3 cells per round, the
+//      sample's own cell included) a DPP wave reduction and a locate step refresh the cache;
 //   3. takes the arg-max over the 64 cached cell maxima (one more DPP reduction), no barrier, no
-//      cross-wave exchange: the serial chain lives in ONE wave.
+//      cross-wave exchange: the serial chain lives in ONE wave, whose cost is the NUMBER of instructions on
+//      its path (a wave alone on its SIMD issues every 5 cycles at best, every 8 when dependent -- SALU and
+//      branches included, tools/issue_bench.hip), so the round is written for few instructions: reductions
+//      as single-instruction DPP steps with the per-lane selects in their wait states, v_writelane cache
+//      updates, the sample's coordinates carried in the cell caches (no memory access between rounds),
+//      data of the sample's own cell and of the next two touched cells requested ahead.
 // Ties (equal maxima inside a cell or across cells) are detected with ballots and resolved with
 // the reference block's order -- smallest bit-reversed (k mod bs), then smallest k, i.e. the
 // smallest fps_prio(k) of sampling.hip -- by looking the candidates' indices up in the scratch
@@ -25,20 +32,8 @@
 // Arithmetic: -ffp-contract=off; d = ((dx*dx + dy*dy) + dz*dz), one rounding per operation.
 #include "common.h"
 
-// FC_PROBE (tools/fps_cells_probe.hip only): per-phase s_memtime accounting of the serial rounds.
-#ifdef FC_PROBE
-#define FC_PROBE_ARG , long long* __restrict__ dbg
-#define FC_PROBE_NULL , (long long*)nullptr
-#define FC_T(i) { const long long t_ = __builtin_readcyclecounter(); acc_[i] += t_ - last_; last_ = t_; }
-#define FC_COUNT(i, v) { acc_[i] += (v); }
-#else
-#define FC_PROBE_ARG
-#define FC_PROBE_NULL
-#define FC_T(i)
-#define FC_COUNT(i, v)
-#endif
-
 namespace {
+
 
 // wave64 reductions on the DPP path, one instruction per step (v_max_i32 with the DPP modifier on src0; the
 // compiler's own lowering of update_dpp is v_mov + s_nop + v_mov_dpp + v_max per step, and in a wave that
@@ -134,7 +129,7 @@ template <int SPC>
 __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int Q,
                                                         const float* __restrict__ dataset,
                                                         int* __restrict__ ws, int* __restrict__ idxs,
-                                                        int* __restrict__ dmax FC_PROBE_ARG) {
+                                                        int* __restrict__ dmax) {
   constexpr int CELL = SPC * 64;      // positions per cell
   constexpr int NPOS = 64 * CELL;     // positions in LDS
   constexpr int PPT = 16 * SPC;       // points per thread during the build
@@ -142,14 +137,17 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
   float* const X = s_dyn;          // x, y by position (cell * CELL + q)
   float* const Y = X + NPOS;
   float* const T = Y + NPOS;       // running minimum distance ("temp" of the reference) by position
-  int* const hist = reinterpret_cast<int*>(T + NPOS);
+  // z: in LDS while four arrays fit (SPC < 3); at SPC = 3 (12288 points x 16 B = 192 KiB > 160 KiB) it stays in
+  // the workspace (48 KiB, L2-resident, requested a whole cull test ahead of its use).  Measured: keeping it on
+  // chip instead (slot 2 in the histogram region, slots 0 / 1 in VGPR vectors read through s_set_gpr_idx)
+  // changes nothing, 1.585 vs 1.536 ms -- the round is bound by dependent instruction issue, not by latency.
+  constexpr bool Z_IN_LDS = SPC < 3;
+  float* const Zl = T + NPOS;                                   // (SPC < 3) z by position
+  int* const hist = reinterpret_cast<int*>(T + NPOS + (Z_IN_LDS ? NPOS : 0));
   int* const misc = hist + FC_BINS1;
   float* const miscf = reinterpret_cast<float*>(misc);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef FC_PROBE
-  const long long t_build0_ = __builtin_readcyclecounter();
-#endif
   dataset += (size_t)blockIdx.x * n * 3;
   // workspace of the cloud: z by position (NPOS floats; LDS holds x, y and temp), then the point index by
   // rank (n ints; rank = position with the pads of the cells squeezed out)
@@ -303,7 +301,8 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
       const int pos = (s * 8 + t) * CELL + qq;
       X[pos] = px[i];
       Y[pos] = py[i];
-      Zg[pos] = pz[i];
+      if (Z_IN_LDS) Zl[pos] = pz[i];
+      else Zg[pos] = pz[i];
       T[pos] = fc_skipped(px[i], py[i], pz[i]) ? -__builtin_inff() : 1e10f;
       sorted_k[b0 + r2] = k;
     }
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     for (int sl = 0; sl < SPC; ++sl) {
       const int q = sl * 64 + lane;
       if (q < cnt) {
-        const float x = X[c * CELL + q], y = Y[c * CELL + q], z = Zg[c * CELL + q];
+        const float x = X[c * CELL + q], y = Y[c * CELL + q], z = Z_IN_LDS ? Zl[c * CELL + q] : Zg[c * CELL + q];
         bl[0] = __builtin_fminf(bl[0], x); bh[0] = __builtin_fmaxf(bh[0], x);
         bl[1] = __builtin_fminf(bl[1], y); bh[1] = __builtin_fmaxf(bh[1], y);
         bl[2] = __builtin_fminf(bl[2], z); bh[2] = __builtin_fmaxf(bh[2], z);
@@ -358,6 +357,9 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
   if (wave != 0) return;
 
   // ------------------------------------------------------------------ the serial rounds: wave 0 alone
+  // A wave that runs alone on its SIMD issues one instruction every 5 cycles at best and every 8 when it
+  // depends on the previous one, SALU and branches included (tools/issue_bench.hip): the round is written
+  // for the smallest instruction count on its path, not for arithmetic throughput.
   // lane c = cell c
   const float lox = miscf[MI_CBOX + lane * 6 + 0], loy = miscf[MI_CBOX + lane * 6 + 1],
               loz = miscf[MI_CBOX + lane * 6 + 2];
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
               hiz = miscf[MI_CBOX + lane * 6 + 5];
   const int cstart = cell_start(lane);      // rank of the cell's position 0
   int cmax = __float_as_int(1e10f);         // cached cell maximum (bit pattern; < 0: no valid point)
-  int cpos = 0;                             // position (cell*CELL + q) of its arg-max under the tie order
+  int cq = 0;                               // in-cell position q of its arg-max under the tie order
   float cwx = 0.f, cwy = 0.f, cwz = 0.f;    // ... and that point's coordinates
 
   const float p0x = dataset[0], p0y = dataset[1], p0z = dataset[2];   // (uniform) point 0 = the seed
@@ -375,111 +377,160 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
 
   struct CellRegs { float x[SPC], y[SPC], z[SPC], t[SPC]; };
   auto load_cell = [&](int c, CellRegs& r) {
+    const int p = c * CELL + lane;
 #pragma unroll
     for (int sl = 0; sl < SPC; ++sl) {
-      const int p = c * CELL + sl * 64 + lane;
-      r.x[sl] = X[p];
-      r.y[sl] = Y[p];
-      r.t[sl] = T[p];
-      r.z[sl] = Zg[p];
+      r.x[sl] = X[p + sl * 64];
+      r.y[sl] = Y[p + sl * 64];
+      r.t[sl] = T[p + sl * 64];
+      r.z[sl] = Z_IN_LDS ? Zl[p + sl * 64] : Zg[p + sl * 64];
     }
   };
-
-#ifdef FC_PROBE
-  long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long last_ = __builtin_readcyclecounter();
-  const long long w0_ = last_;
-#endif
-  // One touched cell.  `full` (uniform): the cell's cached arg-max may have been lowered, so its maximum and
-  // arg-max are recomputed (wave reduction + locate); otherwise only the running minima are updated.
-  auto process = [&](int c, const CellRegs& r, bool full) {
-    int vi[SPC];
+  // running minima of one cell against the current sample; returns the new values' bit patterns
+  auto update_cell = [&](int c, const CellRegs& r, int (&vi)[SPC]) {
 #pragma unroll
     for (int sl = 0; sl < SPC; ++sl) {
       const float dx = r.x[sl] - sx, dy = r.y[sl] - sy, dz = r.z[sl] - sz;
       const float d = dx * dx + dy * dy + dz * dz;
-      const float d2 = __builtin_fminf(d, r.t[sl]);
+      // fminf without the compiler's canonicalising v_max(t, t): t is never NaN (1e10, -inf or an earlier
+      // minimum), and v_min_f32 returns the other operand for a NaN d
+      float d2;
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(r.t[sl]));
       T[c * CELL + sl * 64 + lane] = d2;
       vi[sl] = __float_as_int(d2);
     }
-    if (!full) return;
-    // per lane: its largest value, the (lowest) slot that holds it, that point's coordinates, and whether a
-    // second slot holds the same value -- all before the wave reduction, off its dependency chain
-    int mloc = vi[0];
-    bool ltie = false;
-    if (SPC == 2) {
-      mloc = max(vi[0], vi[SPC - 1]);
-      ltie = vi[0] == vi[SPC - 1];
-    } else if (SPC == 3) {
-      const int a = vi[0], b = vi[SPC > 1 ? 1 : 0], cc = vi[SPC - 1];
-      mloc = max(max(a, b), cc);
-      ltie = max(min(a, b), min(max(a, b), cc)) == mloc;     // median == max
+  };
+  // A cell whose cached arg-max may have been lowered: new maximum (DPP wave reduction) and arg-max.  The
+  // per-lane "which slot holds my largest value, and that point's coordinates" selects fill the wait states
+  // of the reduction steps (a DPP read needs two after the write of its source).
+  auto refresh_cell = [&](int c, const CellRegs& r, const int (&vi)[SPC]) {
+    int M, ls = 0, mloc = vi[0];
+    float lx = r.x[0], ly = r.y[0], lz = r.z[0];
+    unsigned long long ct = 0;      // lanes where a second slot holds the lane's largest value
+    if constexpr (SPC == 3) {
+      mloc = max(max(vi[0], vi[1]), vi[2]);
+      int red, md;
+      unsigned long long c0, c1;
+      asm volatile(
+          "v_mov_b32 %[red], %[mloc]\n\t"
+          "v_cmp_eq_u32 %[c1], %[v1], %[mloc]\n\t"
+          "v_cmp_eq_u32 %[c0], %[v0], %[mloc]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_med3_i32 %[md], %[v0], %[v1], %[v2]\n\t"
+          "v_cndmask_b32_e64 %[ls], 2, 1, %[c1]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[lx], %[x2], %[x1], %[c1]\n\t"
+          "v_cndmask_b32_e64 %[ly], %[y2], %[y1], %[c1]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[lz], %[z2], %[z1], %[c1]\n\t"
+          "v_cndmask_b32_e64 %[ls], %[ls], 0, %[c0]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[lx], %[lx], %[x0], %[c0]\n\t"
+          "v_cndmask_b32_e64 %[ly], %[ly], %[y0], %[c0]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[lz], %[lz], %[z0], %[c0]\n\t"
+          "v_cmp_eq_u32 %[ct], %[md], %[mloc]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_readlane_b32 %[M], %[red], 63\n\t"
+          "s_nop 1"
+          : [M] "=s"(M), [red] "=&v"(red), [md] "=&v"(md), [ls] "=&v"(ls), [lx] "=&v"(lx), [ly] "=&v"(ly),
+            [lz] "=&v"(lz), [c0] "=&s"(c0), [c1] "=&s"(c1), [ct] "=&s"(ct)
+          : [mloc] "v"(mloc), [v0] "v"(vi[0]), [v1] "v"(vi[1]), [v2] "v"(vi[2]), [x0] "v"(r.x[0]), [x1] "v"(r.x[1]),
+            [x2] "v"(r.x[2]), [y0] "v"(r.y[0]), [y1] "v"(r.y[1]), [y2] "v"(r.y[2]), [z0] "v"(r.z[0]),
+            [z1] "v"(r.z[1]), [z2] "v"(r.z[2]));
+    } else if constexpr (SPC == 2) {
+      mloc = max(vi[0], vi[1]);
+      int red;
+      unsigned long long c0;
+      asm volatile(
+          "v_mov_b32 %[red], %[mloc]\n\t"
+          "v_cmp_eq_u32 %[c0], %[v0], %[mloc]\n\t"
+          "v_cmp_eq_u32 %[ct], %[v0], %[v1]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[ls], 1, 0, %[c0]\n\t"
+          "v_cndmask_b32_e64 %[lx], %[x1], %[x0], %[c0]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_cndmask_b32_e64 %[ly], %[y1], %[y0], %[c0]\n\t"
+          "v_cndmask_b32_e64 %[lz], %[z1], %[z0], %[c0]\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_max_i32_dpp %[red], %[red], %[red] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+          "s_nop 1\n\t"
+          "v_readlane_b32 %[M], %[red], 63\n\t"
+          "s_nop 1"
+          : [M] "=s"(M), [red] "=&v"(red), [ls] "=&v"(ls), [lx] "=&v"(lx), [ly] "=&v"(ly), [lz] "=&v"(lz),
+            [c0] "=&s"(c0), [ct] "=&s"(ct)
+          : [mloc] "v"(mloc), [v0] "v"(vi[0]), [v1] "v"(vi[1]), [x0] "v"(r.x[0]), [x1] "v"(r.x[1]),
+            [y0] "v"(r.y[0]), [y1] "v"(r.y[1]), [z0] "v"(r.z[0]), [z1] "v"(r.z[1]));
+    } else {
+      M = fc_wave_max_i32(mloc);
     }
-    int lslot = SPC - 1;
-    float lx = r.x[SPC - 1], ly = r.y[SPC - 1], lz = r.z[SPC - 1];
-#pragma unroll
-    for (int sl = SPC - 2; sl >= 0; --sl) {      // (descending: the lowest slot wins among equals)
-      const bool here = vi[sl] == mloc;
-      lslot = here ? sl : lslot;
-      lx = here ? r.x[sl] : lx;
-      ly = here ? r.y[sl] : ly;
-      lz = here ? r.z[sl] : lz;
-    }
-    const int M = fc_wave_max_i32(mloc);
     int q = 0;
     float wx = 0.f, wy = 0.f, wz = 0.f;
-    if (M >= 0) {
-      const unsigned long long e = __ballot(mloc == M);
-      const unsigned long long et = __ballot(mloc == M && ltie);
-      if (!(e & (e - 1)) && !et) {
-        const int wl = __builtin_ctzll(e);
-        q = __builtin_amdgcn_readlane(lslot, wl) * 64 + wl;
-        wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx), wl));
-        wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly), wl));
-        wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lz), wl));
-      } else {
-        // equal maxima inside the cell: the reference's order = smallest priority
-        const int cs = __builtin_amdgcn_readlane(cstart, c);
-        unsigned key = 0xffffffffu;
+    const unsigned long long e = __ballot(mloc == M);
+    if (__builtin_expect(M >= 0 && !(e & (e - 1)) && !(e & ct), 1)) {
+      const int wl = __builtin_ctzll(e);
+      q = __builtin_amdgcn_readlane(ls, wl) * 64 + wl;
+      wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx), wl));
+      wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly), wl));
+      wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lz), wl));
+    } else if (M >= 0) {
+      // equal maxima inside the cell: the reference's order = smallest priority
+      const int cs = __builtin_amdgcn_readlane(cstart, c);
+      unsigned key = 0xffffffffu;
 #pragma unroll
-        for (int sl = 0; sl < SPC; ++sl) {
-          if (vi[sl] == M) {
-            const int qq = sl * 64 + lane;
-            const unsigned p = fc_prio(sorted_k[cs + qq], L, Q);
-            key = min(key, (p << 8) | (unsigned)qq);
-          }
+      for (int sl = 0; sl < SPC; ++sl) {
+        if (vi[sl] == M) {
+          const int qq = sl * 64 + lane;
+          const unsigned p = fc_prio(sorted_k[cs + qq], L, Q);
+          key = min(key, (p << 8) | (unsigned)qq);
         }
-        key = fc_wave_min_u32(key);
-        q = (int)(key & 255u);
-        const int wl = q & 63, ws = q >> 6;      // (uniform)
-        float tx = r.x[0], ty = r.y[0], tz = r.z[0];
-#pragma unroll
-        for (int sl = 1; sl < SPC; ++sl) {
-          tx = ws == sl ? r.x[sl] : tx;
-          ty = ws == sl ? r.y[sl] : ty;
-          tz = ws == sl ? r.z[sl] : tz;
-        }
-        wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tx), wl));
-        wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty), wl));
-        wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz), wl));
       }
+      key = fc_wave_min_u32(key);
+      q = (int)(key & 255u);
+      const int wl = q & 63, ws = q >> 6;      // (uniform)
+      float tx = r.x[0], ty = r.y[0], tz = r.z[0];
+#pragma unroll
+      for (int sl = 1; sl < SPC; ++sl) {
+        tx = ws == sl ? r.x[sl] : tx;
+        ty = ws == sl ? r.y[sl] : ty;
+        tz = ws == sl ? r.z[sl] : tz;
+      }
+      wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tx), wl));
+      wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty), wl));
+      wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tz), wl));
     }
-    // the arg-max's coordinates ride in the cell's cache: no memory access between two rounds
-    const bool me = lane == c;
-    cmax = me ? M : cmax;
-    cpos = me ? c * CELL + q : cpos;
-    cwx = me ? wx : cwx;
-    cwy = me ? wy : cwy;
-    cwz = me ? wz : cwz;
+    // the arg-max's coordinates ride in the cell's cache (lane c): no memory access between two rounds
+    // (two SGPR operands exceed the constant bus: the lane select goes through M0, like the compiler's own
+    // v_writelane lowering)
+    asm volatile(
+        "s_mov_b32 m0, %[c]\n\t"
+        "s_nop 1\n\t"
+        "v_writelane_b32 %[cmax], %[M], m0\n\t"
+        "v_writelane_b32 %[cq], %[q], m0\n\t"
+        "v_writelane_b32 %[cwx], %[wx], m0\n\t"
+        "v_writelane_b32 %[cwy], %[wy], m0\n\t"
+        "v_writelane_b32 %[cwz], %[wz], m0"
+        : [cmax] "+v"(cmax), [cq] "+v"(cq), [cwx] "+v"(cwx), [cwy] "+v"(cwy), [cwz] "+v"(cwz)
+        : [M] "s"(M), [q] "s"(q), [wx] "s"(wx), [wy] "s"(wy), [wz] "s"(wz), [c] "s"(c)
+        : "m0");
   };
 
-  int cw = -1;           // the previous round's winning cell: always touched, its data already requested (ra)
-  CellRegs ra, rb;
+  int cw = -1;           // the previous round's winning cell: always touched
+  unsigned long long force = ~0ull;      // first round: the caches are not valid yet, every cell is refreshed
+  CellRegs ra, rb, rc;
   for (int j = 1; j < m; ++j) {
-    FC_T(7)
+    // the sample's own cell is certainly touched: request its data before anything else (unconditionally --
+    // cell 0 when there is none -- so that the registers are not merged with last round's under a wait)
+    load_cell(cw < 0 ? 0 : cw, ra);
     // 1. one lane per cell: (a) cull test; (b) does the sample lower the cell's cached arg-max?  Only then
     // can the cell's cached (max, arg-max) change: values never grow, and the arg-max keeps its value and its
-    // rank among equals.  Same unfused expression as the point distance, so the test is exact.
+    // rank among equals.  Same unfused expression as the point distance, so both tests are exact.
     const float ax = __builtin_fmaxf(__builtin_fmaxf(lox - sx, sx - hix), 0.f);
     const float ay = __builtin_fmaxf(__builtin_fmaxf(loy - sy, sy - hiy), 0.f);
     const float az = __builtin_fmaxf(__builtin_fmaxf(loz - sz, sz - hiz), 0.f);
@@ -491,43 +542,48 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     // lb = inf; a cell without valid points has cmax = -inf.
     unsigned long long mask = __ballot(lb <= __int_as_float(cmax));
     unsigned long long fullm = __ballot(dw < __int_as_float(cmax));
-    if (j == 1) { mask = ~0ull; fullm = ~0ull; }     // the caches are not valid yet
-    FC_COUNT(8, __builtin_popcountll(mask | (cw >= 0 ? 1ull << cw : 0ull)))
-    FC_T(0)
-    // 2. touched cells, the next one's data requested while this one is processed.  The sample's own cell
-    // comes first: its data was requested as soon as the arg-max of the previous round was known.
-    int c = cw;
-    if (c >= 0) {
-      mask &= ~(1ull << c);
-      fullm |= 1ull << c;
-    } else if (mask) {
-      c = __builtin_ctzll(mask);
+    // the own cell is handled apart (cw = -1 clears bit 63: only when no cell is touched, or before `force`)
+    asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(cw));
+    mask |= force;
+    fullm = (fullm | force) & mask;
+    force = 0;
+    // 2. the first two other touched cells: data requested now, used after the sample's own cell
+    int c1 = -1, c2 = -1;
+    if (mask) {
+      c1 = __builtin_ctzll(mask);
       mask &= mask - 1;
-      load_cell(c, ra);
+      load_cell(c1, rb);
+      if (mask) {
+        c2 = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        load_cell(c2, rc);
+      }
     }
-    while (c >= 0) {
-      int cn = -1;
-      if (mask) {
-        cn = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        load_cell(cn, rb);
-      }
-      process(c, ra, (fullm >> c) & 1);
-      FC_T(1)
-      if (cn < 0) break;
-      c = -1;
-      if (mask) {
-        c = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        load_cell(c, ra);
-      }
-      process(cn, rb, (fullm >> cn) & 1);
-      FC_T(2)
+    // the sample's own cell: its data was requested as soon as the arg-max of the previous round was known
+    if (__builtin_expect(cw >= 0, 1)) {
+      int vi[SPC];
+      update_cell(cw, ra, vi);
+      refresh_cell(cw, ra, vi);
+    }
+    if (c1 >= 0) {
+      int vi[SPC];
+      update_cell(c1, rb, vi);
+      if (c2 >= 0) update_cell(c2, rc, vi);
+    }
+    // the rest: further touched cells, and the cells above whose arg-max was lowered
+    mask |= fullm;
+    while (mask) {
+      const int c = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      load_cell(c, rb);
+      int vi[SPC];
+      update_cell(c, rb, vi);          // (idempotent for a cell that was updated above)
+      if ((fullm >> c) & 1) refresh_cell(c, rb, vi);
     }
     // 3. arg-max over the cells
     const int G = fc_wave_max_i32(cmax);
     int wrank;
-    if (G < 0) {
+    if (__builtin_expect(G < 0, 0)) {
       // no valid point at all: the reference's threads keep (best = -1, besti = 0) -> index 0
       wrank = -1;
       cw = -1;
@@ -535,24 +591,24 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     } else {
       const unsigned long long g = __ballot(cmax == G);
       cw = __builtin_ctzll(g);
-      if (g & (g - 1)) {
+      if (__builtin_expect((g & (g - 1)) != 0, 0)) {
         // tie across cells
         unsigned key = 0xffffffffu;
-        if (cmax == G) key = (fc_prio(sorted_k[cstart + (cpos - lane * CELL)], L, Q) << 6) | (unsigned)lane;
+        if (cmax == G) key = (fc_prio(sorted_k[cstart + cq], L, Q) << 6) | (unsigned)lane;
         key = fc_wave_min_u32(key);
         cw = (int)(key & 63u);
       }
-      if (j + 1 < m) load_cell(cw, ra);      // the next sample lies in this cell: it will be touched
-      const int wpos = __builtin_amdgcn_readlane(cpos, cw);
-      wrank = __builtin_amdgcn_readlane(cstart, cw) + (wpos - cw * CELL);
+      wrank = __builtin_amdgcn_readlane(cstart, cw) + __builtin_amdgcn_readlane(cq, cw);
       sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwx), cw));
       sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwy), cw));
       sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwz), cw));
     }
-    FC_T(5)
     // 4. results: 64 rounds per coalesced store
-    res = lane == (j & 63) ? wrank : res;
-    resd = lane == (j & 63) ? G : resd;
+    {
+      const int jl = j & 63;
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 1\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                   : "+v"(res), "+v"(resd) : "s"(wrank), "s"(G), "s"(jl) : "m0");
+    }
     if ((j & 63) == 63 || j == m - 1) {
       const int jj = (j & ~63) + lane;
       if (jj <= j) {
@@ -560,15 +616,7 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
         if (dmax && jj >= 1) dmax[jj] = resd;
       }
     }
-    FC_T(6)
   }
-#ifdef FC_PROBE
-  if (lane == 0 && blockIdx.x == 0 && dbg) {
-    for (int i = 0; i < 9; ++i) dbg[i] = acc_[i];
-    dbg[9] = __builtin_readcyclecounter() - w0_;
-    dbg[10] = w0_ - t_build0_;
-  }
-#endif
   if (m == 1 && lane == 0) idxs[0] = 0;
 }
 
@@ -587,12 +635,12 @@ int pvn3d_fps_cells_launch(int b, int n, int m, int L, int Q, const float* datas
                            int* dmax, hipStream_t st) {
   if (n <= 64 || n > 12288 || !ws) return -1;
   const int spc = (n + 4095) / 4096;
-  const size_t lds = (size_t)(3 * 64 * spc * 64 + FC_AUX_INTS) * sizeof(float);
+  const size_t lds = (size_t)((spc < 3 ? 4 : 3) * 64 * spc * 64 + FC_AUX_INTS) * sizeof(float);
 #define FC_LAUNCH(SPC)                                                                         \
   do {                                                                                         \
     auto kern = fps_cells_kernel<SPC>;                                                         \
     PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(kern));                                \
-    hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, n, m, L, Q, dataset, ws, idxs, dmax FC_PROBE_NULL); \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, n, m, L, Q, dataset, ws, idxs, dmax); \
   } while (0)
   if (spc == 1) FC_LAUNCH(1);
   else if (spc == 2) FC_LAUNCH(2);
