@@ -14,6 +14,8 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_ll = ctypes.c_longlong
+_d = ctypes.c_double
 
 # name -> (restype, argtypes); one entry per declaration in include/pvn3d_hip.h
 SIGNATURES = {
@@ -53,6 +55,25 @@ SIGNATURES = {
     "pvn3d_relabel_by_centre": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pvn3d_add_adds_workspace_bytes": (_sz, [_i, _i]),
     "pvn3d_add_adds_batch": (_i, [_i, _i, _p, _p, _p, _p, _p, _sz, _p, _p, _p]),
+    # training-mode SharedMLP on bf16 MFMA (csrc/mlp_train.hip)
+    "pvn3d_mt_gemm_nt": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p]),
+    "pvn3d_mt_gemm_nt_stat_rows": (_i, [_i]),
+    "pvn3d_mt_gemm_nt_splitk": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p]),
+    "pvn3d_mt_transpose": (_i, [_ll, _i, _p, _p, _ll, _p]),
+    "pvn3d_mt_pack_weight": (_i, [_i, _i, _p, _i, _i, _p, _i, _i, _p]),
+    "pvn3d_mt_gather_sa": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _ll, _ll, _ll, _p, _p, _i, _p]),
+    "pvn3d_mt_unpack_cm": (_i, [_i, _i, _i, _i, _i, _p, _p, _p]),
+    "pvn3d_mt_gather_fp": (_i, [_i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _p, _ll, _ll, _ll, _p, _p, _p, _i, _p]),
+    "pvn3d_mt_bn_finalize": (_i, [_i, _i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_relu_apply": (_i, [_ll, _i, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_pool_max": (_i, [_ll, _i, _i, _i, _p, _p, _ll, _p, _p]),
+    "pvn3d_mt_pool_bwd": (_i, [_ll, _i, _i, _i, _p, _ll, _p, _p, _p]),
+    "pvn3d_mt_pack_grad": (_i, [_ll, _i, _i, _p, _ll, _p, _p]),
+    "pvn3d_mt_unpack_out": (_i, [_ll, _i, _i, _p, _p, _ll, _p]),
+    "pvn3d_mt_bn_bwd_partials": (_i, [_ll]),
+    "pvn3d_mt_bn_bwd_reduce": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_bwd_finalize": (_i, [_i, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_bwd_apply": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -1,0 +1,738 @@
+// mlp_train.hip -- the training-mode grouped-point x MLP-weight contraction on bf16 MFMA (gfx950).
+//
+// Replaces, for the training step (BASELINE config 5), what the reference runs through cuDNN / ATen:
+//   SharedMLP = [Conv2d 1x1 (bias-free) -> BatchNorm2d (batch statistics) -> ReLU] x L
+//   (pvn3d/lib/utils/etw_pytorch_utils/pytorch_utils.py:25-50, 80-134) on the grouped tensor, then
+//   F.max_pool2d over nsample (pvn3d/lib/pointnet2_utils/pointnet2_modules.py:58-71), and the FP modules'
+//   interpolate -> concat -> SharedMLP (:188-206), forward AND backward.
+//
+// Layout: every activation is a POINT-MAJOR bf16 matrix [rows][ld] (row = one (cloud, centre, sample) column of
+// the reference's (B, C, npoint, nsample) tensor, ld = channels rounded up to 16, pad columns zero).  A 1x1
+// convolution is then a plain GEMM with K contiguous in both operands, a neighbour gather is one contiguous
+// row, and nothing is ever transposed to NCHW.  Per layer:
+//   forward : Y = H_prev . W^T            mt_gemm_nt (v_mfma_f32_32x32x16_bf16, fp32 accumulate), whose epilogue
+//             also emits per-channel partial sums of y and y^2 (BatchNorm statistics, deterministic two-stage)
+//             -> mt_bn_finalize (mean, 1/std, folded scale / shift, running statistics)
+//             -> mt_bn_relu_apply (H = relu(a y + b))  [-> mt_pool_max with arg-indices after the last layer]
+//   backward: dz = dH . [H > 0];  sums of dz and dz.yhat (mt_bn_bwd_reduce -> mt_bn_bwd_finalize: dgamma, dbeta)
+//             dY = a dz + k1 y + k0  (mt_bn_bwd_apply: the whole BatchNorm backward is affine in dz and y)
+//             dH_prev = dY . W       (mt_gemm_nt against the transposed weights)
+//             dW = dY^T . H_prev     (mt_gemm_nt on transposed copies, K = rows, split-K with fp32 atomics)
+// plus the gathers that build layer 0's input (SA: relative xyz ++ neighbour features; FP: three_interpolate ++
+// skip features); their backwards hand a channel-major fp32 copy (mt_unpack_cm) to the row-owner scatter kernels of
+// group_points.hip / interpolate.hip (global fp32 atomics measured 6x slower: 20 ms of a 50 ms step).
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ bf16_t f2bf(float f) {      // round to nearest even (inputs are finite)
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// C[M][N] = A[M][K] . B[N][K]^T, A / B bf16 with K contiguous (lda, ldb in elements, multiples of 8; K a multiple
+// of 16; rows of B beyond N and rows of A beyond M read as zero).  Workgroup tile 128 x NT, four waves of 32 rows
+// each, K in chunks of 32 through double-buffered LDS (row stride 40 elements = 80 B: sixteen consecutive rows
+// land in sixteen different 16-byte bank groups for the ds_read_b128 fragment loads).
+// EPI 0: C bf16 [M][ldc] (pad columns < ldc written as the zeros they accumulate) and, if stat_sum != nullptr,
+//        stat_sum / stat_sq [gridDim.x][stat_ld] = per-tile column sums of c and c^2 (fp32 accumulators).
+// EPI 1: C fp32 [M][ldc], atomicAdd (split-K: blockIdx.z owns K range [z*klen, (z+1)*klen)).
+constexpr int GEMM_LDS_STRIDE = 40;
+constexpr int GEMM_MAX_GX = 1024;      // row-tile workgroups (each loops over its tiles; bounds the partial statistics)
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, const bf16_t* __restrict__ A, int lda,
+                                                         const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv,
+                                                         int ldc, float* __restrict__ stat_sum,
+                                                         float* __restrict__ stat_sq, int stat_ld, int klen) {
+  constexpr int NB = NT / 32;                 // 32-column blocks per wave
+  constexpr int BL = (NT * 4 + 255) / 256;    // 16-byte B loads per thread and chunk
+  __shared__ __attribute__((aligned(16))) bf16_t sA[2][128 * GEMM_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_t sB[2][NT * GEMM_LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * NT;
+  const int kb = blockIdx.z * klen, ke = min(K, kb + klen);
+  const int nchunks = (ke - kb + 31) / 32;
+  const int mtiles = (M + 127) / 128;
+  float tsum[NB], tsq[NB];          // per-lane column statistics, accumulated over this workgroup's row tiles
+#pragma unroll
+  for (int i = 0; i < NB; ++i) { tsum[i] = 0.f; tsq[i] = 0.f; }
+
+  for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+  const int m0 = mt * 128;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  uint4 ra[2], rb[BL];
+  auto gload = [&](int c) {
+    const int k0 = kb + c * 32;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (tid >> 2) + p * 64, seg = tid & 3;
+      const int k = k0 + seg * 8;
+      ra[p] = (m0 + row < M && k < ke) ? *reinterpret_cast<const uint4*>(A + (size_t)(m0 + row) * lda + k)
+                                       : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BL; ++p) {
+      const int t = tid + p * 256;
+      const int row = t >> 2, seg = t & 3;
+      const int k = k0 + seg * 8;
+      rb[p] = (row < NT && n0 + row < N && k < ke) ? *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * ldb + k)
+                                                  : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (tid >> 2) + p * 64, seg = tid & 3;
+      *reinterpret_cast<uint4*>(&sA[buf][row * GEMM_LDS_STRIDE + seg * 8]) = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < BL; ++p) {
+      const int t = tid + p * 256;
+      const int row = t >> 2, seg = t & 3;
+      if (row < NT) *reinterpret_cast<uint4*>(&sB[buf][row * GEMM_LDS_STRIDE + seg * 8]) = rb[p];
+    }
+  };
+
+  if (nchunks > 0) {
+    gload(0);
+    __syncthreads();           // (the previous tile's fragment reads are done)
+    lstore(0);
+    __syncthreads();
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ko = ks * 16 + (lane >> 5) * 8;
+      const bf16x8 a = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const uint4*>(&sA[buf][(wave * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 b = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const uint4*>(&sB[buf][(nb * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int rbase = m0 + wave * 32 + 4 * (lane >> 5);
+  if (EPI == 0) {
+    bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 32 + (lane & 31);
+      if (col < ldc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < M) C[(size_t)row * ldc + col] = f2bf(acc[nb][r]);
+        }
+      }
+      if (stat_sum) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tsum[nb] += acc[nb][r]; tsq[nb] += acc[nb][r] * acc[nb][r]; }
+      }
+    }
+  } else {
+    float* C = reinterpret_cast<float*>(Cv);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = n0 + nb * 32 + (lane & 31);
+      if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < M) atomicAdd(&C[(size_t)row * ldc + col], acc[nb][r]);
+        }
+      }
+    }
+  }
+  }   // row tiles
+
+  if (EPI == 0 && stat_sum) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&sA[0][0]);     // [2][4][NT] floats <= 8 KiB
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float s = tsum[nb], q = tsq[nb];
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        red[(0 * 4 + wave) * NT + nb * 32 + lane] = s;
+        red[(1 * 4 + wave) * NT + nb * 32 + lane] = q;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < NT; t += 256) {
+      if (n0 + t < stat_ld) {
+        const float s = (red[0 * NT + t] + red[1 * NT + t]) + (red[2 * NT + t] + red[3 * NT + t]);
+        const float q = (red[4 * NT + t] + red[5 * NT + t]) + (red[6 * NT + t] + red[7 * NT + t]);
+        stat_sum[(size_t)blockIdx.x * stat_ld + n0 + t] = s;
+        stat_sq[(size_t)blockIdx.x * stat_ld + n0 + t] = q;
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc,
+                   float* ssum, float* ssq, int stat_ld, int ksplit, hipStream_t st) {
+  const int ncols = EPI == 0 ? ldc : N;             // EPI 0 also writes the (zero) pad columns
+  const int gx = min(pvn3d_ceil_div(M, 128), GEMM_MAX_GX);
+  int klen = K;
+  if (ksplit > 1) klen = pvn3d_ceil_div(pvn3d_ceil_div(K, ksplit), 32) * 32;
+  const int gz = pvn3d_ceil_div(K, klen);
+#define MT_GEMM(NT)                                                                                          \
+  hipLaunchKernelGGL((mt_gemm_nt_kernel<NT, EPI>), dim3(gx, pvn3d_ceil_div(ncols, NT), gz), dim3(256), 0, st, \
+                     M, N, K, A, lda, B, ldb, C, ldc, ssum, ssq, stat_ld, klen)
+  if (ncols <= 32) MT_GEMM(32);
+  else if (ncols <= 64) MT_GEMM(64);
+  else if (ncols <= 128 || (ncols > 256 && ncols <= 384)) MT_GEMM(128);
+  else MT_GEMM(256);
+#undef MT_GEMM
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ layout helpers
+// X [rows][ld] bf16 -> XT [ld][ldt] (ldt >= rows): 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void mt_transpose_kernel(int rows, int ld, const bf16_t* __restrict__ X,
+                                                           bf16_t* __restrict__ XT, int ldt) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int r = t >> 6, c = t & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < ld) ? X[(size_t)(r0 + r) * ld + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int c = t >> 6, r = t & 63;
+    if (c0 + c < ld && r0 + r < ldt) XT[(size_t)(c0 + c) * ldt + r0 + r] = tile[r][c];
+  }
+}
+
+// fp32 [rows][cols] (row stride lds) -> bf16 [rows][ld] zero-padded; transpose != 0: out[c][r] = in[r][c]
+__global__ void mt_pack_weight_kernel(int rows, int cols, const float* __restrict__ W, int lds, int transpose,
+                                      bf16_t* __restrict__ out, int out_rows, int ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_rows * ld) return;
+  const int r = i / ld, c = i % ld;
+  float v = 0.f;
+  if (!transpose) { if (r < rows && c < cols) v = W[(size_t)r * lds + c]; }
+  else { if (c < rows && r < cols) v = W[(size_t)c * lds + r]; }
+  out[i] = f2bf(v);
+}
+
+// ------------------------------------------------------------------------------------------------ gathers
+// SA level input: X0[(b*m + j)*ns + s][c] = (c < 3: xyz[b, idx] - new_xyz[b, j]) | (c < 3 + C: feat[b, c - 3, idx])
+// | 0.  feat element (b, c, n) at feat[b*fsb + c*fsc + n*fsn] (fp32: channel-major tensors and transposed views of
+// point-major ones alike).  One thread = 8 consecutive channels of one row.
+__global__ void mt_gather_sa_kernel(int b, int n, int m, int ns, int C, int use_xyz, const float* __restrict__ xyz,
+                                    const float* __restrict__ new_xyz, const float* __restrict__ feat, long long fsb,
+                                    long long fsc, long long fsn, const int* __restrict__ idx,
+                                    bf16_t* __restrict__ X0, int ld) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long rows = (long long)b * m * ns;
+  if (t >= rows * cpr) return;
+  const long long row = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  const int bi = (int)(row / ((long long)m * ns));
+  const int j = (int)((row / ns) % m);
+  const int k = idx[row];
+  const int nx = use_xyz ? 3 : 0;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    float x = 0.f;
+    if (c < nx) x = xyz[((size_t)bi * n + k) * 3 + c] - new_xyz[((size_t)bi * m + j) * 3 + c];
+    else if (c < nx + C) x = feat[bi * fsb + (c - nx) * fsc + k * fsn];
+    v[i] = x;
+  }
+  *reinterpret_cast<uint4*>(X0 + row * ld + c0) = pack8(v);
+}
+
+// dX0 [B*R][ld] bf16 -> out[b][c][r] fp32 for the channels [c_off, c_off + C): the layout the row-owner scatter
+// kernels (group_points.hip, interpolate.hip: group_points_grad / three_interpolate_grad) stream.  64 x 64 tiles.
+__global__ __launch_bounds__(256) void mt_unpack_cm_kernel(int R, int ld, int c_off, int C, const bf16_t* __restrict__ X,
+                                                           float* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  X += (size_t)b * R * ld;
+  out += (size_t)b * C * R;
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int r = t >> 6, c = t & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? bf2f(X[(size_t)(r0 + r) * ld + c_off + c0 + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int c = t >> 6, r = t & 63;
+    if (c0 + c < C && r0 + r < R) out[(size_t)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+// FP level input: X0[b*n + i][c] = (c < C2: sum_t w[b,i,t] * known[b, c, idx[b,i,t]]) | (c < C2 + C1:
+// unknown[b, c - C2, i]) | 0   (pointnet2_modules.py:188-203: cat([interpolated, unknow_feats], dim=1))
+__global__ void mt_gather_fp_kernel(int b, int n, int mk, int C2, int C1, const float* __restrict__ known,
+                                    long long ksb, long long ksc, long long ksn, const float* __restrict__ unknown,
+                                    long long usb, long long usc, long long usn, const int* __restrict__ idx,
+                                    const float* __restrict__ w, bf16_t* __restrict__ X0, int ld) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long rows = (long long)b * n;
+  if (t >= rows * cpr) return;
+  const long long row = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  const int bi = (int)(row / n), i0 = (int)(row % n);
+  const int k0 = idx[row * 3], k1 = idx[row * 3 + 1], k2 = idx[row * 3 + 2];
+  const float w0 = w[row * 3], w1 = w[row * 3 + 1], w2 = w[row * 3 + 2];
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    float x = 0.f;
+    if (c < C2) {
+      const float* p = known + bi * ksb + c * ksc;
+      x = p[k0 * ksn] * w0 + p[k1 * ksn] * w1 + p[k2 * ksn] * w2;
+    } else if (c < C2 + C1) {
+      x = unknown[bi * usb + (c - C2) * usc + i0 * usn];
+    }
+    v[i] = x;
+  }
+  *reinterpret_cast<uint4*>(X0 + row * ld + c0) = pack8(v);
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// partial [P][ld] x 2 -> per-channel mean, 1/std, folded scale a = gamma/std and shift b = beta - mean*a (zero in
+// the pad channels), running statistics (momentum update, unbiased variance) like nn.BatchNorm2d in training mode.
+// grid ceil(ld/32), block (32 channels x 8 partial lanes)
+__global__ __launch_bounds__(256) void mt_bn_finalize_kernel(int P, int ld, int C, double count,
+                                                             const float* __restrict__ psum,
+                                                             const float* __restrict__ psq,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float momentum,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             float* __restrict__ a_out, float* __restrict__ b_out) {
+  __shared__ double ss[8][32], sq[8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < ld)
+    for (int p = pl; p < P; p += 8) { s += psum[(size_t)p * ld + c]; q += psq[(size_t)p * ld + c]; }
+  ss[pl][cl] = s;
+  sq[pl][cl] = q;
+  __syncthreads();
+  if (pl == 0 && c < ld) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
+    if (c < C) {
+      const double mean = s / count;
+      double var = q / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float a = gamma[c] * invstd;
+      mean_out[c] = (float)mean;
+      invstd_out[c] = invstd;
+      a_out[c] = a;
+      b_out[c] = beta[c] - (float)mean * a;
+      if (run_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+      }
+    } else {
+      mean_out[c] = 0.f; invstd_out[c] = 0.f; a_out[c] = 0.f; b_out[c] = 0.f;
+    }
+  }
+}
+
+// H = relu(a y + b), 8 channels per thread
+__global__ void mt_bn_relu_apply_kernel(long long rows, int ld, const bf16_t* __restrict__ Y,
+                                        const float* __restrict__ a, const float* __restrict__ b,
+                                        bf16_t* __restrict__ H) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cpr) return;
+  const int c0 = (int)(t % cpr) * 8;
+  float y[8];
+  unpack8(*reinterpret_cast<const uint4*>(Y + t * 8), y);
+  const float4 a0 = *reinterpret_cast<const float4*>(a + c0), a1 = *reinterpret_cast<const float4*>(a + c0 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
+  const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = fmaxf(fmaf(av[i], y[i], bv[i]), 0.f);
+  *reinterpret_cast<uint4*>(H + t * 8) = pack8(y);
+}
+
+// max over the ns rows of every group: H [G*ns][ld] -> out[g*out_ld + c] (fp32, c < C), arg [G][ld] (uint8)
+__global__ void mt_pool_max_kernel(long long G, int ns, int ld, int C, const bf16_t* __restrict__ H,
+                                   float* __restrict__ out, long long out_ld, unsigned char* __restrict__ arg) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * cpr) return;
+  const long long g = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { best[i] = -__builtin_inff(); bi[i] = 0; }
+  for (int s = 0; s < ns; ++s) {
+    float h[8];
+    unpack8(*reinterpret_cast<const uint4*>(H + (g * ns + s) * ld + c0), h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (h[i] > best[i]) { best[i] = h[i]; bi[i] = s; }       // first maximum wins (as ATen's max_pool2d)
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (c0 + i < C) out[g * out_ld + c0 + i] = best[i];
+    arg[g * ld + c0 + i] = (unsigned char)bi[i];
+  }
+}
+
+// dH [G*ns][ld] = (s == arg ? dpool : 0)
+__global__ void mt_pool_bwd_kernel(long long G, int ns, int ld, int C, const float* __restrict__ dout, long long out_ld,
+                                   const unsigned char* __restrict__ arg, bf16_t* __restrict__ dH) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * ns * cpr) return;
+  const long long row = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  const long long g = row / ns;
+  const int s = (int)(row % ns);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    v[i] = (c0 + i < C && arg[g * ld + c0 + i] == s) ? dout[g * out_ld + c0 + i] : 0.f;
+  *reinterpret_cast<uint4*>(dH + t * 8) = pack8(v);
+}
+
+// fp32 gradient of a point-major output (rows, C) with row stride gld -> bf16 [rows][ld] zero-padded
+__global__ void mt_pack_grad_kernel(long long rows, int ld, int C, const float* __restrict__ g, long long gld,
+                                    bf16_t* __restrict__ dH) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cpr) return;
+  const long long row = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = c0 + i < C ? g[row * gld + c0 + i] : 0.f;
+  *reinterpret_cast<uint4*>(dH + t * 8) = pack8(v);
+}
+
+// H [rows][ld] bf16 -> out[row*out_ld + c] fp32 (c < C)
+__global__ void mt_unpack_out_kernel(long long rows, int ld, int C, const bf16_t* __restrict__ H, float* __restrict__ out,
+                                     long long out_ld) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cpr) return;
+  const long long row = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  float h[8];
+  unpack8(*reinterpret_cast<const uint4*>(H + t * 8), h);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (c0 + i < C) out[row * out_ld + c0 + i] = h[i];
+}
+
+// partial sums of dz = dH.[H > 0] and dz.yhat (yhat = (y - mean)/std).  Block = 256 threads = (ld/8 channel chunks)
+// x (row lanes); each block covers `rows_per_block` rows and writes one partial row.
+__global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, int ld, int rows_per_block,
+                                                               const bf16_t* __restrict__ dH,
+                                                               const bf16_t* __restrict__ H,
+                                                               const bf16_t* __restrict__ Y,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               float* __restrict__ p1, float* __restrict__ p2) {
+  extern __shared__ float s_red[];          // [2][rl][ld]
+  const int cpr = ld >> 3;
+  const int rl = 256 / cpr;                 // row lanes (>= 3 for ld <= 528)
+  const int chunk = threadIdx.x % cpr, rlane = threadIdx.x / cpr;
+  const int c0 = chunk * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (rlane < rl) {
+    float mu[8], is[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    for (long long r = r0 + rlane; r < r1; r += rl) {
+      float g[8], h[8], y[8];
+      unpack8(*reinterpret_cast<const uint4*>(dH + r * ld + c0), g);
+      unpack8(*reinterpret_cast<const uint4*>(H + r * ld + c0), h);
+      unpack8(*reinterpret_cast<const uint4*>(Y + r * ld + c0), y);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dz = h[i] > 0.f ? g[i] : 0.f;
+        s1[i] += dz;
+        s2[i] += dz * ((y[i] - mu[i]) * is[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s_red[(0 * rl + rlane) * ld + c0 + i] = s1[i];
+      s_red[(1 * rl + rlane) * ld + c0 + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rl; ++r) { a += s_red[(0 * rl + r) * ld + c]; b += s_red[(1 * rl + r) * ld + c]; }
+    p1[(size_t)blockIdx.x * ld + c] = a;
+    p2[(size_t)blockIdx.x * ld + c] = b;
+  }
+}
+
+// -> dgamma = sum dz.yhat, dbeta = sum dz, and the affine form of the BatchNorm backward
+//    dY = a.(dz - mean(dz) - yhat.mean(dz.yhat)) = a.dz + k1.y + k0
+__global__ __launch_bounds__(256) void mt_bn_bwd_finalize_kernel(int P, int ld, int C, double count,
+                                                                 const float* __restrict__ p1,
+                                                                 const float* __restrict__ p2,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ a,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ k1, float* __restrict__ k0) {
+  __shared__ double ss[8][32], sq[8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < ld)
+    for (int p = pl; p < P; p += 8) { s += p1[(size_t)p * ld + c]; q += p2[(size_t)p * ld + c]; }
+  ss[pl][cl] = s;
+  sq[pl][cl] = q;
+  __syncthreads();
+  if (pl == 0 && c < ld) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
+    if (c < C) {
+      dbeta[c] = (float)s;
+      dgamma[c] = (float)q;
+      const double c1 = s / count, c2 = q / count;
+      const double kk1 = -(double)a[c] * c2 * (double)invstd[c];
+      k1[c] = (float)kk1;
+      k0[c] = (float)(-(double)a[c] * c1 - kk1 * (double)mean[c]);
+    } else {
+      k1[c] = 0.f; k0[c] = 0.f;
+    }
+  }
+}
+
+// dY = a.dz + k1.y + k0 with dz = dH.[H > 0]
+__global__ void mt_bn_bwd_apply_kernel(long long rows, int ld, const bf16_t* __restrict__ dH,
+                                       const bf16_t* __restrict__ H, const bf16_t* __restrict__ Y,
+                                       const float* __restrict__ a, const float* __restrict__ k1,
+                                       const float* __restrict__ k0, bf16_t* __restrict__ dY) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cpr) return;
+  const int c0 = (int)(t % cpr) * 8;
+  float g[8], h[8], y[8], o[8];
+  unpack8(*reinterpret_cast<const uint4*>(dH + t * 8), g);
+  unpack8(*reinterpret_cast<const uint4*>(H + t * 8), h);
+  unpack8(*reinterpret_cast<const uint4*>(Y + t * 8), y);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float dz = h[i] > 0.f ? g[i] : 0.f;
+    o[i] = fmaf(a[c0 + i], dz, fmaf(k1[c0 + i], y[i], k0[c0 + i]));
+  }
+  *reinterpret_cast<uint4*>(dY + t * 8) = pack8(o);
+}
+
+inline unsigned grid1(long long work, int block) { return (unsigned)((work + block - 1) / block); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+#define MT_ST ((hipStream_t)stream)
+
+extern "C" int pvn3d_mt_gemm_nt(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                float* stat_sum, float* stat_sq, int stat_ld, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0 || (K & 15) || (lda & 7) || (ldb & 7) || !A || !B || !C) return (int)hipErrorInvalidValue;
+  return launch_gemm_nt<0>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, stat_sum, stat_sq, stat_ld, 1,
+                           MT_ST);
+}
+
+extern "C" int pvn3d_mt_gemm_nt_stat_rows(int M) { return min(pvn3d_ceil_div(M, 128), GEMM_MAX_GX); }
+
+// C fp32 [M][ldc] += A . B^T over K split `ksplit` ways (atomics); C must hold the values to add to (zeros)
+extern "C" int pvn3d_mt_gemm_nt_splitk(int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                                       int ldc, int ksplit, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0 || (K & 15) || (lda & 7) || (ldb & 7) || !A || !B || !C || ksplit < 1) return (int)hipErrorInvalidValue;
+  return launch_gemm_nt<1>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, nullptr, nullptr, 0, ksplit,
+                           MT_ST);
+}
+
+extern "C" int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream) {
+  if (rows <= 0 || ld <= 0) return 0;
+  if (rows > 0x7fffffffLL || ldt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_transpose_kernel, dim3(pvn3d_ceil_div((int)rows, 64), pvn3d_ceil_div(ld, 64)), dim3(256), 0,
+                     MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_pack_weight(int rows, int cols, const float* W, int lds, int transpose, void* out, int out_rows,
+                                    int ld, void* stream) {
+  if (out_rows <= 0 || ld <= 0) return 0;
+  hipLaunchKernelGGL(mt_pack_weight_kernel, dim3(grid1((long long)out_rows * ld, 256)), dim3(256), 0, MT_ST, rows, cols,
+                     W, lds, transpose, (bf16_t*)out, out_rows, ld);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_gather_sa(int b, int n, int m, int ns, int C, int use_xyz, const float* xyz,
+                                  const float* new_xyz, const float* feat, long long fsb, long long fsc, long long fsn,
+                                  const int* idx, void* X0, int ld, void* stream) {
+  const long long rows = (long long)b * m * ns;
+  if (rows <= 0) return 0;
+  if ((ld & 15) || ld < (use_xyz ? 3 : 0) + C) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_gather_sa_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, b, n, m, ns, C,
+                     use_xyz, xyz, new_xyz, feat, fsb, fsc, fsn, idx, (bf16_t*)X0, ld);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_unpack_cm(int b, int R, int ld, int c_off, int C, const void* X, float* out, void* stream) {
+  if (b <= 0 || R <= 0 || C <= 0) return 0;
+  if (c_off < 0 || c_off + C > ld) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_unpack_cm_kernel, dim3(pvn3d_ceil_div(R, 64), pvn3d_ceil_div(C, 64), b), dim3(256), 0, MT_ST, R,
+                     ld, c_off, C, (const bf16_t*)X, out);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_gather_fp(int b, int n, int mk, int C2, int C1, const float* known, long long ksb, long long ksc,
+                                  long long ksn, const float* unknown, long long usb, long long usc, long long usn,
+                                  const int* idx, const float* w, void* X0, int ld, void* stream) {
+  const long long rows = (long long)b * n;
+  if (rows <= 0) return 0;
+  if ((ld & 15) || ld < C2 + C1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_gather_fp_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, b, n, mk, C2, C1,
+                     known, ksb, ksc, ksn, unknown, usb, usc, usn, idx, w, (bf16_t*)X0, ld);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_finalize(int P, int ld, int C, double count, const float* psum, const float* psq,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                                    float* run_var, float* mean, float* invstd, float* a, float* b, void* stream) {
+  if (ld <= 0) return 0;
+  hipLaunchKernelGGL(mt_bn_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(256), 0, MT_ST, P, ld, C, count, psum,
+                     psq, gamma, beta, eps, momentum, run_mean, run_var, mean, invstd, a, b);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_relu_apply(long long rows, int ld, const void* Y, const float* a, const float* b, void* H,
+                                      void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(mt_bn_relu_apply_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld,
+                     (const bf16_t*)Y, a, b, (bf16_t*)H);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_pool_max(long long G, int ns, int ld, int C, const void* H, float* out, long long out_ld,
+                                 unsigned char* arg, void* stream) {
+  if (G <= 0) return 0;
+  if (ns < 1 || ns > 255) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_pool_max_kernel, dim3(grid1(G * (ld >> 3), 256)), dim3(256), 0, MT_ST, G, ns, ld, C,
+                     (const bf16_t*)H, out, out_ld, arg);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_pool_bwd(long long G, int ns, int ld, int C, const float* dout, long long out_ld,
+                                 const unsigned char* arg, void* dH, void* stream) {
+  if (G <= 0) return 0;
+  hipLaunchKernelGGL(mt_pool_bwd_kernel, dim3(grid1(G * ns * (ld >> 3), 256)), dim3(256), 0, MT_ST, G, ns, ld, C, dout,
+                     out_ld, arg, (bf16_t*)dH);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_pack_grad(long long rows, int ld, int C, const float* g, long long gld, void* dH, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(mt_pack_grad_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld, C, g, gld,
+                     (bf16_t*)dH);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_unpack_out(long long rows, int ld, int C, const void* H, float* out, long long out_ld,
+                                   void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(mt_unpack_out_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld, C,
+                     (const bf16_t*)H, out, out_ld);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_bwd_partials(long long rows) { return (int)((rows + 2047) / 2048); }
+
+extern "C" int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* H, const void* Y,
+                                      const float* mean, const float* invstd, float* p1, float* p2, void* stream) {
+  if (rows <= 0) return 0;
+  if (ld > 2048 || (ld & 7)) return (int)hipErrorInvalidValue;
+  const int rl = 256 / (ld >> 3);
+  hipLaunchKernelGGL(mt_bn_bwd_reduce_kernel, dim3(pvn3d_mt_bn_bwd_partials(rows)), dim3(256),
+                     (size_t)2 * rl * ld * sizeof(float), MT_ST, rows, ld, 2048, (const bf16_t*)dH, (const bf16_t*)H,
+                     (const bf16_t*)Y, mean, invstd, p1, p2);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_bwd_finalize(int P, int ld, int C, double count, const float* p1, const float* p2,
+                                        const float* mean, const float* invstd, const float* a, float* dgamma,
+                                        float* dbeta, float* k1, float* k0, void* stream) {
+  if (ld <= 0) return 0;
+  hipLaunchKernelGGL(mt_bn_bwd_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(256), 0, MT_ST, P, ld, C, count, p1,
+                     p2, mean, invstd, a, dgamma, dbeta, k1, k0);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* H, const void* Y,
+                                     const float* a, const float* k1, const float* k0, void* dY, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(mt_bn_bwd_apply_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld,
+                     (const bf16_t*)dH, (const bf16_t*)H, (const bf16_t*)Y, a, k1, k0, (bf16_t*)dY);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

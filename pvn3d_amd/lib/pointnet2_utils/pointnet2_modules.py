@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import _ext
 from . import _fused_mlp
+from . import _train_mlp
 from . import pointnet2_utils
 from ..utils import pytorch_utils as pt_utils
 
@@ -131,6 +132,16 @@ class _PointnetSAModuleBase(nn.Module):
             out = self._forward_fused(xyz, new_xyz, features, idxs)
             if out is not None:
                 return new_xyz, out
+        if (_train_mlp.TRAIN_FUSED and self.training and self.npoint is not None and xyz.is_cuda
+                and torch.is_grad_enabled() and (features is None or features.dtype == torch.float32)):
+            # training: gather -> bf16 MFMA GEMM + BatchNorm(batch statistics) + ReLU chain -> max-pool, forward and
+            # backward on the kernels of csrc/mlp_train.hip
+            tidx = [idx if idx is not None else pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz)
+                    for g, idx in zip(self.groupers, idxs)] \
+                if all(isinstance(g, pointnet2_utils.QueryAndGroup) for g in self.groupers) else None
+            out = _train_mlp.sa_level_train(self, xyz, new_xyz, features, tidx) if tidx is not None else None
+            if out is not None:
+                return new_xyz, out
         if features is not None and not features.is_contiguous():
             features = features.contiguous()       # a point-major view from a fused producer
         for grouper, mlp, idx in zip(self.groupers, self.mlps, idxs):
@@ -237,6 +248,12 @@ class PointnetFPModule(nn.Module):
                     with _stage("fp_mlp"):
                         return _ext.fp_interp_mlp(known_feats, unknow_feats, idx, weight.contiguous(), packed,
                                                   point_major_out=getattr(self, "_point_major_out", False))
+            if (_train_mlp.TRAIN_FUSED and self.training and known_feats.is_cuda and torch.is_grad_enabled()
+                    and known_feats.dtype == torch.float32
+                    and (unknow_feats is None or unknow_feats.dtype == torch.float32)):
+                out = _train_mlp.fp_train(self, unknow_feats, known_feats, idx, weight)
+                if out is not None:
+                    return out
             interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))

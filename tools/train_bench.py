@@ -17,7 +17,12 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--library-mlp", action="store_true",
+                    help="SharedMLP through torch Conv2d / BatchNorm2d (MIOpen / hipBLASLt) instead of csrc/mlp_train.hip")
     args = ap.parse_args()
+    if args.library_mlp:
+        from pvn3d_amd.lib.pointnet2_utils import _train_mlp
+        _train_mlp.TRAIN_FUSED = False
     dev = torch.device("cuda:0")
     batch = ts.synthetic_batch(args.frames, 12288, dev, seed_base=7500, n_obj=3072)
     torch.manual_seed(1)
