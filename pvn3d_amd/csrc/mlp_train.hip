@@ -222,19 +222,32 @@ int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* 
 }
 
 // ------------------------------------------------------------------------------------------------ layout helpers
-// X [rows][ld] bf16 -> XT [ld][ldt] (ldt >= rows): 64 x 64 tiles through LDS
+// X [rows][ld] bf16 -> XT [ld][ldt] (ldt >= rows, both multiples of 8): (4096 / TC) x TC tiles through LDS, TC = 16 /
+// 32 / 64 columns so that narrow matrices (ld = 16: the first SA level) still fill the tile.  16-byte global loads
+// (8 channels of a row) and stores (8 rows of a channel).
+template <int TC>
 __global__ __launch_bounds__(256) void mt_transpose_kernel(int rows, int ld, const bf16_t* __restrict__ X,
                                                            bf16_t* __restrict__ XT, int ldt) {
-  __shared__ bf16_t tile[64][66];
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
-    const int r = t >> 6, c = t & 63;
-    tile[r][c] = (r0 + r < rows && c0 + c < ld) ? X[(size_t)(r0 + r) * ld + c0 + c] : (bf16_t)0;
+  constexpr int TR = 4096 / TC;
+  constexpr int LS = TR + 8;                 // LDS row stride: 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) bf16_t tile[TC * LS];
+  const int r0 = blockIdx.x * TR, c0 = blockIdx.y * TC;
+  for (int t = threadIdx.x; t < TR * TC / 8; t += 256) {
+    const int r = t / (TC / 8), c = (t % (TC / 8)) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + c < ld) v = *reinterpret_cast<const uint4*>(X + (size_t)(r0 + r) * ld + c0 + c);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[(c + 2 * i) * LS + r] = (bf16_t)(w[i] & 0xffffu);
+      tile[(c + 2 * i + 1) * LS + r] = (bf16_t)(w[i] >> 16);
+    }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
-    const int c = t >> 6, r = t & 63;
-    if (c0 + c < ld && r0 + r < ldt) XT[(size_t)(c0 + c) * ldt + r0 + r] = tile[r][c];
+  for (int t = threadIdx.x; t < TR * TC / 8; t += 256) {
+    const int c = t / (TR / 8), r = (t % (TR / 8)) * 8;
+    if (c0 + c < ld && r0 + r < ldt)
+      *reinterpret_cast<uint4*>(XT + (size_t)(c0 + c) * ldt + r0 + r) = *reinterpret_cast<const uint4*>(&tile[c * LS + r]);
   }
 }
 
@@ -299,6 +312,25 @@ __global__ __launch_bounds__(256) void mt_unpack_cm_kernel(int R, int ld, int c_
   }
 }
 
+// in[b][c][r] fp32 (channel-major, C channels) -> X [B*R][ld] bf16, zero in the pad columns: the gradient of a
+// module that returned the reference's contiguous (B, C, n) layout
+__global__ __launch_bounds__(256) void mt_pack_cm_kernel(int R, int ld, int C, const float* __restrict__ in,
+                                                         bf16_t* __restrict__ X) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  in += (size_t)b * C * R;
+  X += (size_t)b * R * ld;
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int c = t >> 6, r = t & 63;
+    tile[c][r] = (c0 + c < C && r0 + r < R) ? in[(size_t)(c0 + c) * R + r0 + r] : 0.f;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 64 * 64; t += 256) {
+    const int r = t >> 6, c = t & 63;
+    if (r0 + r < R && c0 + c < ld) X[(size_t)(r0 + r) * ld + c0 + c] = f2bf(tile[c][r]);
+  }
+}
+
 // FP level input: X0[b*n + i][c] = (c < C2: sum_t w[b,i,t] * known[b, c, idx[b,i,t]]) | (c < C2 + C1:
 // unknown[b, c - C2, i]) | 0   (pointnet2_modules.py:188-203: cat([interpolated, unknow_feats], dim=1))
 __global__ void mt_gather_fp_kernel(int b, int n, int mk, int C2, int C1, const float* __restrict__ known,
@@ -333,8 +365,8 @@ __global__ void mt_gather_fp_kernel(int b, int n, int mk, int C2, int C1, const 
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // partial [P][ld] x 2 -> per-channel mean, 1/std, folded scale a = gamma/std and shift b = beta - mean*a (zero in
 // the pad channels), running statistics (momentum update, unbiased variance) like nn.BatchNorm2d in training mode.
-// grid ceil(ld/32), block (32 channels x 8 partial lanes)
-__global__ __launch_bounds__(256) void mt_bn_finalize_kernel(int P, int ld, int C, double count,
+// grid ceil(ld/32), block (32 channels x 32 partial lanes)
+__global__ __launch_bounds__(1024) void mt_bn_finalize_kernel(int P, int ld, int C, double count,
                                                              const float* __restrict__ psum,
                                                              const float* __restrict__ psq,
                                                              const float* __restrict__ gamma,
@@ -342,18 +374,18 @@ __global__ __launch_bounds__(256) void mt_bn_finalize_kernel(int P, int ld, int 
                                                              float* __restrict__ run_mean, float* __restrict__ run_var,
                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                              float* __restrict__ a_out, float* __restrict__ b_out) {
-  __shared__ double ss[8][32], sq[8][32];
+  __shared__ double ss[32][32], sq[32][32];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < ld)
-    for (int p = pl; p < P; p += 8) { s += psum[(size_t)p * ld + c]; q += psq[(size_t)p * ld + c]; }
+    for (int p = pl; p < P; p += 32) { s += psum[(size_t)p * ld + c]; q += psq[(size_t)p * ld + c]; }
   ss[pl][cl] = s;
   sq[pl][cl] = q;
   __syncthreads();
   if (pl == 0 && c < ld) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
+    for (int i = 1; i < 32; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
     if (c < C) {
       const double mean = s / count;
       double var = q / count - mean * mean;
@@ -489,7 +521,33 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
     for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    for (long long r = r0 + rlane; r < r1; r += rl) {
+    // four rows in flight per thread (twelve 16-byte loads): one row at a time is latency-bound at a third of the
+    // HBM rate
+    long long r = r0 + rlane;
+    for (; r + 3LL * rl < r1; r += 4LL * rl) {
+      uint4 vg[4], vh[4], vy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long o = (r + (long long)u * rl) * ld + c0;
+        vg[u] = *reinterpret_cast<const uint4*>(dH + o);
+        vh[u] = *reinterpret_cast<const uint4*>(H + o);
+        vy[u] = *reinterpret_cast<const uint4*>(Y + o);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float g[8], h[8], y[8];
+        unpack8(vg[u], g);
+        unpack8(vh[u], h);
+        unpack8(vy[u], y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dz = h[i] > 0.f ? g[i] : 0.f;
+          s1[i] += dz;
+          s2[i] += dz * ((y[i] - mu[i]) * is[i]);
+        }
+      }
+    }
+    for (; r < r1; r += rl) {
       float g[8], h[8], y[8];
       unpack8(*reinterpret_cast<const uint4*>(dH + r * ld + c0), g);
       unpack8(*reinterpret_cast<const uint4*>(H + r * ld + c0), h);
@@ -518,7 +576,7 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
 
 // -> dgamma = sum dz.yhat, dbeta = sum dz, and the affine form of the BatchNorm backward
 //    dY = a.(dz - mean(dz) - yhat.mean(dz.yhat)) = a.dz + k1.y + k0
-__global__ __launch_bounds__(256) void mt_bn_bwd_finalize_kernel(int P, int ld, int C, double count,
+__global__ __launch_bounds__(1024) void mt_bn_bwd_finalize_kernel(int P, int ld, int C, double count,
                                                                  const float* __restrict__ p1,
                                                                  const float* __restrict__ p2,
                                                                  const float* __restrict__ mean,
@@ -526,18 +584,18 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_finalize_kernel(int P, int ld, 
                                                                  const float* __restrict__ a,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  float* __restrict__ k1, float* __restrict__ k0) {
-  __shared__ double ss[8][32], sq[8][32];
+  __shared__ double ss[32][32], sq[32][32];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < ld)
-    for (int p = pl; p < P; p += 8) { s += p1[(size_t)p * ld + c]; q += p2[(size_t)p * ld + c]; }
+    for (int p = pl; p < P; p += 32) { s += p1[(size_t)p * ld + c]; q += p2[(size_t)p * ld + c]; }
   ss[pl][cl] = s;
   sq[pl][cl] = q;
   __syncthreads();
   if (pl == 0 && c < ld) {
 #pragma unroll
-    for (int i = 1; i < 8; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
+    for (int i = 1; i < 32; ++i) { s += ss[i][cl]; q += sq[i][cl]; }
     if (c < C) {
       dbeta[c] = (float)s;
       dgamma[c] = (float)q;
@@ -601,8 +659,15 @@ extern "C" int pvn3d_mt_gemm_nt_splitk(int M, int N, int K, const void* A, int l
 extern "C" int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream) {
   if (rows <= 0 || ld <= 0) return 0;
   if (rows > 0x7fffffffLL || ldt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(mt_transpose_kernel, dim3(pvn3d_ceil_div((int)rows, 64), pvn3d_ceil_div(ld, 64)), dim3(256), 0,
-                     MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);
+  if (ld <= 16)
+    hipLaunchKernelGGL(mt_transpose_kernel<16>, dim3(pvn3d_ceil_div((int)rows, 256), pvn3d_ceil_div(ld, 16)), dim3(256), 0,
+                       MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);
+  else if (ld <= 32)
+    hipLaunchKernelGGL(mt_transpose_kernel<32>, dim3(pvn3d_ceil_div((int)rows, 128), pvn3d_ceil_div(ld, 32)), dim3(256), 0,
+                       MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);
+  else
+    hipLaunchKernelGGL(mt_transpose_kernel<64>, dim3(pvn3d_ceil_div((int)rows, 64), pvn3d_ceil_div(ld, 64)), dim3(256), 0,
+                       MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
@@ -637,6 +702,15 @@ extern "C" int pvn3d_mt_unpack_cm(int b, int R, int ld, int c_off, int C, const 
   return 0;
 }
 
+extern "C" int pvn3d_mt_pack_cm(int b, int R, int ld, int C, const float* in, void* X, void* stream) {
+  if (b <= 0 || R <= 0 || ld <= 0) return 0;
+  if (C > ld) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_pack_cm_kernel, dim3(pvn3d_ceil_div(R, 64), pvn3d_ceil_div(ld, 64), b), dim3(256), 0, MT_ST, R, ld,
+                     C, in, (bf16_t*)X);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pvn3d_mt_gather_fp(int b, int n, int mk, int C2, int C1, const float* known, long long ksb, long long ksc,
                                   long long ksn, const float* unknown, long long usb, long long usc, long long usn,
                                   const int* idx, const float* w, void* X0, int ld, void* stream) {
@@ -653,7 +727,7 @@ extern "C" int pvn3d_mt_bn_finalize(int P, int ld, int C, double count, const fl
                                     const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
                                     float* run_var, float* mean, float* invstd, float* a, float* b, void* stream) {
   if (ld <= 0) return 0;
-  hipLaunchKernelGGL(mt_bn_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(256), 0, MT_ST, P, ld, C, count, psum,
+  hipLaunchKernelGGL(mt_bn_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(1024), 0, MT_ST, P, ld, C, count, psum,
                      psq, gamma, beta, eps, momentum, run_mean, run_var, mean, invstd, a, b);
   PVN3D_LAUNCH_CHECK();
   return 0;
@@ -704,7 +778,16 @@ extern "C" int pvn3d_mt_unpack_out(long long rows, int ld, int C, const void* H,
   return 0;
 }
 
-extern "C" int pvn3d_mt_bn_bwd_partials(long long rows) { return (int)((rows + 2047) / 2048); }
+// rows per workgroup of the reduction: about 1024 workgroups, at least 64 rows each
+static int mt_bwd_rows_per_block(long long rows) {
+  long long rpb = (rows + 1023) / 1024;
+  rpb = (rpb + 63) / 64 * 64;
+  return (int)(rpb < 64 ? 64 : rpb);
+}
+extern "C" int pvn3d_mt_bn_bwd_partials(long long rows) {
+  const int rpb = mt_bwd_rows_per_block(rows);
+  return (int)((rows + rpb - 1) / rpb);
+}
 
 extern "C" int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* H, const void* Y,
                                       const float* mean, const float* invstd, float* p1, float* p2, void* stream) {
@@ -712,7 +795,7 @@ extern "C" int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, co
   if (ld > 2048 || (ld & 7)) return (int)hipErrorInvalidValue;
   const int rl = 256 / (ld >> 3);
   hipLaunchKernelGGL(mt_bn_bwd_reduce_kernel, dim3(pvn3d_mt_bn_bwd_partials(rows)), dim3(256),
-                     (size_t)2 * rl * ld * sizeof(float), MT_ST, rows, ld, 2048, (const bf16_t*)dH, (const bf16_t*)H,
+                     (size_t)2 * rl * ld * sizeof(float), MT_ST, rows, ld, mt_bwd_rows_per_block(rows), (const bf16_t*)dH, (const bf16_t*)H,
                      (const bf16_t*)Y, mean, invstd, p1, p2);
   PVN3D_LAUNCH_CHECK();
   return 0;
@@ -722,7 +805,7 @@ extern "C" int pvn3d_mt_bn_bwd_finalize(int P, int ld, int C, double count, cons
                                         const float* mean, const float* invstd, const float* a, float* dgamma,
                                         float* dbeta, float* k1, float* k0, void* stream) {
   if (ld <= 0) return 0;
-  hipLaunchKernelGGL(mt_bn_bwd_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(256), 0, MT_ST, P, ld, C, count, p1,
+  hipLaunchKernelGGL(mt_bn_bwd_finalize_kernel, dim3(pvn3d_ceil_div(ld, 32)), dim3(1024), 0, MT_ST, P, ld, C, count, p1,
                      p2, mean, invstd, a, dgamma, dbeta, k1, k0);
   PVN3D_LAUNCH_CHECK();
   return 0;

@@ -241,7 +241,7 @@ class FPTrain(torch.autograd.Function):
     the point-major (B, n, C_out) fp32 tensor."""
 
     @staticmethod
-    def forward(ctx, unknow_feats, known_feats, idx, weight, layers, *params):
+    def forward(ctx, unknow_feats, known_feats, idx, weight, layers, channel_major, *params):
         B, C2, mk = known_feats.shape
         n = idx.size(1)
         C1 = unknow_feats.size(1) if unknow_feats is not None else 0
@@ -264,8 +264,14 @@ class FPTrain(torch.autograd.Function):
             ch = _Chain(x0, c0, ws, gs, bs, [bn for _, bn in layers])
             h = ch.forward()
             cout = ch.c[-1]
-            out = torch.empty((B, n, cout), dtype=torch.float32, device=dev)
-            check(lib.pvn3d_mt_unpack_out(rows, _ld(cout), cout, h.data_ptr(), out.data_ptr(), cout, st), "mt_unpack_out")
+            if channel_major:        # the reference's contiguous (B, C_out, n)
+                out = torch.empty((B, cout, n), dtype=torch.float32, device=dev)
+                check(lib.pvn3d_mt_unpack_cm(B, n, _ld(cout), 0, cout, h.data_ptr(), out.data_ptr(), st), "mt_unpack_cm")
+            else:                    # point-major (B, n, C_out): the next level gathers rows
+                out = torch.empty((B, n, cout), dtype=torch.float32, device=dev)
+                check(lib.pvn3d_mt_unpack_out(rows, _ld(cout), cout, h.data_ptr(), out.data_ptr(), cout, st),
+                      "mt_unpack_out")
+        ctx.channel_major = channel_major
         ctx.chain = ch
         ctx.meta = (B, n, mk, C2, C1, idx, weight,
                     unknow_feats is not None and unknow_feats.requires_grad, known_feats.requires_grad)
@@ -281,8 +287,11 @@ class FPTrain(torch.autograd.Function):
         with on_device(dev):
             st = _stream(gout)
             dh = torch.empty((ch.rows, _ld(cout)), dtype=torch.bfloat16, device=dev)
-            check(lib.pvn3d_mt_pack_grad(ch.rows, _ld(cout), cout, gout.data_ptr(), cout, dh.data_ptr(), st),
-                  "mt_pack_grad")
+            if ctx.channel_major:
+                check(lib.pvn3d_mt_pack_cm(B, n, _ld(cout), cout, gout.data_ptr(), dh.data_ptr(), st), "mt_pack_cm")
+            else:
+                check(lib.pvn3d_mt_pack_grad(ch.rows, _ld(cout), cout, gout.data_ptr(), cout, dh.data_ptr(), st),
+                      "mt_pack_grad")
             dx0, dws, dgs, dbs = ch.backward(dh, need_u or need_k)
             dk = du = None
             if need_k:
@@ -296,7 +305,7 @@ class FPTrain(torch.autograd.Function):
         for li, dw in enumerate(dws):
             grads += [dw.view(dw.size(0), dw.size(1), 1, 1), dgs[li], dbs[li]]
         ctx.chain = None
-        return (du, dk, None, None, None) + tuple(grads)
+        return (du, dk, None, None, None, None) + tuple(grads)
 
 
 def sa_level_train(module, xyz, new_xyz, features, idxs):
@@ -313,8 +322,10 @@ def sa_level_train(module, xyz, new_xyz, features, idxs):
         use_xyz = grouper.use_xyz or features is None
         spec.append((idx, use_xyz, layers))
         layer_lists.append(layers)
-    out = SALevelTrain.apply(xyz, new_xyz, features, spec, *_flat_params(layer_lists))
-    return out.transpose(1, 2)
+    out = SALevelTrain.apply(xyz, new_xyz, features, spec, *_flat_params(layer_lists)).transpose(1, 2)
+    # stand-alone the module returns the reference's contiguous (B, C, npoint); inside Pointnet2MSG the next level
+    # gathers rows from the point-major buffer, so the transposed view is handed over
+    return out if getattr(module, "_point_major_out", False) else out.contiguous()
 
 
 def fp_train(module, unknow_feats, known_feats, idx, weight):
@@ -322,6 +333,7 @@ def fp_train(module, unknow_feats, known_feats, idx, weight):
     layers = shared_mlp_layers(module.mlp)
     if layers is None:
         return None
-    out = FPTrain.apply(unknow_feats, known_feats, idx.contiguous(), weight.contiguous(), layers,
+    channel_major = not getattr(module, "_point_major_out", False)
+    out = FPTrain.apply(unknow_feats, known_feats, idx.contiguous(), weight.contiguous(), layers, channel_major,
                         *_flat_params([layers]))
-    return out.transpose(1, 2)
+    return out if channel_major else out.transpose(1, 2)
