@@ -433,15 +433,23 @@ def extra_configs(net, dev, poll_every, with_cpu):
     from pvn3d_amd import train_step as ts
     B = 24
     batch = ts.synthetic_batch(B, 12288, dev, seed_base=7500, n_obj=3072)
+    from pvn3d_amd.lib.pointnet2_utils import _train_mlp
     entry = dict(name="train_step", workload="config 5 on ONE GPU: Pointnet2MSG + offset heads, forward + vote loss + backward + Adam "
-                                              "step, %d frames of N=12288 per step; native gather/scatter ops + vote loss, "
-                                              "library (MIOpen/hipBLASLt) 1x1-conv GEMMs" % B)
-    for tag, dt in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
+                                              "step, %d frames of N=12288 per step; native gather/scatter ops + vote loss; "
+                                              "bf16: SA/FP SharedMLP forward+backward on csrc/mlp_train.hip (bf16 MFMA GEMM + fused "
+                                              "BatchNorm/ReLU/pool kernels); bf16_library_mlp / fp32: torch Conv2d/BatchNorm2d "
+                                              "(MIOpen/hipBLASLt)" % B)
+    for tag, dt, fused in (("fp32", None, False), ("bf16_library_mlp", torch.bfloat16, False),
+                           ("bf16_autocast", torch.bfloat16, True)):
         torch.manual_seed(1)
         model = ts.PointVoteNet().to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         losses = []
-        ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt)), 5, warm=2)
+        _train_mlp.TRAIN_FUSED = fused
+        try:
+            ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt)), 5, warm=2)
+        finally:
+            _train_mlp.TRAIN_FUSED = True
         entry[tag] = dict(ms_per_step=ms, frames_per_s=B * 1e3 / ms, loss_first=float(losses[0]), loss_last=float(losses[-1]),
                           peak_mem_gb=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
         del model, opt

@@ -312,6 +312,64 @@ int pvn3d_three_interpolate_grad_det(int b, int c, int n, int m, const float* gr
                                      const int* idx, const float* weight, float* grad_points,
                                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Training-mode SharedMLP on bf16 MFMA (csrc/mlp_train.hip; BASELINE config 5) ---------------------------
+ * Replaces, for a module in training mode, the reference's grouped (B,C,npoint,nsample) tensor -> [Conv2d 1x1 ->
+ * BatchNorm2d(batch statistics) -> ReLU] x L -> max_pool2d (pointnet2_modules.py:58-71, 188-206;
+ * pytorch_utils.py:25-50) and its autograd backward.  Activations are POINT-MAJOR bf16 matrices [rows][ld]
+ * (row = one (cloud, centre, sample) column, ld = channels rounded up to 16, pad columns zero).  bf16 = the upper
+ * half of the fp32 bit pattern, round-to-nearest-even. */
+/* C[M][N] = A[M][K] . B[N][K]^T (A, B bf16, K contiguous and a multiple of 16; lda, ldb multiples of 8) on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulate.  pvn3d_mt_gemm_nt: C bf16 [M][ldc] (columns N..ldc-1 written as
+ * zero); stat_sum / stat_sq, if given, [pvn3d_mt_gemm_nt_stat_rows(M)][stat_ld] = partial per-column sums of c
+ * and c^2 from the fp32 accumulators (BatchNorm statistics; summed by pvn3d_mt_bn_finalize).
+ * pvn3d_mt_gemm_nt_splitk: C fp32 [M][ldc] += A . B^T with K split `ksplit` ways (fp32 atomics) -- the weight
+ * gradient dW = dY^T . H with K = rows. */
+int pvn3d_mt_gemm_nt(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                     float* stat_sum, float* stat_sq, int stat_ld, void* stream);
+int pvn3d_mt_gemm_nt_stat_rows(int M);
+int pvn3d_mt_gemm_nt_splitk(int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                            int ksplit, void* stream);
+/* X bf16 [rows][ld] -> XT [ld][ldt]; W fp32 [rows][cols] (row stride lds) -> bf16 [out_rows][ld] zero-padded,
+ * transposed when `transpose`; bf16 [B*R][ld] channels [c_off, c_off+C) <-> fp32 channel-major [B][C][R]. */
+int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream);
+int pvn3d_mt_pack_weight(int rows, int cols, const float* W, int lds, int transpose, void* out, int out_rows, int ld,
+                         void* stream);
+int pvn3d_mt_unpack_cm(int b, int R, int ld, int c_off, int C, const void* X, float* out, void* stream);
+int pvn3d_mt_pack_cm(int b, int R, int ld, int C, const float* in, void* X, void* stream);
+/* Layer-0 inputs.  SA: X0[(b*m+j)*ns+s][c] = relative xyz (c < 3 when use_xyz) ++ feat[b, c, idx[b,j,s]]
+ * (QueryAndGroup, pointnet2_utils.py:293-330); FP: X0[b*n+i][c] = three_interpolate(known)[c < C2] ++ unknown
+ * (pointnet2_modules.py:188-203).  feat / known / unknown: fp32, element (b,c,n) at base + b*sb + c*sc + n*sn. */
+int pvn3d_mt_gather_sa(int b, int n, int m, int ns, int C, int use_xyz, const float* xyz, const float* new_xyz,
+                       const float* feat, long long fsb, long long fsc, long long fsn, const int* idx, void* X0, int ld,
+                       void* stream);
+int pvn3d_mt_gather_fp(int b, int n, int mk, int C2, int C1, const float* known, long long ksb, long long ksc,
+                       long long ksn, const float* unknown, long long usb, long long usc, long long usn, const int* idx,
+                       const float* w, void* X0, int ld, void* stream);
+/* BatchNorm2d in training mode.  finalize: partial sums [P][ld] -> mean, 1/std, a = gamma/std, b = beta - mean*a
+ * (zero in pad channels), running_mean / running_var updated with `momentum` (unbiased variance) when given.
+ * relu_apply: H = relu(a y + b).  pool_max: max over the ns rows of every group -> out[g*out_ld + c] fp32 and the
+ * arg-index (first maximum), pool_bwd its backward.  bwd_reduce: partial sums of dz = dH.[H>0] and dz.yhat over
+ * pvn3d_mt_bn_bwd_partials(rows) row blocks; bwd_finalize: dgamma, dbeta and the affine form of the backward
+ * dY = a.dz + k1.y + k0; bwd_apply applies it. */
+int pvn3d_mt_bn_finalize(int P, int ld, int C, double count, const float* psum, const float* psq, const float* gamma,
+                         const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* mean,
+                         float* invstd, float* a, float* b, void* stream);
+int pvn3d_mt_bn_relu_apply(long long rows, int ld, const void* Y, const float* a, const float* b, void* H, void* stream);
+int pvn3d_mt_pool_max(long long G, int ns, int ld, int C, const void* H, float* out, long long out_ld,
+                      unsigned char* arg, void* stream);
+int pvn3d_mt_pool_bwd(long long G, int ns, int ld, int C, const float* dout, long long out_ld, const unsigned char* arg,
+                      void* dH, void* stream);
+int pvn3d_mt_pack_grad(long long rows, int ld, int C, const float* g, long long gld, void* dH, void* stream);
+int pvn3d_mt_unpack_out(long long rows, int ld, int C, const void* H, float* out, long long out_ld, void* stream);
+int pvn3d_mt_bn_bwd_partials(long long rows);
+int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* H, const void* Y, const float* mean,
+                           const float* invstd, float* p1, float* p2, void* stream);
+int pvn3d_mt_bn_bwd_finalize(int P, int ld, int C, double count, const float* p1, const float* p2, const float* mean,
+                             const float* invstd, const float* a, float* dgamma, float* dbeta, float* k1, float* k0,
+                             void* stream);
+int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* H, const void* Y, const float* a,
+                          const float* k1, const float* k0, void* dY, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,12 +4,14 @@ What runs where:
   * FPS, gather, ball query, grouping, three_nn, three_interpolate and ALL their gradients: the hand-written
     gfx950 kernels of this package (fp32 gathers / atomic or deterministic scatters), through the reference's
     autograd Function API (lib/pointnet2_utils/pointnet2_utils.py);
-  * the 1x1-conv SharedMLP layers (the grouped-point x MLP-weight contraction) forward and backward: plain
-    library GEMMs -- torch Conv2d / Conv1d, i.e. MIOpen / hipBLASLt on the bf16 MFMA pipes under
-    ``torch.autocast(dtype=torch.bfloat16)`` -- with fp32 master weights.  Training-mode BatchNorm needs the
-    batch statistics of every layer's pre-activation over ALL columns before the next layer can start, so the
-    single-pass fused chain of the inference path (csrc/sa_mlp.hip) does not apply here; a 1x1 convolution
-    between two materialised tensors is a plain GEMM and belongs to the vendor library;
+  * the SharedMLP layers of every SA / FP module (the grouped-point x MLP-weight contraction: 1x1 conv ->
+    BatchNorm with batch statistics -> ReLU, then max-pool) forward and backward: csrc/mlp_train.hip through
+    lib/pointnet2_utils/_train_mlp.py -- point-major bf16 activations, one hand-written bf16 MFMA GEMM kernel
+    (fp32 accumulate; BatchNorm statistics in its epilogue; split-K for the weight gradient) and fused
+    BatchNorm / ReLU / pool kernels, fp32 master weights (``_train_mlp.TRAIN_FUSED = False`` restores torch
+    Conv2d / BatchNorm2d = MIOpen / hipBLASLt);
+  * the two small per-point heads of this file (not part of the reference's hot path): torch Conv1d / BatchNorm1d
+    under ``torch.autocast``;
   * the vote loss (of_l1_loss, lib/loss.py) forward and backward: csrc/vote_loss.hip, fp32;
   * gradient averaging across ranks: bucketed asynchronous all-reduce (sharding.all_reduce_gradients; RCCL
     over xGMI) instead of the reference's nn.DataParallel reduce-to-GPU-0 (train_linemod_pvn3d.py:480).

@@ -137,3 +137,42 @@ def test_fp_module_training_matches_torch(dev):
         assert _rel(a[key], b[key]) < 1.2 * _rel(c[key], b[key]) + 5e-3, key
     for k in b["params"]:
         assert _rel(a["params"][k], b["params"][k]) < 1.2 * _rel(c["params"][k], b["params"][k]) + 5e-3, k
+
+
+def test_full_size_training_gradients_vs_torch_autocast(dev):
+    """BASELINE config 5 shapes (N = 12288, 2 frames): loss and every parameter gradient of the voting network
+    with the SA / FP MLPs on csrc/mlp_train.hip, against the same network through torch fp32; the yardstick is
+    torch's own autocast(bfloat16) run of the reference composition (see the two tests above for why bf16
+    gradients of the early layers cannot be closer than ~10 % to fp32 in relative L2)."""
+    from pvn3d_amd import train_step as ts
+    from pvn3d_amd.lib.pointnet2_utils import _train_mlp
+    torch.manual_seed(0)
+    batch = ts.synthetic_batch(2, 12288, dev, seed_base=60, n_obj=3072)
+    base = ts.PointVoteNet().to(dev).train()
+    res = {}
+    for mode in ("fp32", "autocast", "fused"):
+        model = copy.deepcopy(base)
+        _train_mlp.TRAIN_FUSED = mode == "fused"
+        try:
+            if mode == "fp32":
+                kp, ctr = model(batch["pc"])
+            else:
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    kp, ctr = model(batch["pc"])
+            loss = ts.vote_loss(kp.float(), ctr.float(), batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
+            loss.backward()
+        finally:
+            _train_mlp.TRAIN_FUSED = True
+        res[mode] = (loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    l32, g32 = res["fp32"]
+    for mode in ("autocast", "fused"):
+        assert abs(res[mode][0] - l32) <= 2e-2 * abs(l32), mode
+    assert set(res["fused"][1]) == set(g32)
+    floor = 1e-3 * max(g.norm().item() for g in g32.values())
+    err = {m: {n: (res[m][1][n] - g).norm().item() / max(g.norm().item(), floor) for n, g in g32.items()}
+           for m in ("autocast", "fused")}
+    worse = [(n, err["fused"][n], err["autocast"][n]) for n in g32 if err["fused"][n] > 1.6 * err["autocast"][n] + 2e-2]
+    assert not worse, worse[:5]
+    # and on aggregate the hand-written chain is not further from fp32 than autocast is
+    mean = {m: float(np.mean(list(err[m].values()))) for m in err}
+    assert mean["fused"] <= 1.15 * mean["autocast"] + 5e-3, mean
