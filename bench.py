@@ -51,6 +51,25 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_VALU_TFLOPS = 157.3
 PEAK_FP32_MFMA_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32, exact fp32 (guide: matrix fp32 = vector peak)
+# VALU issue bound of the pair-scanning ops ("report time and % of a VALU bound, not GB/s"):
+# one fp32 VALU instruction per lane and clock on each of 256 CUs x 4 SIMDs x 32 lanes at 2.4 GHz (= the 157.3
+# TFLOP/s peak counted as FMAs), and the fewest instructions the reference arithmetic allows per (query, point)
+# pair: 3 sub + 3 mul + 2 add for the unfused squared distance, + 1 compare / min.
+VALU_LANE_INSTR_PER_S = 256 * 4 * 32 * 2.4e9
+VALU_INSTR_PER_PAIR = {"fps": 9, "three_nn": 9, "ball_query": 9}
+
+
+def pair_evals_per_frame(n_pts):
+    """(query, point) distance evaluations of the reference's brute-force kernels per frame (SURVEY.md 8d:
+    27.8 M / 27.9 M / 55.7 M at N = 12288)."""
+    s = n_pts / 12288.0
+    sa = [(int(12288 * s), int(2048 * s)), (int(2048 * s), int(1024 * s)), (int(1024 * s), int(512 * s)),
+          (int(512 * s), int(128 * s))]
+    fps = sum(n * (m - 1) for n, m in sa)
+    bq = 2 * sum(n * m for n, m in sa)          # two radii per level
+    nn = sum(n * m for n, m in [(int(512 * s), int(128 * s)), (int(1024 * s), int(512 * s)),
+                                (int(2048 * s), int(1024 * s)), (int(12288 * s), int(2048 * s))])
+    return {"fps": fps, "ball_query": bq, "three_nn": nn}
 
 # Pointnet2MSG hyper-parameters, pvn3d/lib/pvn3d.py:65-118 (input_channels = 6)
 SA_LEVELS = [  # (n_in, npoint, C_in, radii, nsamples, C_out)
@@ -363,9 +382,22 @@ def extra_configs(net, dev, poll_every, with_cpu):
     ms_b = _median_ms(lambda: post(inp), 20)
     both = (lambda: (run_net(net, inp, off), post(inp))) if net is not None else (lambda: post(inp))
     ms_ab = _median_ms(both, 20)
+    ms_g = ms_gab = ms_fps = None
+    if net is not None:
+        # the same forward as one HIP-graph replay (shapes are static at N = 12288), and FPS level 0 alone
+        from pvn3d_amd.lib.pointnet2_utils import _ext as _e
+        with torch.no_grad():
+            want = net(inp["pc"]).clone()
+        g = net.graphed(inp["pc"])
+        assert torch.equal(g(inp["pc"]), want), "graph replay differs from the eager forward"
+        ms_g = _median_ms(lambda: g(inp["pc"]), 20)
+        ms_gab = _median_ms(lambda: (g(inp["pc"]), post(inp)), 20)
+        ms_fps = _median_ms(lambda: _e.furthest_point_sampling(inp["pcld"], 2048), 20)
+        del g
     res = post(inp)
     out.append(dict(name="b1_latency", workload="config 2 (LineMOD eval path), ONE frame per call: N=12288, n_obj=3072, K=8",
-                    ms_per_frame=dict(pointnet2_msg=ms_a, vote_cluster_pose=ms_b, both_serial=ms_ab),
+                    ms_per_frame=dict(pointnet2_msg=ms_a, vote_cluster_pose=ms_b, both_serial=ms_ab,
+                                      pointnet2_msg_graph=ms_g, both_serial_graph=ms_gab, fps_level0=ms_fps),
                     frames_per_s=1e3 / ms_ab, meanshift_iters_max=int(res["iters"].max().item()),
                     pose_err_vs_ground_truth=pose_err(res, inp["frames"])))
 
@@ -591,6 +623,24 @@ def main():
                 rooflines[name] = dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=gbs / PEAK_HBM_GBS, traffic=None, ms_per_step=op_step[name],
                                        algorithmic_bytes_per_frame=alg[name])
+        # the pair-scanning ops move kilobytes: their bound is VALU issue.  `achieved` counts the REFERENCE's
+        # pair evaluations (what a brute-force kernel must do); the grid / cell kernels skip most of them exactly,
+        # which is why a fraction can exceed what the CUs they occupy could issue
+        pairs = pair_evals_per_frame(args.n_pts)
+        for name in ("fps", "three_nn", "ball_query"):
+            if name in op_step and op_step[name] > 0:
+                gp = pairs[name] * F / (op_step[name] * 1e-3) / 1e9
+                peak = VALU_LANE_INSTR_PER_S / VALU_INSTR_PER_PAIR[name] / 1e9
+                entry = dict(bound="valu", achieved=gp, peak=peak, unit="Gpair/s", frac=gp / peak, traffic=None,
+                             ms_per_step=op_step[name], pair_evals_per_frame=pairs[name],
+                             valu_instr_per_pair=VALU_INSTR_PER_PAIR[name], hbm_view=rooflines.get(name))
+                if name == "fps":
+                    # one wave per cloud (csrc/fps_cells.hip): F of the chip's 1024 SIMDs are in use
+                    entry["simds_in_use"] = F
+                    entry["frac_of_simds_in_use"] = gp / (peak * F / 1024.0)
+                    entry["note"] = ("serial in the samples: one wave per cloud; exact spatial culling evaluates ~3 % of "
+                                     "the reference's pairs, so the fraction of the occupied SIMDs' issue rate exceeds 1")
+                rooflines[name] = entry
         if net is not None:
             sa_fl, fp_fl = mlp_flops_per_frame(net, scale)
             for name, fl in (("sa_mlp", sa_fl), ("fp_mlp", fp_fl)):
@@ -632,6 +682,7 @@ def main():
                     if all(p in sb for p in parts):
                         rooflines[name]["traffic"] = sum(sb[p]["total_bytes"] for p in parts)
                         rooflines[name]["traffic_source"] = "profiles/%s_pmc_traffic.json" % pmc.get("tag")
+                        rooflines[name]["traffic_measured_in_run"] = False
         except (OSError, ValueError, KeyError):
             pass
         leaf = {k: v for k, v in per_step.items() if k != "pointnet2_msg_total"}
@@ -680,6 +731,12 @@ def main():
         if world == 1 and not args.no_extra_configs and args.n_pts == 12288:
             out["device_copy"] = device_copy_bandwidth(dev)
             out["configs"] = extra_configs(net, dev, args.poll_every, not args.no_cpu_baseline)
+            # the headline converges in ~4 MeanShift iterations per fit; the heavy-tailed vote set (47-274
+            # iterations, the range SURVEY.md section 6 saw on the reference) is the hard case: its own top-level value
+            for c in out["configs"]:
+                if c.get("name") == "heavy_tail_votes":
+                    out["value_heavy_tail"] = dict(value=c["frames_per_s"], unit="frames/s (vote -> cluster -> pose only)",
+                                                   ms_per_frame=c["ms_per_frame"], meanshift_iters=c["meanshift_iters"])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

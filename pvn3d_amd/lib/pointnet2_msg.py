@@ -25,6 +25,38 @@ def _geo_stream(dev):
     return st
 
 
+class GraphedForward(object):
+    """A HIP-graph replay of ``net(pointcloud)`` for ONE static input shape (eval mode, no autograd): the ~70
+    launches of the fused forward -- both streams of it, the geometry stream joins the capture through its events
+    -- become one graph launch.  The reference evaluates one frame per call (test_mini_batch_size = 1,
+    pvn3d/common.py:41): at B = 1 the forward is launch-bound outside FPS.
+    ``g = GraphedForward(net, example); out = g(pc)``: `pc` is copied into the captured input buffer, the returned
+    tensor is the captured output buffer (overwritten by the next call)."""
+
+    def __init__(self, net, example, warmup=3):
+        assert not net.training and example.is_cuda
+        self.net = net
+        self.static_in = example.clone()
+        cur = torch.cuda.current_stream(example.device)
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up off the capture: one-time function attributes,
+            for _ in range(warmup):                          # allocator pools, packed weights
+                net(self.static_in)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(example.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_out = net(self.static_in)
+
+    def __call__(self, pointcloud):
+        if pointcloud.shape != self.static_in.shape:
+            raise RuntimeError("GraphedForward was captured for shape %s" % (tuple(self.static_in.shape),))
+        self.static_in.copy_(pointcloud)
+        self.graph.replay()
+        return self.static_out
+
+
 class Pointnet2MSG(nn.Module):
     def __init__(self, input_channels=6, use_xyz=True):
         super(Pointnet2MSG, self).__init__()
@@ -58,6 +90,10 @@ class Pointnet2MSG(nn.Module):
             fp._point_major_out = True
         for sa in self.SA_modules:
             sa._point_major_out = True
+
+    def graphed(self, example):
+        """-> GraphedForward(self, example): HIP-graph replay of the eval forward for example's shape."""
+        return GraphedForward(self, example)
 
     @staticmethod
     def _break_up_pc(pc):

@@ -208,7 +208,12 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     # (F*C flags; the reference synchronises per class and per mean-shift iteration).  With every class
     # slot instantiated the vote buffer alone is F*C*(K+1)*N*16 bytes (2.4 GB at 64 frames, 21 classes)
     # and every launch carries 21 - (objects in view) empty segments per frame.
-    pairs = torch.nonzero(present.cpu())                                        # (n_inst, 2) on the host
+    # A single frame (the reference's test_mini_batch_size = 1) instantiates all C class slots instead (40 MB of
+    # votes): no host round trip at all, the absent classes are empty segments.
+    if F == 1:
+        pairs = torch.stack([torch.zeros(C, dtype=torch.long), torch.arange(C, dtype=torch.long)], 1)
+    else:
+        pairs = torch.nonzero(present.cpu())                                    # (n_inst, 2) on the host
     n_inst = int(pairs.size(0))
     poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
     poses_full[:, :, 0, 0] = 1.0

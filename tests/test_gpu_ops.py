@@ -763,6 +763,25 @@ def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_graphed_forward_replays_the_eager_forward(dev):
+    """Pointnet2MSG.graphed: the HIP-graph replay of the eval forward (both streams captured) returns the eager
+    forward's bits, also for a second input of the same shape, and refuses another shape."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    torch.manual_seed(5)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    pcs = []
+    for i in range(2):
+        x = synth.synth_frame(frame=90 + i, n_pts=12288, n_obj=3072)
+        pcs.append(torch.from_numpy(np.concatenate([x["pcld"], x["feats"].T], 1)[None]).to(dev))
+    with torch.no_grad():
+        want = [net(pc).clone() for pc in pcs]
+    g = net.graphed(pcs[0])
+    for pc, w in zip(pcs + pcs[:1], want + want[:1]):
+        assert torch.equal(g(pc), w)
+    with pytest.raises(RuntimeError):
+        g(pcs[0][:, :100])
+
+
 def test_geometry_ahead_handle_gives_the_same_forward(dev):
     """Pointnet2MSG.geometry_ahead (xyz-only work of a batch enqueued early, for pipelining across batches)
     + forward(geometry=handle) returns exactly what the plain forward returns, also when the handle of one
