@@ -222,10 +222,15 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * flags: PVN3D_MS_ALIGNED32 -- the caller guarantees seg_off[s] % 32 == 0 and that rows
  * [seg_off[s], seg_off[s] + roundup32(seg_cnt[s])) belong to segment s (pvn3d_vote_compact's
  * layout does; informational).  The iteration kernel keeps two seeds per lane (packed fp32 math)
- * when max_cnt_host >= 1024 and one otherwise, and splits a fit's points over the four waves of a
- * workgroup when the launch would not fill the chip; all variants give identical bits, and the
- * PVN3D_MS_FORCE_* flags pin the choice (tests, A/B timing). */
+ * when max_cnt_host >= 256 and one otherwise, and splits a fit's points over the four waves of a
+ * workgroup (always, unless PVN3D_MS_FORCE_WHOLE); all variants give identical bits, and the
+ * PVN3D_MS_FORCE_* flags pin the choice (tests, A/B timing).
+ * Exact early-out: from iteration 5 on, seeds whose update returned their own position bit for bit
+ * (fixed points of the iteration function: shift 0 in every later iteration) are dropped from the
+ * iterated set every fourth iteration -- same centres, labels and iteration counts, bit for bit;
+ * PVN3D_MS_NO_EARLY_OUT iterates every seed every time (tests, A/B timing). */
 #define PVN3D_MS_ALIGNED32 1
+#define PVN3D_MS_NO_EARLY_OUT 2
 #define PVN3D_MS_FORCE_SCALAR 4
 #define PVN3D_MS_FORCE_PACKED 8
 #define PVN3D_MS_FORCE_WHOLE 16

@@ -44,6 +44,11 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* core_idx;        // [total]  per segment: indices of "core" points, ascending
   int* nc_idx;          // [total]  per segment: indices of the other points, ascending
   int* n_core;          // [n_seg]
+  // exact early-out of converged seeds (ms_compact_kernel)
+  unsigned* frozen_cm;  // [n_seg]  max |c'|^2 over the seeds found to be bitwise fixed points (float bits)
+  int* act_cnt;         // [n_seg]  0: no list (every seed is iterated); k + 1: act_idx holds k seeds
+  int* act_form;        // [n_seg]  arithmetic form (1 exact, 2 fast) the list was built for
+  int* act_idx;         // [total]  per segment: the seeds that are not fixed points under act_form, ascending
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -53,6 +58,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_c0 = take(sizeof(float4) * (size_t)total);
   const size_t o_c1 = take(sizeof(float4) * (size_t)total);
+  const size_t o_aidx = take(sizeof(int) * (size_t)total);
   const size_t o_small = off;  // everything from here is zero-filled per call
   const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_cm = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
@@ -63,6 +69,9 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_core = take(sizeof(int) * (size_t)total);
   const size_t o_nc = take(sizeof(int) * (size_t)total);
   const size_t o_ncore = take(sizeof(int) * (size_t)n_seg);
+  const size_t o_fcm = take(sizeof(unsigned) * (size_t)n_seg);
+  const size_t o_acnt = take(sizeof(int) * (size_t)n_seg);
+  const size_t o_aform = take(sizeof(int) * (size_t)n_seg);
   if (st) {
     st->cbuf[0] = (float4*)(base + o_c0);
     st->cbuf[1] = (float4*)(base + o_c1);
@@ -75,6 +84,10 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->core_idx = (int*)(base + o_core);
     st->nc_idx = (int*)(base + o_nc);
     st->n_core = (int*)(base + o_ncore);
+    st->frozen_cm = (unsigned*)(base + o_fcm);
+    st->act_cnt = (int*)(base + o_acnt);
+    st->act_form = (int*)(base + o_aform);
+    st->act_idx = (int*)(base + o_aidx);
   }
   (void)o_small;
   return off;
@@ -175,6 +188,10 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 // point order across the chunks; total = (P0 + P1) + (P2 + P3).
 // ---------------------------------------------------------------------------------------
 typedef float ms_f2 __attribute__((ext_vector_type(2)));
+#ifdef MS_FROZEN_PROBE
+// tools/ms_frozen_stats.py: [t] = seeds whose iteration-t update is a bitwise fixed point, [512 + t] = seeds iterated
+__device__ int g_ms_probe[1024];
+#endif
 
 __device__ __forceinline__ ms_f2 ms_fma2(ms_f2 a, ms_f2 b, ms_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ ms_f2 ms_splat(float x) { return ms_f2{x, x}; }
@@ -218,11 +235,12 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
     unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
-    int max_iter, float thresh, float kappa, float inv_kappa) {
+    int max_iter, float thresh, float kappa, float inv_kappa, unsigned* __restrict__ frozen_cm,
+    const int* __restrict__ act_cnt, const int* __restrict__ act_form, const int* __restrict__ act_idx) {
   constexpr int S = PK ? 2 : 1;
   constexpr int LANES = SPLIT ? 64 : MS_THREADS;     // distinct seed lanes of the workgroup
   __shared__ float4 s_pts[MS_CHUNK];
-  __shared__ float s_red[2][MS_THREADS / 64];
+  __shared__ float s_red[3][MS_THREADS / 64];
   __shared__ MsAcc s_part[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
   const int seg = blockIdx.y;
   const int n = seg_cnt[seg];
@@ -233,26 +251,41 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float prev = __uint_as_float(ms[t - 1]);
     if (!(prev >= thresh) || (t - 1) > max_iter) return;  // converged / capped (:42)
   }
+  unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
+  // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
+  // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
+  // |c'|^2 <= 64 (no overflow: the largest weight is exp2(|c'|^2)) the per-pair subtraction of
+  // |c'|^2 is dropped.  The bound comes from the previous iteration's output (seeds that are no longer
+  // iterated -- below -- through frozen_cm); iteration 1 always takes the exact form.
+  const bool fast = t > 1 && fmaxf(__uint_as_float(cmx[t - 1]), __uint_as_float(frozen_cm[seg])) <= 64.f;
+  // Exact early-out: a seed whose update returned its own position bit for bit is a fixed point of this
+  // iteration function -- it would return the same bits in every later iteration of the same arithmetic form,
+  // shift 0 -- so it is dropped from the seed list (ms_compact_kernel) and only the others are iterated.  Only
+  // C[max_idx] and the per-iteration maximum shift reach the output (meanshift_pytorch.py:42-51), and both
+  // position buffers hold a fixed point's position.  A list built for the other form is ignored.
+  const int form = fast ? 2 : 1;
+  const int lc = act_cnt[seg];
+  const bool use_list = lc > 0 && act_form[seg] == form;
+  const int n_eff = use_list ? lc - 1 : n;
+  if (tile0 >= n_eff) return;
+#ifdef MS_FROZEN_PROBE
+  if (threadIdx.x == 0 && t < 256) atomicAdd(&g_ms_probe[768 + t], 1);      // workgroups that do work
+#endif
   const int base = seg_off[seg];
   const float4 org = pts[base];  // frame origin: the fit's first point
   const int tid = threadIdx.x;
   const int sl = SPLIT ? (tid & 63) : tid;            // seed lane
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
-  // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
-  // |c'|^2 <= 64 (no overflow: the largest weight is exp2(|c'|^2)) the per-pair subtraction of
-  // |c'|^2 is dropped.  The bound comes from the previous iteration's output; iteration 1 always
-  // takes the exact form.
-  unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
-  const bool fast = t > 1 && __uint_as_float(cmx[t - 1]) <= 64.f;
-
   float cx[S], cy[S], cz[S];
+  int sid[S];             // seed index of this lane's seeds (-1: none)
   ms_f2 p2x = ms_splat(0.f), p2y = ms_splat(0.f), p2z = ms_splat(0.f), pcm = ms_splat(0.f);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int i = tile0 + s * LANES + sl;
+    const int j = tile0 + s * LANES + sl;
+    const int i = j < n_eff ? (use_list ? act_idx[base + j] : j) : -1;
+    sid[s] = i;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) {
+    if (i >= 0) {
       if (t == 1) {
         const float4 a = pts[base + i];
         c = make_float4((a.x - org.x) * kappa, (a.y - org.y) * kappa, (a.z - org.z) * kappa, 0.f);
@@ -317,11 +350,11 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     tot.z = (acc[0].z + acc[NACC > 1 ? 1 : 0].z) + (acc[NACC > 2 ? 2 : 0].z + acc[NACC > 3 ? 3 : 0].z);
   }
 
-  float mshift = 0.f, mcm = 0.f;
+  float mshift = 0.f, mcm = 0.f, fcm = 0.f;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int i = tile0 + s * LANES + sl;
-    if (i < n) {
+    const int i = sid[s];
+    if (i >= 0) {
       const float inv = 1.0f / tot.w[s];
       const float nx = tot.x[s] * inv, ny = tot.y[s] * inv, nz = tot.z[s] * inv;
       const float ex = nx - cx[s], ey = ny - cy[s], ez = nz - cz[s];
@@ -329,30 +362,88 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
       mshift = fmaxf(mshift, sh);
       const float ncm = fmaf(nz, nz, fmaf(ny, ny, nx * nx));
       mcm = (ncm <= mcm) ? mcm : ((ncm != ncm) ? __builtin_inff() : ncm);   // NaN counts as +inf
-      cout[base + i] = make_float4(nx, ny, nz, 0.f);
+      // .w = the form under which the seed is a bitwise fixed point (0: it moved)
+      const bool fixed = nx == cx[s] && ny == cy[s] && nz == cz[s];
+      cout[base + i] = make_float4(nx, ny, nz, fixed ? (float)form : 0.f);
+      if (fixed) fcm = fmaxf(fcm, ncm);
+#ifdef MS_FROZEN_PROBE
+      if (t < 512) {
+        atomicAdd(&g_ms_probe[512 + t], 1);
+        if (nx == cx[s] && ny == cy[s] && nz == cz[s]) atomicAdd(&g_ms_probe[t], 1);
+      }
+#endif
     }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
     mcm = fmaxf(mcm, __shfl_xor(mcm, o, 64));
+    fcm = fmaxf(fcm, __shfl_xor(fcm, o, 64));
   }
   if (SPLIT) {          // one wave left
     if (tid == 0) {
       atomicMax(ms + t, __float_as_uint(mshift));
       atomicMax(cmx + t, __float_as_uint(mcm));
+      if (fcm > 0.f) atomicMax(frozen_cm + seg, __float_as_uint(fcm));
       atomicMax(iters + seg, t);
     }
     return;
   }
-  if ((tid & 63) == 0) { s_red[0][tid >> 6] = mshift; s_red[1][tid >> 6] = mcm; }
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = mshift; s_red[1][tid >> 6] = mcm; s_red[2][tid >> 6] = fcm; }
   __syncthreads();
   if (tid == 0) {
-    float m = s_red[0][0], c = s_red[1][0];
-    for (int i = 1; i < MS_THREADS / 64; ++i) { m = fmaxf(m, s_red[0][i]); c = fmaxf(c, s_red[1][i]); }
+    float m = s_red[0][0], c = s_red[1][0], f = s_red[2][0];
+    for (int i = 1; i < MS_THREADS / 64; ++i) {
+      m = fmaxf(m, s_red[0][i]); c = fmaxf(c, s_red[1][i]); f = fmaxf(f, s_red[2][i]);
+    }
     atomicMax(ms + t, __float_as_uint(m));
     atomicMax(cmx + t, __float_as_uint(c));
+    if (f > 0.f) atomicMax(frozen_cm + seg, __float_as_uint(f));
     atomicMax(iters + seg, t);
+  }
+}
+
+// Seed list for the iterations after t: the seeds of every still-running fit that are not bitwise fixed
+// points under the arithmetic form iteration t+1 will use, in ascending order.  grid (n_seg), block 1024.
+__global__ __launch_bounds__(1024) void ms_compact_kernel(
+    const int* __restrict__ seg_off, const int* __restrict__ seg_cnt, const float4* __restrict__ cur,
+    const unsigned* __restrict__ maxshift, const unsigned* __restrict__ cmmax,
+    const unsigned* __restrict__ frozen_cm, int t, int max_iter, float thresh, int* __restrict__ act_cnt,
+    int* __restrict__ act_form, int* __restrict__ act_idx) {
+  __shared__ int s_wave[16];
+  __shared__ int s_run;
+  const int seg = blockIdx.x;
+  const int n = seg_cnt[seg];
+  if (n <= 0) return;
+  const float prev = __uint_as_float(maxshift[(size_t)seg * (max_iter + 2) + t]);
+  if (!(prev >= thresh) || t > max_iter) return;        // no iteration t+1 for this fit
+  const bool fast = fmaxf(__uint_as_float(cmmax[(size_t)seg * (max_iter + 2) + t]),
+                          __uint_as_float(frozen_cm[seg])) <= 64.f;
+  const float code = fast ? 2.f : 1.f;
+  const int base = seg_off[seg];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_run = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool active = i < n && cur[base + i].w != code;
+    const unsigned long long b = __ballot(active);
+    if (lane == 0) s_wave[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    int before = s_run;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    if (active) act_idx[base + before + pvn3d_mbcnt(b)] = i;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w];
+      s_run += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    act_cnt[seg] = s_run + 1;
+    act_form[seg] = fast ? 2 : 1;
   }
 }
 
@@ -664,17 +755,35 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     PVN3D_RETURN_IF_ERR(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
   }
   int rc = 0;
+  int next_poll = poll_every;
   for (int t = 1; t <= max_iter + 1; ++t) {
     const float4* cin = S.cbuf[(t - 1) & 1];
     float4* cout = S.cbuf[t & 1];
 #define MS_ITER(PK_, SP_)                                                                                    \
   hipLaunchKernelGGL((ms_iter_kernel<PK_, SP_>), grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout, \
-                     S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa)
+                     S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa, S.frozen_cm, S.act_cnt,   \
+                     S.act_form, S.act_idx)
     if (packed) { if (split) MS_ITER(true, true); else MS_ITER(true, false); }
     else { if (split) MS_ITER(false, true); else MS_ITER(false, false); }
 #undef MS_ITER
     if ((rc = (int)hipGetLastError()) != 0) break;
-    if (poll && (t % poll_every) == 0 && t <= max_iter) {
+    // from iteration 5 on (the easy fits are done after ~4) the seed lists are rebuilt every fourth iteration:
+    // on heavy-tailed votes 85-89 % of the seeds are bitwise fixed points after five iterations
+    // (tools/ms_frozen_stats.py).  What it buys (144 fits of 3072 votes, 10 % outliers of sigma 30 cm, 267
+    // iterations): 43.4 -> 26.8 ms.  The iteration launch does not get 8x shorter with 8x fewer seeds: its
+    // duration is ~1.2 us per still-running fit + 7 us whatever the number of busy workgroups (measured; a
+    // 16-wave workgroup shape and batched prologue loads changed nothing), so the long tail of a heavy-tailed
+    // batch stays (iterations) x (that floor).
+    if (!(flags & PVN3D_MS_NO_EARLY_OUT) && t >= 5 && (t & 3) == 1 && t <= max_iter) {
+      hipLaunchKernelGGL(ms_compact_kernel, dim3(n_seg), dim3(1024), 0, st, seg_off, seg_cnt, cout, S.maxshift,
+                         S.cmmax, S.frozen_cm, t, max_iter, thresh, S.act_cnt, S.act_form, S.act_idx);
+      if ((rc = (int)hipGetLastError()) != 0) break;
+    }
+    // Poll schedule: every poll_every iterations at first, then geometrically sparser (x1.5).  Late iterations
+    // are short (few fits, few seeds left) -- four of them take less than one host round trip, so a fixed
+    // cadence leaves the GPU waiting for the host -- and an iteration enqueued for nothing costs one launch.
+    if (poll && t == next_poll && t <= max_iter) {
+      next_poll = t + (t / 2 > poll_every ? t / 2 : poll_every);
       hipLaunchKernelGGL(ms_poll_kernel, dim3(1), dim3(256), 0, st, S.maxshift, seg_cnt, n_seg,
                          t, max_iter, thresh, S.active + slot);
       if ((rc = (int)hipMemcpyAsync(poll_host + slot, S.active + slot, sizeof(int),
@@ -720,3 +829,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef MS_FROZEN_PROBE
+extern "C" int pvn3d_ms_probe_read(int* host_out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ms_probe), sizeof(int) * 1024);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    static int zeros[1024];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_ms_probe), zeros, sizeof(int) * 1024);
+  }
+  return (int)e;
+}
+#endif

@@ -33,6 +33,7 @@ def _poll_buf():
 
 
 MS_ALIGNED32 = 1    # include/pvn3d_hip.h PVN3D_MS_ALIGNED32
+MS_NO_EARLY_OUT = 2  # PVN3D_MS_NO_EARLY_OUT: iterate every seed in every iteration
 MS_FORCE_SCALAR = 4  # PVN3D_MS_FORCE_SCALAR: one seed per lane
 MS_FORCE_PACKED = 8  # PVN3D_MS_FORCE_PACKED: two seeds per lane (packed fp32 math)
 MS_FORCE_WHOLE = 16  # PVN3D_MS_FORCE_WHOLE: every wave walks all points of the fit
@@ -47,14 +48,14 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     seg_cnt.  Returns ctr (n_seg,3) float32, labels (total) uint8, iters (n_seg) int32.
     poll_every = 0 -> fully asynchronous (enqueues max_iter+1 iterations).
     aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows.
-    kernel: None (library default) or a '+'-joined choice of "scalar" | "packed" and "whole" | "split" --
-    pins the iteration kernel variant (all give identical results).
+    kernel: None (library default) or a '+'-joined choice of "scalar" | "packed", "whole" | "split" and
+    "noearly" (no early-out of converged seeds) -- pins the iteration kernel variant (all give identical results).
     """
     flags = MS_ALIGNED32 if aligned32 else 0
     if kernel is not None:
         for k in kernel.split("+"):
             flags |= {"scalar": MS_FORCE_SCALAR, "packed": MS_FORCE_PACKED, "whole": MS_FORCE_WHOLE,
-                      "split": MS_FORCE_SPLIT}[k]
+                      "split": MS_FORCE_SPLIT, "noearly": MS_NO_EARLY_OUT}[k]
     dev = pts4.device
     assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
     n_seg = int(seg_off.numel())

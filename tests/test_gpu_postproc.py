@@ -209,13 +209,16 @@ def test_iteration_kernel_variants_are_bit_identical(dev):
     so = torch.tensor(off[:-1], dtype=torch.int32, device=dev)
     sc = torch.tensor([len(a) for a in segs], dtype=torch.int32, device=dev)
     outs = {}
-    for kern in ("scalar+whole", "packed+whole", "scalar+split", "packed+split"):
+    # "+noearly": every seed iterated in every iteration; without it seeds that are bitwise fixed points of the
+    # iteration function leave the iterated set from iteration 5 on (exact: same bits)
+    kerns = ("scalar+whole+noearly", "packed+whole", "scalar+split", "packed+split", "packed+split+noearly", "scalar+whole")
+    for kern in kerns:
         c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern)
         l = l.cpu().numpy()
         valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)])     # rows past a segment's count are scratch
         outs[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
-    for kern in ("packed+whole", "scalar+split", "packed+split"):
-        for x, y in zip(outs["scalar+whole"], outs[kern]):
+    for kern in kerns[1:]:
+        for x, y in zip(outs[kerns[0]], outs[kern]):
             assert np.array_equal(x, y), kern
     assert outs["packed+split"][2].max() > 20       # the heavy-tailed fits really iterate
 
