@@ -115,7 +115,8 @@ class Pointnet2MSG(nn.Module):
         # `xyz` is allocated on the current stream but read by kernels of the geometry stream after this
         # function has returned and dropped its reference: keep the allocator from recycling it early
         xyz.record_stream(_geo_stream(xyz.device))
-        return self._geometry_ahead(xyz)
+        sa_geo, fp_geo = self._geometry_ahead(xyz)
+        return {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device}
 
     def _geometry_ahead(self, xyz):
         """Run every level's xyz-only work on the geometry stream; returns per-level results and
@@ -156,6 +157,9 @@ class Pointnet2MSG(nn.Module):
         ahead = (GEOMETRY_STREAM and _pm.FUSED_INFERENCE and not self.training and xyz.is_cuda
                  and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]
+        if geometry is not None and not ahead:
+            raise RuntimeError("a geometry handle is only used by the eval fast path (GEOMETRY_STREAM, "
+                               "FUSED_INFERENCE, no autograd): drop it or switch the module to eval / no_grad")
         if not ahead:
             nest = None
             for li, sa in enumerate(self.SA_modules):
@@ -168,7 +172,17 @@ class Pointnet2MSG(nn.Module):
                 l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
             return l_features[0]
         cur = torch.cuda.current_stream(xyz.device)
-        sa_geo, fp_geo = geometry if geometry is not None else self._geometry_ahead(xyz)
+        if geometry is not None:
+            if geometry["shape"] != tuple(xyz.shape) or geometry["device"] != xyz.device:
+                raise RuntimeError("geometry handle was built for a cloud of shape %s on %s, not %s on %s"
+                                   % (geometry["shape"], geometry["device"], tuple(xyz.shape), xyz.device))
+            sa_geo, fp_geo = geometry["sa"], geometry["fp"]
+            for (geom, _), in [(g,) for g in sa_geo]:
+                for t in [geom[0]] + list(geom[1]):
+                    if t is not None:
+                        t.record_stream(cur)       # produced on the geometry stream, consumed on THIS stream
+        else:
+            sa_geo, fp_geo = self._geometry_ahead(xyz)
         for sa, (geom, ev) in zip(self.SA_modules, sa_geo):
             cur.wait_event(ev)
             li_xyz, li_features = sa(l_xyz[-1], l_features[-1], geometry=geom)

@@ -109,6 +109,8 @@ class _PointnetSAModuleBase(nn.Module):
                     if m is None or m > (follow[-1] if follow else self.npoint):
                         break
                     follow.append(int(m))
+                if follow and max(follow) > 8192:
+                    follow = []        # fps_nest_verify stages at most 8192 picks in LDS: every level runs its own FPS
                 sel, dmax = _ext.furthest_point_sampling_nested(xyz, self.npoint, want_dmax=bool(follow))
         with _stage("gather"):
             xyz_t = xyz.transpose(1, 2).contiguous()
