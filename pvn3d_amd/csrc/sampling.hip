@@ -338,31 +338,51 @@ struct NestLevels {
   int count, tmax;
 };
 
-// grid (ceil(n0/256), b): thread k = candidate k of the FPS-ordered cloud `pts` (b, n0, 3); dmax (b, n0) = the
-// winning distances of the run that produced the order.  dynamic LDS: tmax x (x, y, z, D).
-__global__ __launch_bounds__(256) void fps_nest_verify_kernel(int n0, NestLevels lv, const float* __restrict__ pts,
-                                                              const int* __restrict__ dmax, int* __restrict__ first_bad) {
+// grid (ceil(n0/64), b), block 1024: lane = candidate k of the FPS-ordered cloud `pts` (b, n0, 3), wave = one of 16
+// segments of the rounds; dmax (b, n0) = the winning distances of the run that produced the order.  The running
+// minimum of a candidate over the rounds is a prefix minimum, and min() is exact under any association: every wave
+// first reduces its own segment of picks, then takes the minimum of the earlier segments as its start value and
+// walks its segment again with the checks -- 2 x (rounds / 16) serial steps instead of `rounds` (the kernel sits
+// on the critical path of a single-frame forward: 141 -> ~20 us).  dynamic LDS: tmax x (x, y, z, D).
+constexpr int NEST_SEGS = 16;
+__global__ __launch_bounds__(1024) void fps_nest_verify_kernel(int n0, NestLevels lv, const float* __restrict__ pts,
+                                                               const int* __restrict__ dmax, int* __restrict__ first_bad) {
   extern __shared__ float4 s_pick[];      // [tmax]: pick t and (bits of) the winning distance of round t
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float s_segmin[NEST_SEGS][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
   pts += (size_t)blockIdx.y * n0 * 3;
   dmax += (size_t)blockIdx.y * n0;
   first_bad += (size_t)blockIdx.y * FPS_NEST_LEVELS;
-  for (int t = threadIdx.x; t < lv.tmax; t += 256)
+  for (int t = threadIdx.x; t < lv.tmax; t += 1024)
     s_pick[t] = make_float4(pts[t * 3], pts[t * 3 + 1], pts[t * 3 + 2], __int_as_float(dmax[t]));
   __syncthreads();
   const int kc = min(k, n0 - 1);
   const float x = pts[kc * 3], y = pts[kc * 3 + 1], z = pts[kc * 3 + 2];
   const bool candidate = k < n0 && !fps_skipped(x, y, z);
+  // a violation needs k > t: the workgroup stops at its largest k
+  const int t_end = min(lv.tmax, (int)(blockIdx.x * 64 + 63) + 1);
+  // rounds 1 .. t_end-1 in NEST_SEGS segments; round t uses picks 0 .. t-1
+  const int per = (t_end - 1 + NEST_SEGS - 1) / NEST_SEGS;
+  const int ta = 1 + seg * per, tb = min(t_end, ta + per);
+  float m = 1e10f;
+  for (int t = ta; t < tb; ++t) {
+    const float4 prev = s_pick[t - 1];
+    const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
+    const float d = dx * dx + dy * dy + dz * dz;
+    m = __builtin_fminf(d, m);
+  }
+  s_segmin[seg][lane] = m;
+  __syncthreads();
+  float run = 1e10f;
+  for (int s = 0; s < seg; ++s) run = __builtin_fminf(s_segmin[s][lane], run);
   unsigned pk[FPS_NEST_LEVELS];
 #pragma unroll
   for (int l = 0; l < FPS_NEST_LEVELS; ++l) pk[l] = l < lv.count ? fps_prio(kc, lv.L[l], lv.Q[l]) : 0u;
-  // a violation needs k > t: the wave stops at its largest k
-  const int t_end = min(lv.tmax, (int)(blockIdx.x * 256 + (threadIdx.x | 63)) + 1);
-  float run = 1e10f;
   int bad[FPS_NEST_LEVELS];
 #pragma unroll
   for (int l = 0; l < FPS_NEST_LEVELS; ++l) bad[l] = 0x7fffffff;
-  for (int t = 1; t < t_end; ++t) {
+  for (int t = ta; t < tb; ++t) {
     const float4 prev = s_pick[t - 1];
     const int dt = __float_as_int(s_pick[t].w);
     const float dx = x - prev.x, dy = y - prev.y, dz = z - prev.z;
@@ -549,7 +569,7 @@ extern "C" int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_l
   // 0x7f7f7f7f = "no round has to be run"
   PVN3D_RETURN_IF_ERR(hipMemsetAsync(flags, 0x7f, (size_t)b * FPS_NEST_LEVELS * sizeof(int), st));
   PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(fps_nest_verify_kernel));
-  hipLaunchKernelGGL(fps_nest_verify_kernel, dim3(pvn3d_ceil_div(n0, 256), b), dim3(256),
+  hipLaunchKernelGGL(fps_nest_verify_kernel, dim3(pvn3d_ceil_div(n0, 64), b), dim3(1024),
                      (size_t)lv.tmax * sizeof(float4), st, n0, lv, ordered_xyz, dmax, flags);
   PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(fps_nest_finalize_kernel, dim3(pvn3d_ceil_div(b, 64)), dim3(64), 0, st, b, lv, flags);
