@@ -317,6 +317,24 @@ int pvn3d_three_interpolate_grad_det(int b, int c, int n, int m, const float* gr
                                      const int* idx, const float* weight, float* grad_points,
                                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Layer-by-layer SharedMLP for small launches (csrc/small_batch.hip) -------------------------------------
+ * The fused chains (pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp) give a workgroup 64 columns and the whole layer
+ * chain; with one frame per call the deep levels are 8 - 64 workgroups.  Same arithmetic (fp32 MFMA, eval
+ * BatchNorm folded into W', b'), one layer per launch, one wave per 32 x 32 output tile, activations as
+ * point-major fp32 matrices [columns][channels].
+ * pvn3d_sb_linear: C[M][ldc] = act(A[M][K] . W[N][K]^T + bias[N]) (relu != 0: max(.,0)).
+ * pvn3d_sb_gather_sa / _fp: the layer-0 input rows (as pvn3d_mt_gather_*, fp32).  pvn3d_sb_pool_max: max over
+ * the ns rows of every group -> out[g*out_ld + c]. */
+int pvn3d_sb_linear(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, int relu,
+                    float* C, int ldc, void* stream);
+int pvn3d_sb_gather_sa(int b, int n, int m, int ns, int C, int use_xyz, const float* xyz, const float* new_xyz,
+                       const float* feat, long long fsb, long long fsc, long long fsn, const int* idx, float* X0, int ld,
+                       void* stream);
+int pvn3d_sb_gather_fp(int b, int n, int mk, int C2, int C1, const float* known, long long ksb, long long ksc,
+                       long long ksn, const float* unknown, long long usb, long long usc, long long usn, const int* idx,
+                       const float* w, float* X0, int ld, void* stream);
+int pvn3d_sb_pool_max(long long G, int ns, int ld, int C, const float* H, float* out, long long out_ld, void* stream);
+
 /* ---- Training-mode SharedMLP on bf16 MFMA (csrc/mlp_train.hip; BASELINE config 5) ---------------------------
  * Replaces, for a module in training mode, the reference's grouped (B,C,npoint,nsample) tensor -> [Conv2d 1x1 ->
  * BatchNorm2d(batch statistics) -> ReLU] x L -> max_pool2d (pointnet2_modules.py:58-71, 188-206;

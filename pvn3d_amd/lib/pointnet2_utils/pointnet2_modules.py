@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from . import _ext
 from . import _fused_mlp
 from . import _train_mlp
+from . import _small_batch
 from . import pointnet2_utils
 from ..utils import pytorch_utils as pt_utils
 
@@ -179,12 +180,21 @@ class _PointnetSAModuleBase(nn.Module):
             return None                                     # slices would not be contiguous channels
         total = offs[-1]
         out_pm = torch.empty((xyz.size(0), new_xyz.size(1), total), dtype=torch.float32, device=xyz.device)
-        for grouper, packed, idx, off in zip(self.groupers, packs, idxs, offs):
+        for grouper, mlp, packed, idx, off in zip(self.groupers, self.mlps, packs, idxs, offs):
             if idx is None:
                 with _stage("ball_query"):
                     idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
             with _stage("sa_mlp"):
-                _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
+                # few columns (one frame per call, deep level): one launch per layer with one wave per 32 x 32 tile
+                # fills the chip where the fused chain has a handful of 64-column workgroups
+                small = None
+                if xyz.size(0) * new_xyz.size(1) * grouper.nsample < 64 * _small_batch.MAX_FUSED_WGS:
+                    small = _small_batch.folded_layers(mlp)
+                if small is not None:
+                    _small_batch.sa_scale(xyz, new_xyz, features, idx, grouper.use_xyz or features is None, small, out_pm,
+                                          off)
+                else:
+                    _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
         out = out_pm[:, :, :sum(widths)].transpose(1, 2)
         # Stand-alone the module returns what the reference returns: a contiguous (B, C_out, npoint) tensor
         # (a caller may .view() it).  Pointnet2MSG marks its own levels `_point_major_out`: the next fused
@@ -246,6 +256,12 @@ class PointnetFPModule(nn.Module):
                     and _no_grad_needed(unknow_feats, known_feats)
                     and not any(p.requires_grad and torch.is_grad_enabled() for p in self.parameters())):
                 packed = _fused_mlp.pack_shared_mlp(self.mlp)
+                if packed is not None and unknown.size(0) * unknown.size(1) < 64 * _small_batch.MAX_FUSED_WGS:
+                    small = _small_batch.folded_layers(self.mlp)
+                    if small is not None:
+                        with _stage("fp_mlp"):
+                            return _small_batch.fp_module(known_feats, unknow_feats, idx, weight.contiguous(), small,
+                                                          getattr(self, "_point_major_out", False))
                 if packed is not None:
                     with _stage("fp_mlp"):
                         return _ext.fp_interp_mlp(known_feats, unknow_feats, idx, weight.contiguous(), packed,

@@ -763,6 +763,38 @@ def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_small_batch_layerwise_path_matches_fused_chain(dev):
+    """One frame per call: the deep levels run one launch per layer (csrc/small_batch.hip) instead of the fused
+    chain; same fp32-MFMA arithmetic, so the whole Pointnet2MSG forward agrees to fp32 rounding -- with the fused
+    path and with the op-by-op torch composition."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pointnet2_utils import _small_batch, pointnet2_modules as pm
+    torch.manual_seed(6)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    for mod in net.modules():                       # non-trivial eval BatchNorm statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.2, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+    x = synth.synth_frame(frame=95, n_pts=12288, n_obj=3072)
+    pc = torch.from_numpy(np.concatenate([x["pcld"], x["feats"].T], 1)[None]).to(dev)
+    with torch.no_grad():
+        small = net(pc).clone()
+        keep = _small_batch.MAX_FUSED_WGS
+        _small_batch.MAX_FUSED_WGS = 0
+        try:
+            fused = net(pc).clone()
+            pm.FUSED_INFERENCE = False
+            try:
+                ref = net(pc).clone()
+            finally:
+                pm.FUSED_INFERENCE = True
+        finally:
+            _small_batch.MAX_FUSED_WGS = keep
+    scale = float(ref.abs().max())
+    assert float((small - fused).abs().max()) <= 2e-5 * scale
+    assert float((small - ref).abs().max()) <= 2e-4 * scale
+
+
 def test_graphed_forward_replays_the_eager_forward(dev):
     """Pointnet2MSG.graphed: the HIP-graph replay of the eval forward (both streams captured) returns the eager
     forward's bits, also for a second input of the same shape, and refuses another shape."""
