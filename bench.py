@@ -503,6 +503,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream, islands back to back")
+    ap.add_argument("--ms-kernel", default=None,
+                    help="MeanShift iteration kernel for the timed steps, e.g. 'sgpr+cap1024' (LDS-free, 1024 waves); "
+                         "default: the library's choice")
     ap.add_argument("--ops-only", action="store_true",
                     help="island (A) = bare SA/FP op chain with synthetic features (no MLP GEMMs)")
     ap.add_argument("--strong", action="store_true",
@@ -545,6 +548,9 @@ def main():
     # --serial both run back to back on one stream (per-stage event timings are taken in that
     # mode so they do not overlap).
     side = torch.cuda.Stream(device=dev)
+    if args.ms_kernel:
+        from pvn3d_amd.lib.utils import _vote_engine
+        _vote_engine.DEFAULT_KERNEL = args.ms_kernel
 
     def gather_results(res):
         return gather_step_results(res, frames_local, frames_total, world, args.strong)

@@ -235,6 +235,12 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
 #define PVN3D_MS_FORCE_PACKED 8
 #define PVN3D_MS_FORCE_WHOLE 16
 #define PVN3D_MS_FORCE_SPLIT 32
+/* LDS-free iteration kernel (needs PVN3D_MS_ALIGNED32): points are wave-uniform SGPR operands streamed with scalar
+ * loads, one wave per tile of seeds, no barrier -- same bits as the other variants.  It is the form to run BESIDE the
+ * fused-MLP kernels (which keep the LDS pipe busy); PVN3D_MS_WAVE_CAP(n) bounds the launch to n waves that stride
+ * over the work, i.e. chooses how many SIMD wave slots the iterations occupy (0 = one wave per tile). */
+#define PVN3D_MS_SGPR_POINTS 64
+#define PVN3D_MS_WAVE_CAP(n) (((n) & 0xfffff) << 8)
 size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
 int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,
                               int n_seg, int total, int max_cnt_host, float bandwidth,

@@ -49,6 +49,7 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* act_cnt;         // [n_seg]  0: no list (every seed is iterated); k + 1: act_idx holds k seeds
   int* act_form;        // [n_seg]  arithmetic form (1 exact, 2 fast) the list was built for
   int* act_idx;         // [total]  per segment: the seeds that are not fixed points under act_form, ascending
+  float4* apts;         // [total + 32]  scaled+centred points (x', y', z', -|a'|^2) for the LDS-free iteration kernel
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -59,6 +60,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_c0 = take(sizeof(float4) * (size_t)total);
   const size_t o_c1 = take(sizeof(float4) * (size_t)total);
   const size_t o_aidx = take(sizeof(int) * (size_t)total);
+  const size_t o_apts = take(sizeof(float4) * ((size_t)total + 32));
   const size_t o_small = off;  // everything from here is zero-filled per call
   const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_cm = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
@@ -88,6 +90,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->act_cnt = (int*)(base + o_acnt);
     st->act_form = (int*)(base + o_aform);
     st->act_idx = (int*)(base + o_aidx);
+    st->apts = (float4*)(base + o_apts);
   }
   (void)o_small;
   return off;
@@ -400,6 +403,238 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     atomicMax(cmx + t, __float_as_uint(c));
     if (f > 0.f) atomicMax(frozen_cm + seg, __float_as_uint(f));
     atomicMax(iters + seg, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-free form of the iteration (PVN3D_MS_SGPR_POINTS): for running BESIDE the fused-MLP kernels.  Those keep
+// the LDS pipe busy with MFMA fragment reads, and ms_iter_kernel's broadcast ds_read_b128 per point queues behind
+// them (tools/coexec_probe.py: a VALU kernel with one broadcast LDS read per 8 VALU instructions hides 0 % of
+// its time under the MLP forward, the same kernel without the read 78 %).  A point is wave-uniform, so here it is
+// an SGPR operand: ms_prep_kernel writes the scaled, centred records once per call, and a wave streams them
+// with s_load_dwordx16 (4 points each), two 8-point blocks in flight.  One wave = one tile of 128 seeds, no
+// barrier, no LDS; the grid is a fixed number of waves that stride over the (fit, tile) items, so the caller
+// chooses how many SIMD slots the kernel takes (PVN3D_MS_WAVE_CAP).  Same canonical summation order, same bits.
+// The loads are inline asm: SMEM returns out of order, so the only wait is lgkmcnt(0), and it has to stand
+// BEFORE the next block's loads are issued -- the compiler's own placement (at first use) would wait for the
+// prefetch it has just issued.
+// ---------------------------------------------------------------------------------------
+typedef float ms_f16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(MS_THREADS) void ms_prep_kernel(const float4* __restrict__ pts,
+                                                             const int* __restrict__ seg_off,
+                                                             const int* __restrict__ seg_cnt, float kappa,
+                                                             float4* __restrict__ apts) {
+  const int seg = blockIdx.y;
+  const int n = seg_cnt[seg];
+  const int q = blockIdx.x * MS_THREADS + threadIdx.x;
+  if (q >= ((n + 3) & ~3)) return;
+  const int base = seg_off[seg];
+  const float4 org = pts[base];
+  float4 a = make_float4(0.f, -1e30f, 0.f, 0.f);   // padded rows weigh exp2(-huge) == 0 (as in ms_iter_kernel)
+  if (q < n) {
+    const float4 r = pts[base + q];
+    const float ax = (r.x - org.x) * kappa, ay = (r.y - org.y) * kappa, az = (r.z - org.z) * kappa;
+    a = make_float4(ax, -fmaf(az, az, fmaf(ay, ay, ax * ax)), ay, az);   // record = (x', -|a'|^2, y', z')
+  }
+  apts[base + q] = a;
+}
+
+#define MS_SLOAD(d0, d1, ptr)                                                                           \
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(d0), "=&s"(d1) : "s"(ptr))
+#define MS_SWAIT(d0, d1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d0), "+s"(d1))
+
+// Two points (A then B) into the running sums of a lane's two seeds.  A record is two SGPR pairs, (x', -|a'|^2) and
+// (y', z'), so that every packed instruction names ONE pair (the constant bus carries one scalar operand per VALU
+// instruction) and broadcasts the half it needs through op_sel -- the fast form's first FMA takes both of its scalar
+// operands from the same pair.  The statements are volatile so that loads, waits and arithmetic stay in the written
+// order; the two points are interleaved for a lone wave (dependent issue costs 8 cycles, independent 5).
+template <bool FAST>
+__device__ __forceinline__ void ms_acc2(MsAcc& A, ms_f2 xa, ms_f2 ya, ms_f2 xb, ms_f2 yb, ms_f2 p2x, ms_f2 p2y,
+                                        ms_f2 p2z, ms_f2 pcm) {
+  ms_f2 ea, eb;
+  if (FAST)
+    asm volatile(
+        "v_pk_fma_f32 %[ea], %[p2x], %[xa], %[xa] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2x], %[xb], %[xb] op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2y], %[ya], %[ea] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2y], %[yb], %[eb] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2z], %[ya], %[ea] op_sel:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2z], %[yb], %[eb] op_sel:[0,1,0]"
+        : [ea] "=&v"(ea), [eb] "=&v"(eb)
+        : [p2x] "v"(p2x), [p2y] "v"(p2y), [p2z] "v"(p2z), [xa] "s"(xa), [ya] "s"(ya), [xb] "s"(xb), [yb] "s"(yb));
+  else
+    asm volatile(
+        "v_pk_add_f32 %[ea], %[xa], %[pcm] op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[eb], %[xb], %[pcm] op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2x], %[xa], %[ea] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2x], %[xb], %[eb] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2y], %[ya], %[ea] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2y], %[yb], %[eb] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2z], %[ya], %[ea] op_sel:[0,1,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2z], %[yb], %[eb] op_sel:[0,1,0]"
+        : [ea] "=&v"(ea), [eb] "=&v"(eb)
+        : [p2x] "v"(p2x), [p2y] "v"(p2y), [p2z] "v"(p2z), [pcm] "v"(pcm), [xa] "s"(xa), [ya] "s"(ya), [xb] "s"(xb),
+          [yb] "s"(yb));
+  const ms_f2 wa = ms_f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+  const ms_f2 wb = ms_f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+  asm volatile(
+      "s_nop 0\n\t"                                         // v_exp_f32 (trans) -> VALU read of its result
+      "v_pk_add_f32 %[Aw], %[Aw], %[wa]\n\t"
+      "v_pk_fma_f32 %[Ax], %[wa], %[xa], %[Ax] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Ay], %[wa], %[ya], %[Ay] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Az], %[wa], %[ya], %[Az] op_sel:[0,1,0]\n\t"
+      "v_pk_add_f32 %[Aw], %[Aw], %[wb]\n\t"
+      "v_pk_fma_f32 %[Ax], %[wb], %[xb], %[Ax] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Ay], %[wb], %[yb], %[Ay] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Az], %[wb], %[yb], %[Az] op_sel:[0,1,0]"
+      : [Aw] "+v"(A.w), [Ax] "+v"(A.x), [Ay] "+v"(A.y), [Az] "+v"(A.z)
+      : [wa] "v"(wa), [wb] "v"(wb), [xa] "s"(xa), [ya] "s"(ya), [xb] "s"(xb), [yb] "s"(yb));
+}
+
+#define MS_PAIR(b, k) __builtin_shufflevector(b, b, k, (k) + 1)
+template <bool FAST>
+__device__ __forceinline__ void ms_acc4(MsAcc& A, const ms_f16 b, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
+  ms_acc2<FAST>(A, MS_PAIR(b, 0), MS_PAIR(b, 2), MS_PAIR(b, 4), MS_PAIR(b, 6), p2x, p2y, p2z, pcm);
+  ms_acc2<FAST>(A, MS_PAIR(b, 8), MS_PAIR(b, 10), MS_PAIR(b, 12), MS_PAIR(b, 14), p2x, p2y, p2z, pcm);
+}
+
+// One quarter (<= 128 points, a multiple of 4) of the canonical order into A; ap points at its first record.
+// No load is in flight on entry or on exit: between MS_SLOAD and MS_SWAIT the destination registers are
+// undefined as far as the hardware is concerned but live as far as the compiler is, so that window must hold
+// nothing but the statements below (a compiler-generated SGPR spill or copy of a0/a1 there would save stale
+// data -- checked in the ISA: the loop bodies hold no v_writelane/s_mov of the buffers).  The look-ahead of the
+// last full step fetches the next quarter's first block: wasted, but it makes that quarter's first load a
+// scalar-cache hit.
+template <bool FAST>
+__device__ __forceinline__ void ms_sgpr_quarter(MsAcc& A, const float4* ap, int pe, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z,
+                                                ms_f2 pcm) {
+  ms_f16 a0, a1, b0, b1;
+  int left = pe;
+  MS_SLOAD(a0, a1, ap);
+  for (; left >= 16; left -= 16) {
+    MS_SWAIT(a0, a1);
+    MS_SLOAD(b0, b1, ap + 8);
+    ms_acc4<FAST>(A, a0, p2x, p2y, p2z, pcm);
+    ms_acc4<FAST>(A, a1, p2x, p2y, p2z, pcm);
+    MS_SWAIT(b0, b1);
+    MS_SLOAD(a0, a1, ap + 16);
+    ms_acc4<FAST>(A, b0, p2x, p2y, p2z, pcm);
+    ms_acc4<FAST>(A, b1, p2x, p2y, p2z, pcm);
+    ap += 16;
+  }
+  MS_SWAIT(a0, a1);
+  if (left > 0) {                   // the fit's last quarter only: 4, 8 or 12 points
+    ms_acc4<FAST>(A, a0, p2x, p2y, p2z, pcm);
+    if (left >= 8) ms_acc4<FAST>(A, a1, p2x, p2y, p2z, pcm);
+    if (left >= 12) {
+      MS_SLOAD(b0, b1, ap + 8);
+      MS_SWAIT(b0, b1);
+      ms_acc4<FAST>(A, b0, p2x, p2y, p2z, pcm);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void ms_iter_sgpr_kernel(
+    const float4* __restrict__ pts, const float4* __restrict__ apts, const int* __restrict__ seg_off,
+    const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
+    unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
+    int max_iter, float thresh, float kappa, float inv_kappa, unsigned* __restrict__ frozen_cm,
+    const int* __restrict__ act_cnt, const int* __restrict__ act_form, const int* __restrict__ act_idx,
+    int tiles_per_seg, int n_items) {
+  constexpr int S = 2;
+  const int sl = threadIdx.x;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int seg = item / tiles_per_seg;
+    const int tile0 = (item - seg * tiles_per_seg) * (64 * S);
+    const int n = seg_cnt[seg];
+    if (tile0 >= n) continue;
+    unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
+    if (t > 1) {
+      const float prev = __uint_as_float(ms[t - 1]);
+      if (!(prev >= thresh) || (t - 1) > max_iter) continue;
+    }
+    unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
+    const bool fast = t > 1 && fmaxf(__uint_as_float(cmx[t - 1]), __uint_as_float(frozen_cm[seg])) <= 64.f;
+    const int form = fast ? 2 : 1;
+    const int lc = act_cnt[seg];
+    const bool use_list = lc > 0 && act_form[seg] == form;
+    const int n_eff = use_list ? lc - 1 : n;
+    if (tile0 >= n_eff) continue;
+    const int base = __builtin_amdgcn_readfirstlane(seg_off[seg]);
+    float cx[S], cy[S], cz[S];
+    int sid[S];
+    ms_f2 p2x = ms_splat(0.f), p2y = ms_splat(0.f), p2z = ms_splat(0.f), pcm = ms_splat(0.f);
+    const float4* ap = apts + base;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int j = tile0 + s * 64 + sl;
+      const int i = j < n_eff ? (use_list ? act_idx[base + j] : j) : -1;
+      sid[s] = i;
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i >= 0) {
+        if (t == 1) {
+          const float4 org = pts[base];
+          const float4 a = pts[base + i];
+          c = make_float4((a.x - org.x) * kappa, (a.y - org.y) * kappa, (a.z - org.z) * kappa, 0.f);
+        } else {
+          c = cin[base + i];
+        }
+      }
+      cx[s] = c.x; cy[s] = c.y; cz[s] = c.z;
+      p2x[s] = 2.f * c.x; p2y[s] = 2.f * c.y; p2z[s] = 2.f * c.z;
+      pcm[s] = fmaf(c.z, c.z, fmaf(c.y, c.y, c.x * c.x));
+    }
+    // acc[0] always receives the current quarter; the four sums rotate after each one, and once more at the end so
+    // that acc[w] is quarter w's sum again (one copy of the hot loop instead of four)
+    MsAcc acc[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc[w].w = acc[w].x = acc[w].y = acc[w].z = ms_splat(0.f);
+    const int cnt4 = (n + 3) & ~3;
+    int nq = 0;
+    for (int q0 = 0; q0 < cnt4; q0 += MS_QUARTER, ++nq) {
+      const int pe = min(MS_QUARTER, cnt4 - q0);
+      if (fast) ms_sgpr_quarter<true>(acc[0], ap + q0, pe, p2x, p2y, p2z, pcm);
+      else ms_sgpr_quarter<false>(acc[0], ap + q0, pe, p2x, p2y, p2z, pcm);
+      const MsAcc r = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = r;
+    }
+    for (int k = (4 - (nq & 3)) & 3; k > 0; --k) {
+      const MsAcc r = acc[0]; acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = r;
+    }
+    MsAcc tot;
+    tot.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    tot.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+    tot.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    tot.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+    float mshift = 0.f, mcm = 0.f, fcm = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int i = sid[s];
+      if (i >= 0) {
+        const float inv = 1.0f / tot.w[s];
+        const float nx = tot.x[s] * inv, ny = tot.y[s] * inv, nz = tot.z[s] * inv;
+        const float ex = nx - cx[s], ey = ny - cy[s], ez = nz - cz[s];
+        const float sh = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * inv_kappa;
+        mshift = fmaxf(mshift, sh);
+        const float ncm = fmaf(nz, nz, fmaf(ny, ny, nx * nx));
+        mcm = (ncm <= mcm) ? mcm : ((ncm != ncm) ? __builtin_inff() : ncm);
+        const bool fixed = nx == cx[s] && ny == cy[s] && nz == cz[s];
+        cout[base + i] = make_float4(nx, ny, nz, fixed ? (float)form : 0.f);
+        if (fixed) fcm = fmaxf(fcm, ncm);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      mshift = fmaxf(mshift, __shfl_xor(mshift, o, 64));
+      mcm = fmaxf(mcm, __shfl_xor(mcm, o, 64));
+      fcm = fmaxf(fcm, __shfl_xor(fcm, o, 64));
+    }
+    if (sl == 0) {
+      atomicMax(ms + t, __float_as_uint(mshift));
+      atomicMax(cmx + t, __float_as_uint(mcm));
+      if (fcm > 0.f) atomicMax(frozen_cm + seg, __float_as_uint(fcm));
+      atomicMax(iters + seg, t);
+    }
   }
 }
 
@@ -744,6 +979,18 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   if (flags & PVN3D_MS_FORCE_SPLIT) split = true;
   const int tile = (split ? 64 : MS_THREADS) * (packed ? 2 : 1);
   const dim3 grid_it(pvn3d_ceil_div(max_cnt_host, tile), n_seg);
+  // LDS-free iteration kernel (one wave per 64 S seeds, points as SGPR operands)
+  const bool sgpr = (flags & PVN3D_MS_SGPR_POINTS) != 0;
+  if (sgpr && !(flags & PVN3D_MS_ALIGNED32)) return (int)hipErrorInvalidValue;   // it reads rows up to roundup32(cnt)
+  const int sg_tiles = pvn3d_ceil_div(max_cnt_host, 128);   // always two seeds per lane
+  const long long sg_items_ll = (long long)sg_tiles * n_seg;
+  if (sgpr && sg_items_ll > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  const int sg_items = (int)sg_items_ll;
+  const int sg_cap = (flags >> 8) & 0xfffff;                                      // PVN3D_MS_WAVE_CAP(n); 0: no cap
+  const int sg_grid = sg_cap > 0 && sg_cap < sg_items ? sg_cap : sg_items;
+  if (sgpr)
+    hipLaunchKernelGGL(ms_prep_kernel, dim3(pvn3d_ceil_div(max_cnt_host + 3, MS_THREADS), n_seg), dim3(MS_THREADS), 0, st,
+                       P, seg_off, seg_cnt, kappa, S.apts);
   const dim3 grid_1(pvn3d_ceil_div(max_cnt_host, MS_THREADS), n_seg);
 
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -763,9 +1010,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   hipLaunchKernelGGL((ms_iter_kernel<PK_, SP_>), grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout, \
                      S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa, S.frozen_cm, S.act_cnt,   \
                      S.act_form, S.act_idx)
-    if (packed) { if (split) MS_ITER(true, true); else MS_ITER(true, false); }
+#define MS_ITER_SGPR()                                                                                         \
+  hipLaunchKernelGGL(ms_iter_sgpr_kernel, dim3(sg_grid), dim3(64), 0, st, P, S.apts, seg_off, seg_cnt, cin, cout, \
+                     S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa, S.frozen_cm, S.act_cnt,   \
+                     S.act_form, S.act_idx, sg_tiles, sg_items)
+    if (sgpr) MS_ITER_SGPR();
+    else if (packed) { if (split) MS_ITER(true, true); else MS_ITER(true, false); }
     else { if (split) MS_ITER(false, true); else MS_ITER(false, false); }
 #undef MS_ITER
+#undef MS_ITER_SGPR
     if ((rc = (int)hipGetLastError()) != 0) break;
     // from iteration 5 on (the easy fits are done after ~4) the seed lists are rebuilt every fourth iteration:
     // on heavy-tailed votes 85-89 % of the seeds are bitwise fixed points after five iterations

@@ -211,9 +211,11 @@ def test_iteration_kernel_variants_are_bit_identical(dev):
     outs = {}
     # "+noearly": every seed iterated in every iteration; without it seeds that are bitwise fixed points of the
     # iteration function leave the iterated set from iteration 5 on (exact: same bits)
-    kerns = ("scalar+whole+noearly", "packed+whole", "scalar+split", "packed+split", "packed+split+noearly", "scalar+whole")
+    # "sgpr": the LDS-free kernel (points as scalar operands, one wave per 128 seeds), "+cap7": 7 waves stride over the work
+    kerns = ("scalar+whole+noearly", "packed+whole", "scalar+split", "packed+split", "packed+split+noearly", "scalar+whole",
+             "sgpr", "sgpr+noearly", "sgpr+cap7")
     for kern in kerns:
-        c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern)
+        c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern, aligned32=True)
         l = l.cpu().numpy()
         valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)])     # rows past a segment's count are scratch
         outs[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
