@@ -2,7 +2,7 @@
 // Two synthetic kernels, one wave per SIMD each (256 workgroups x 256 threads), launched on two streams:
 //   M: fp32 MFMA only (v_mfma_f32_32x32x2_f32, four independent accumulators), V: fp32 VALU only (fma + exp),
 //   B: bf16 MFMA only (v_mfma_f32_32x32x16_bf16).
-// Build: hipcc --offload-arch=gfx950 -O3 tools/coissue_bench.hip -o /tmp/coissue_bench
+// Build: hipcc --offload-arch=gfx950 -O3 tools/coissue_bench.hip -o tools/coissue_bench.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <algorithm>
