@@ -365,6 +365,15 @@ int pvn3d_mt_pack_weight(int rows, int cols, const float* W, int lds, int transp
                          void* stream);
 int pvn3d_mt_unpack_cm(int b, int R, int ld, int c_off, int C, const void* X, float* out, void* stream);
 int pvn3d_mt_pack_cm(int b, int R, int ld, int C, const float* in, void* X, void* stream);
+/* Backward of the layer-0 gathers without atomics on the data (the reference scatters with atomicAdd,
+ * group_points_gpu.cu:49-75, interpolate_gpu.cu:137-170).  pvn3d_mt_csr_build inverts an index list once per call:
+ * idx [b][E] with values in [0, n_src) (n_src <= 32768) -> start [b][n_src + 1], ent [b][E] (entry ids grouped by the
+ * row they reference).  pvn3d_mt_inv_gather: out[(b * n_src + p) * out_ld + c] (+)= sum over the entries e of row p of
+ * w[b][e] * dX[(b * E/div + e/div) * ld + c_off + c] for c < C <= 512 (bf16 dX, fp32 point-major out; wider tensors
+ * in channel blocks; w may be NULL = 1; div = 1 for set abstraction, 3 for three_interpolate; accumulate != 0 adds). */
+int pvn3d_mt_csr_build(int b, int n_src, int E, const int* idx, int* start, int* ent, void* stream);
+int pvn3d_mt_inv_gather(int b, int n_src, int E, int div, int C, int c_off, int ld, const void* dX, const int* start,
+                        const int* ent, const float* w, float* out, int out_ld, int accumulate, void* stream);
 /* Layer-0 inputs.  SA: X0[(b*m+j)*ns+s][c] = relative xyz (c < 3 when use_xyz) ++ feat[b, c, idx[b,j,s]]
  * (QueryAndGroup, pointnet2_utils.py:293-330); FP: X0[b*n+i][c] = three_interpolate(known)[c < C2] ++ unknown
  * (pointnet2_modules.py:188-203).  feat / known / unknown: fp32, element (b,c,n) at base + b*sb + c*sc + n*sn. */

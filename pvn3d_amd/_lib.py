@@ -68,6 +68,8 @@ SIGNATURES = {
     "pvn3d_mt_pack_weight": (_i, [_i, _i, _p, _i, _i, _p, _i, _i, _p]),
     "pvn3d_mt_gather_sa": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _ll, _ll, _ll, _p, _p, _i, _p]),
     "pvn3d_mt_unpack_cm": (_i, [_i, _i, _i, _i, _i, _p, _p, _p]),
+    "pvn3d_mt_csr_build": (_i, [_i, _i, _i, _p, _p, _p, _p]),
+    "pvn3d_mt_inv_gather": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_mt_pack_cm": (_i, [_i, _i, _i, _i, _p, _p, _p]),
     "pvn3d_mt_gather_fp": (_i, [_i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _p, _ll, _ll, _ll, _p, _p, _p, _i, _p]),
     "pvn3d_mt_bn_finalize": (_i, [_i, _i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),

@@ -362,6 +362,121 @@ __global__ void mt_gather_fp_kernel(int b, int n, int mk, int C2, int C1, const 
   *reinterpret_cast<uint4*>(X0 + row * ld + c0) = pack8(v);
 }
 
+// ---- backward of the layer-0 gathers, as gathers -------------------------------------------------------------
+// The gradient of a gather is a scatter-add: dfeat[b, idx[b,e]] += dX0[row(e)].  Done with atomics it costs more
+// than the GEMMs (round 3: 3.7 ms of a 26 ms step through the row-owner LDS-atomic kernels, 20 ms through global
+// atomics).  The index lists are fixed per call, so they are inverted once (mt_csr_build: per cloud a counting sort of
+// the entries by source row, in LDS) and the scatter becomes a gather again: one lane group per source row walks its
+// list and sums contiguous bf16 row slices of dX0 (mt_inv_gather) -- no atomics on the data, point-major fp32 out.
+// mt_csr_build: one workgroup per cloud; idx [b][E] in [0, n_src); start [b][n_src + 1]; ent [b][E] = the entry ids
+// grouped by source row (order inside a group unspecified).
+__global__ __launch_bounds__(1024) void mt_csr_build_kernel(int n_src, int E, const int* __restrict__ idx,
+                                                           int* __restrict__ start, int* __restrict__ ent) {
+  extern __shared__ int s_bin[];          // [n_src]: counts, then write cursors
+  __shared__ int s_wsum[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int* ib = idx + (size_t)b * E;
+  for (int i = tid; i < n_src; i += 1024) s_bin[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 1024) {
+    const int k = ib[e];
+    if ((unsigned)k < (unsigned)n_src) atomicAdd(&s_bin[k], 1);
+  }
+  __syncthreads();
+  const int per = (n_src + 1023) / 1024;
+  const int lo = min(tid * per, n_src), hi = min(lo + per, n_src);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += s_bin[i];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) s_wsum[wave] = inc;
+  __syncthreads();
+  int run = inc - sum;
+  for (int w = 0; w < wave; ++w) run += s_wsum[w];
+  int* sb = start + (size_t)b * (n_src + 1);
+  for (int i = lo; i < hi; ++i) {
+    const int c = s_bin[i];
+    s_bin[i] = run;
+    sb[i] = run;
+    run += c;
+  }
+  if (tid == 1023) sb[n_src] = run;
+  __syncthreads();
+  int* eb = ent + (size_t)b * E;
+  for (int e = tid; e < E; e += 1024) {
+    const int k = ib[e];
+    if ((unsigned)k < (unsigned)n_src) eb[atomicAdd(&s_bin[k], 1)] = e;
+  }
+}
+
+// out[(b * n_src + p) * out_ld + c] (+)= sum over the entries e of source row p of
+// w[b][e] * dX[(b * (E / div) + e / div) * ld + c_off + c], c < C.  div = 1: SA (one dX0 row per entry), div = 3: FP
+// (three weighted entries per dX0 row).  One wave per source row: LPP = 1 << lpp_shift lanes span the channels (lane
+// l sums channels l, l + LPP, ...: contiguous 2-byte loads across the lanes) and the 64 / LPP lane groups take
+// every (64 / LPP)-th entry of the list -- ball query pads a short neighbourhood with its first hit, so a few rows
+// own lists hundreds of entries long, and those set the launch time when one lane group walks a list alone.
+template <bool HAS_W>
+__global__ __launch_bounds__(256) void mt_inv_gather_kernel(int n_src, int E, int div, int C, int c_off, int ld,
+                                                            const bf16_t* __restrict__ dX, const int* __restrict__ start,
+                                                            const int* __restrict__ ent, const float* __restrict__ w,
+                                                            float* __restrict__ out, int out_ld, int accumulate,
+                                                            int lpp_shift) {
+  const int b = blockIdx.y;
+  const int lpp = 1 << lpp_shift;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);                  // source row of this wave
+  if (row >= n_src) return;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (lpp - 1), slot = lane >> lpp_shift, nslot = 64 >> lpp_shift;
+  const int* sb = start + (size_t)b * (n_src + 1);
+  const int j0 = sb[row], j1 = sb[row + 1];
+  const int* eb = ent + (size_t)b * E;
+  const float* wb = HAS_W ? w + (size_t)b * E : nullptr;
+  const bf16_t* base = dX + (size_t)b * (E / div) * ld + c_off + gl;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int j = j0 + slot;
+  for (; j + nslot < j1; j += 2 * nslot) {                              // two entries in flight per lane group
+    const int e0 = eb[j], e1 = eb[j + nslot];
+    const float w0 = HAS_W ? wb[e0] : 1.f, w1 = HAS_W ? wb[e1] : 1.f;
+    const bf16_t* r0 = base + (size_t)(e0 / div) * ld;
+    const bf16_t* r1 = base + (size_t)(e1 / div) * ld;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool on = gl + (k << lpp_shift) < C;
+      v0[k] = on ? bf2f(r0[k << lpp_shift]) : 0.f;
+      v1[k] = on ? bf2f(r1[k << lpp_shift]) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w1, v1[k], fmaf(w0, v0[k], acc[k]));
+  }
+  if (j < j1) {
+    const int e0 = eb[j];
+    const float w0 = HAS_W ? wb[e0] : 1.f;
+    const bf16_t* r0 = base + (size_t)(e0 / div) * ld;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (gl + (k << lpp_shift) < C) acc[k] = fmaf(w0, bf2f(r0[k << lpp_shift]), acc[k]);
+  }
+  for (int o = lpp; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+  }
+  if (slot == 0) {
+    float* op = out + ((size_t)b * n_src + row) * out_ld + gl;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = gl + (k << lpp_shift);
+      if (c < C) op[k << lpp_shift] = accumulate ? op[k << lpp_shift] + acc[k] : acc[k];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // partial [P][ld] x 2 -> per-channel mean, 1/std, folded scale a = gamma/std and shift b = beta - mean*a (zero in
 // the pad channels), running statistics (momentum update, unbiased variance) like nn.BatchNorm2d in training mode.
@@ -698,6 +813,34 @@ extern "C" int pvn3d_mt_unpack_cm(int b, int R, int ld, int c_off, int C, const 
   if (c_off < 0 || c_off + C > ld) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mt_unpack_cm_kernel, dim3(pvn3d_ceil_div(R, 64), pvn3d_ceil_div(C, 64), b), dim3(256), 0, MT_ST, R,
                      ld, c_off, C, (const bf16_t*)X, out);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_csr_build(int b, int n_src, int E, const int* idx, int* start, int* ent, void* stream) {
+  if (b <= 0 || n_src <= 0) return 0;
+  if (E < 0 || n_src > 32768) return (int)hipErrorInvalidValue;          // the bins live in LDS
+  auto k = mt_csr_build_kernel;
+  PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(k));
+  hipLaunchKernelGGL(k, dim3(b), dim3(1024), (size_t)n_src * sizeof(int), MT_ST, n_src, E, idx, start, ent);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_inv_gather(int b, int n_src, int E, int div, int C, int c_off, int ld, const void* dX,
+                                   const int* start, const int* ent, const float* w, float* out, int out_ld,
+                                   int accumulate, void* stream) {
+  if (b <= 0 || n_src <= 0 || C <= 0) return 0;
+  if (div <= 0 || E % div || C > 512 || c_off < 0 || c_off + C > ld || out_ld < C) return (int)hipErrorInvalidValue;
+  int shift = 3;                                                         // 8 .. 64 lanes across the channels
+  while (shift < 6 && (8 << shift) < C) ++shift;
+  const dim3 grid(pvn3d_ceil_div(n_src, 4), b);
+  if (w)
+    hipLaunchKernelGGL(mt_inv_gather_kernel<true>, grid, dim3(256), 0, MT_ST, n_src, E, div, C, c_off, ld,
+                       (const bf16_t*)dX, start, ent, w, out, out_ld, accumulate, shift);
+  else
+    hipLaunchKernelGGL(mt_inv_gather_kernel<false>, grid, dim3(256), 0, MT_ST, n_src, E, div, C, c_off, ld,
+                       (const bf16_t*)dX, start, ent, w, out, out_ld, accumulate, shift);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

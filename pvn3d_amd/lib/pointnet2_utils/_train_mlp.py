@@ -153,6 +153,25 @@ class _Chain(object):
         return dh, dws, dgs, dbs
 
 
+# Backward of the layer-0 gathers through inverted index lists (csrc/mlp_train.hip mt_csr_build / mt_inv_gather)
+# instead of the atomic scatter kernels; False restores mt_unpack_cm + group_points_grad / three_interpolate_grad.
+INVERSE_GATHER = True
+
+
+def _inv_gather(dx0, B, n_src, idx, div, C, c_off, w, out, accumulate, st):
+    """out (B, n_src, C) fp32 (+)= scatter-add of dx0's channels [c_off, c_off + C) along idx, as a gather."""
+    dev = dx0.device
+    E = idx.numel() // B
+    start = torch.empty((B, n_src + 1), dtype=torch.int32, device=dev)
+    ent = torch.empty((B, E), dtype=torch.int32, device=dev)
+    check(lib.pvn3d_mt_csr_build(B, n_src, E, idx.data_ptr(), start.data_ptr(), ent.data_ptr(), st), "mt_csr_build")
+    for c0 in range(0, C, 512):             # channel blocks of <= 512
+        cb = min(512, C - c0)
+        check(lib.pvn3d_mt_inv_gather(B, n_src, E, div, cb, c_off + c0, dx0.size(1), dx0.data_ptr(), start.data_ptr(),
+                                      ent.data_ptr(), w.data_ptr() if w is not None else None,
+                                      out.data_ptr() + 4 * c0, C, 1 if accumulate else 0, st), "mt_inv_gather")
+
+
 def _flat_params(layer_lists):
     """[[(conv, bn)]] -> flat tensor list (conv.weight, bn.weight, bn.bias per layer) for autograd."""
     flat = []
@@ -215,6 +234,7 @@ class SALevelTrain(torch.autograd.Function):
         fshape, fneeds = ctx.feat_meta
         dfeat = None
         grads = []
+        point_major = fneeds and INVERSE_GATHER and N <= 32768
         with on_device(dev):
             st = _stream(gout)
             for ch, (arg, idx, use_xyz, ns, width, off) in zip(ctx.chains, ctx.args):
@@ -223,7 +243,13 @@ class SALevelTrain(torch.autograd.Function):
                 check(lib.pvn3d_mt_pool_bwd(B * m, ns, ldw, width, gout.data_ptr() + 4 * off, total, arg.data_ptr(),
                                             dh.data_ptr(), st), "mt_pool_bwd")
                 dx0, dws, dgs, dbs = ch.backward(dh, fneeds)
-                if fneeds:
+                if point_major:
+                    # point-major (B, N, C) gradient, handed back as the transposed view the previous level produced
+                    first = dfeat is None
+                    if first:
+                        dfeat = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+                    _inv_gather(dx0, B, N, idx, 1, C, 3 if use_xyz else 0, None, dfeat, not first, st)
+                elif fneeds:
                     # feature channels of dX0 as (B, C, npoint, nsample) fp32 -> the row-owner scatter of group_points_grad
                     gcm = torch.empty((B, C, m, ns), dtype=torch.float32, device=dev)
                     check(lib.pvn3d_mt_unpack_cm(B, m * ns, dx0.size(1), 3 if use_xyz else 0, C, dx0.data_ptr(),
@@ -233,6 +259,8 @@ class SALevelTrain(torch.autograd.Function):
                 for li, dw in enumerate(dws):
                     grads += [dw.view(dw.size(0), dw.size(1), 1, 1), dgs[li], dbs[li]]
         ctx.chains = None
+        if dfeat is not None and point_major:
+            dfeat = dfeat.transpose(1, 2)          # (B, C, N) view of the point-major buffer
         return (None, None, dfeat, None) + tuple(grads)
 
 
@@ -294,7 +322,11 @@ class FPTrain(torch.autograd.Function):
                       "mt_pack_grad")
             dx0, dws, dgs, dbs = ch.backward(dh, need_u or need_k)
             dk = du = None
-            if need_k:
+            if need_k and INVERSE_GATHER and mk <= 32768:
+                dk = torch.empty((B, mk, C2), dtype=torch.float32, device=dev)
+                _inv_gather(dx0, B, mk, idx, 3, C2, 0, weight, dk, False, st)
+                dk = dk.transpose(1, 2)
+            elif need_k:
                 gk = torch.empty((B, C2, n), dtype=torch.float32, device=dev)
                 check(lib.pvn3d_mt_unpack_cm(B, n, dx0.size(1), 0, C2, dx0.data_ptr(), gk.data_ptr(), st), "mt_unpack_cm")
                 dk = _ext.three_interpolate_grad(gk, idx, weight, mk)

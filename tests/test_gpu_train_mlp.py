@@ -39,6 +39,42 @@ def test_gemm_nt_matches_torch(dev, M, N, K):
     assert _rel(Cf, want) < 1e-5
 
 
+@pytest.mark.parametrize("n_src,E,div,C,c_off", [(300, 4000, 1, 6, 3), (2048, 32768, 1, 96, 3), (512, 2048, 1, 512, 3),
+                                                  (128, 3 * 700, 3, 1024, 0), (1, 64, 1, 40, 0), (77, 3 * 33, 3, 130, 0)])
+def test_inverse_gather_is_the_scatter_add(dev, n_src, E, div, C, c_off):
+    """mt_csr_build + mt_inv_gather (the backward of the layer-0 gathers, done as a gather over inverted index lists)
+    against torch index_add_ in fp64: heavy-hitter rows (ball query pads with the first hit), rows nobody references,
+    channel blocks beyond 512, the xyz channel offset, weighted three-neighbour entries, accumulate."""
+    from pvn3d_amd.lib.pointnet2_utils import _train_mlp as tm
+    B = 3
+    g = torch.Generator(device="cpu").manual_seed(n_src + E + C)
+    idx = torch.randint(0, n_src, (B, E), generator=g, dtype=torch.int32)
+    idx[:, : E // 3] = idx[:, :1]                          # one row owns a third of the list
+    if n_src > 2:
+        idx[idx == 1] = 0                                  # row 1 is referenced by nobody
+    ld = (c_off + C + 15) // 16 * 16
+    rows = E // div
+    dx = torch.randn(B * rows, ld, generator=g).to(torch.bfloat16)
+    w = torch.rand(B, E, generator=g) if div == 3 else None
+    out = torch.full((B, n_src, C), 5.0, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    idx_d, dx_d = idx.to(dev), dx.to(dev)
+    w_d = w.to(dev) if w is not None else None
+    tm._inv_gather(dx_d, B, n_src, idx_d, div, C, c_off, w_d, out, False, st)
+    want = torch.zeros((B, n_src, C), dtype=torch.float64)
+    src = dx.double().view(B, rows, ld)[:, :, c_off:c_off + C]
+    for b in range(B):
+        vals = src[b][torch.arange(E) // div]
+        if w is not None:
+            vals = vals * w[b].double()[:, None]
+        want[b].index_add_(0, idx[b].long(), vals)
+    got = out.cpu().double()
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert float(got[:, 1].abs().max()) == 0.0 if n_src > 2 else True
+    tm._inv_gather(dx_d, B, n_src, idx_d, div, C, c_off, w_d, out, True, st)        # accumulate
+    assert float((out.cpu().double() - 2 * want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def _grads(mod, inputs, out):
     g = torch.randn_like(out) if not hasattr(_grads, "g") else None
     return g
