@@ -386,9 +386,12 @@ int pvn3d_mt_gather_fp(int b, int n, int mk, int C2, int C1, const float* known,
 /* BatchNorm2d in training mode.  finalize: partial sums [P][ld] -> mean, 1/std, a = gamma/std, b = beta - mean*a
  * (zero in pad channels), running_mean / running_var updated with `momentum` (unbiased variance) when given.
  * relu_apply: H = relu(a y + b).  pool_max: max over the ns rows of every group -> out[g*out_ld + c] fp32 and the
- * arg-index (first maximum), pool_bwd its backward.  bwd_reduce: partial sums of dz = dH.[H>0] and dz.yhat over
- * pvn3d_mt_bn_bwd_partials(rows) row blocks; bwd_finalize: dgamma, dbeta and the affine form of the backward
- * dY = a.dz + k1.y + k0; bwd_apply applies it. */
+ * arg-index (first maximum), pool_bwd its backward; bn_relu_pool = relu_apply + pool_max straight from Y (the last
+ * layer of a set-abstraction chain: its post-ReLU matrix is never written).  bwd_reduce: partial sums of
+ * dz = dH.[H>0] and dz.yhat over pvn3d_mt_bn_bwd_partials(rows) row blocks -- the mask is recomputed from y
+ * (H = bf16(relu(a y + b))), so H is not read; bwd_finalize: dgamma, dbeta and the affine form of the backward
+ * dY = a.dz + k1.y + k0; bwd_apply applies it.  The *_pooled forms do both for a layer whose dH is a max-pool
+ * backward (one nonzero per group and channel, taken from dpool / arg; P = pvn3d_mt_bn_bwd_partials(G)). */
 int pvn3d_mt_bn_finalize(int P, int ld, int C, double count, const float* psum, const float* psq, const float* gamma,
                          const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* mean,
                          float* invstd, float* a, float* b, void* stream);
@@ -400,12 +403,20 @@ int pvn3d_mt_pool_bwd(long long G, int ns, int ld, int C, const float* dout, lon
 int pvn3d_mt_pack_grad(long long rows, int ld, int C, const float* g, long long gld, void* dH, void* stream);
 int pvn3d_mt_unpack_out(long long rows, int ld, int C, const void* H, float* out, long long out_ld, void* stream);
 int pvn3d_mt_bn_bwd_partials(long long rows);
-int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* H, const void* Y, const float* mean,
-                           const float* invstd, float* p1, float* p2, void* stream);
+int pvn3d_mt_bn_relu_pool(long long G, int ns, int ld, int C, const void* Y, const float* a, const float* b, float* out,
+                          long long out_ld, void* arg, void* stream);
+int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* Y, const float* a, const float* b,
+                           const float* mean, const float* invstd, float* p1, float* p2, void* stream);
+int pvn3d_mt_bn_bwd_reduce_pooled(long long G, int ns, int ld, int C, const float* dout, long long out_ld, const void* arg,
+                                  const void* Y, const float* a, const float* b, const float* mean, const float* invstd,
+                                  float* p1, float* p2, void* stream);
+int pvn3d_mt_bn_bwd_apply_pooled(long long G, int ns, int ld, int C, const float* dout, long long out_ld, const void* arg,
+                                 const void* Y, const float* a, const float* b, const float* k1, const float* k0,
+                                 void* dY, void* stream);
 int pvn3d_mt_bn_bwd_finalize(int P, int ld, int C, double count, const float* p1, const float* p2, const float* mean,
                              const float* invstd, const float* a, float* dgamma, float* dbeta, float* k1, float* k0,
                              void* stream);
-int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* H, const void* Y, const float* a,
+int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* Y, const float* a, const float* b,
                           const float* k1, const float* k0, void* dY, void* stream);
 
 #ifdef __cplusplus

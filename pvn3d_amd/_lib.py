@@ -79,7 +79,10 @@ SIGNATURES = {
     "pvn3d_mt_pack_grad": (_i, [_ll, _i, _i, _p, _ll, _p, _p]),
     "pvn3d_mt_unpack_out": (_i, [_ll, _i, _i, _p, _p, _ll, _p]),
     "pvn3d_mt_bn_bwd_partials": (_i, [_ll]),
-    "pvn3d_mt_bn_bwd_reduce": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_bwd_reduce": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_relu_pool": (_i, [_ll, _i, _i, _i, _p, _p, _p, _p, _ll, _p, _p]),
+    "pvn3d_mt_bn_bwd_reduce_pooled": (_i, [_ll, _i, _i, _i, _p, _ll, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_mt_bn_bwd_apply_pooled": (_i, [_ll, _i, _i, _i, _p, _ll, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pvn3d_mt_bn_bwd_finalize": (_i, [_i, _i, _i, _d, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pvn3d_mt_bn_bwd_apply": (_i, [_ll, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
 }

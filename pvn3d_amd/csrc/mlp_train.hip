@@ -522,6 +522,27 @@ __global__ __launch_bounds__(1024) void mt_bn_finalize_kernel(int P, int ld, int
   }
 }
 
+// H > 0 without reading H: H = bf16(relu(a y + b)) (mt_bn_relu_apply), so the mask is recomputed from y -- the
+// backward passes stream two matrices instead of three
+// (a positive fp32 a y + b rounds to a positive bf16 unless it is a subnormal below 2^-134, where the derivative of
+// the ReLU is 1 anyway)
+__device__ __forceinline__ bool relu_on(float a, float y, float b) { return fmaf(a, y, b) > 0.f; }
+// thread index -> (row, 8-channel chunk) and row -> (group, sample) in 32-bit arithmetic (the entry points refuse
+// launches beyond 2^31 chunks; a 64-bit division costs more than the rest of these kernels)
+__device__ __forceinline__ void split_idx(long long t, int cpr, long long& row, int& c0) {
+  const unsigned u = (unsigned)t, r = u / (unsigned)cpr;
+  row = r;
+  c0 = (int)(u - r * (unsigned)cpr) * 8;
+}
+__device__ __forceinline__ void split_row(long long row, int ns, long long& g, int& s) {
+  const unsigned u = (unsigned)row, q = u / (unsigned)ns;
+  g = q;
+  s = (int)(u - q * (unsigned)ns);
+}
+__device__ __forceinline__ void load8f(const float* __restrict__ p, float (&v)[8]) {
+  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+}
 // H = relu(a y + b), 8 channels per thread
 __global__ void mt_bn_relu_apply_kernel(long long rows, int ld, const bf16_t* __restrict__ Y,
                                         const float* __restrict__ a, const float* __restrict__ b,
@@ -529,7 +550,9 @@ __global__ void mt_bn_relu_apply_kernel(long long rows, int ld, const bf16_t* __
   const int cpr = ld >> 3;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cpr) return;
-  const int c0 = (int)(t % cpr) * 8;
+  long long row_;
+  int c0;
+  split_idx(t, cpr, row_, c0);
   float y[8];
   unpack8(*reinterpret_cast<const uint4*>(Y + t * 8), y);
   const float4 a0 = *reinterpret_cast<const float4*>(a + c0), a1 = *reinterpret_cast<const float4*>(a + c0 + 4);
@@ -617,8 +640,8 @@ __global__ void mt_unpack_out_kernel(long long rows, int ld, int C, const bf16_t
 // x (row lanes); each block covers `rows_per_block` rows and writes one partial row.
 __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, int ld, int rows_per_block,
                                                                const bf16_t* __restrict__ dH,
-                                                               const bf16_t* __restrict__ H,
                                                                const bf16_t* __restrict__ Y,
+                                                               const float* __restrict__ av, const float* __restrict__ bv,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                float* __restrict__ p1, float* __restrict__ p2) {
@@ -631,45 +654,42 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
   if (rlane < rl) {
-    float mu[8], is[8];
+    float mu[8], is[8], aa[8], bb[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; }
+    for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; aa[i] = av[c0 + i]; bb[i] = bv[c0 + i]; }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    // four rows in flight per thread (twelve 16-byte loads): one row at a time is latency-bound at a third of the
+    // four rows in flight per thread (eight 16-byte loads): one row at a time is latency-bound at a third of the
     // HBM rate
     long long r = r0 + rlane;
     for (; r + 3LL * rl < r1; r += 4LL * rl) {
-      uint4 vg[4], vh[4], vy[4];
+      uint4 vg[4], vy[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long o = (r + (long long)u * rl) * ld + c0;
         vg[u] = *reinterpret_cast<const uint4*>(dH + o);
-        vh[u] = *reinterpret_cast<const uint4*>(H + o);
         vy[u] = *reinterpret_cast<const uint4*>(Y + o);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float g[8], h[8], y[8];
+        float g[8], y[8];
         unpack8(vg[u], g);
-        unpack8(vh[u], h);
         unpack8(vy[u], y);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float dz = h[i] > 0.f ? g[i] : 0.f;
+          const float dz = relu_on(aa[i], y[i], bb[i]) ? g[i] : 0.f;
           s1[i] += dz;
           s2[i] += dz * ((y[i] - mu[i]) * is[i]);
         }
       }
     }
     for (; r < r1; r += rl) {
-      float g[8], h[8], y[8];
+      float g[8], y[8];
       unpack8(*reinterpret_cast<const uint4*>(dH + r * ld + c0), g);
-      unpack8(*reinterpret_cast<const uint4*>(H + r * ld + c0), h);
       unpack8(*reinterpret_cast<const uint4*>(Y + r * ld + c0), y);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float dz = h[i] > 0.f ? g[i] : 0.f;
+        const float dz = relu_on(aa[i], y[i], bb[i]) ? g[i] : 0.f;
         s1[i] += dz;
         s2[i] += dz * ((y[i] - mu[i]) * is[i]);
       }
@@ -686,6 +706,136 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
     for (int r = 0; r < rl; ++r) { a += s_red[(0 * rl + r) * ld + c]; b += s_red[(1 * rl + r) * ld + c]; }
     p1[(size_t)blockIdx.x * ld + c] = a;
     p2[(size_t)blockIdx.x * ld + c] = b;
+  }
+}
+
+// The same partial sums for the LAST layer of a set-abstraction chain, whose dH is the max-pool backward: one
+// nonzero per (group, channel), at row g*ns + arg[g][c], of value bf16(dpool[g][c]).  Reads the pooled gradient,
+// the arg indices and one y per (group, channel) instead of two dense (rows x ld) matrices (and the dense dH is never
+// written).  Block = (ld/8 channel chunks) x (group lanes); a block covers `groups_per_block` groups.
+__global__ __launch_bounds__(256) void mt_bn_bwd_reduce_pooled_kernel(long long G, int ns, int ld, int C,
+                                                                      int groups_per_block, const float* __restrict__ dout,
+                                                                      long long out_ld, const unsigned char* __restrict__ arg,
+                                                                      const bf16_t* __restrict__ Y,
+                                                                      const float* __restrict__ av, const float* __restrict__ bv,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      float* __restrict__ p1, float* __restrict__ p2) {
+  extern __shared__ float s_red[];          // [2][rl][ld]
+  const int cpr = ld >> 3;
+  const int rl = 256 / cpr;
+  const int chunk = threadIdx.x % cpr, rlane = threadIdx.x / cpr;
+  const int c0 = chunk * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  if (rlane < rl) {
+    float mu[8], is[8], aa[8], bb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; aa[i] = av[c0 + i]; bb[i] = bv[c0 + i]; }
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    const long long g1 = min(G, g0 + groups_per_block);
+    for (long long g = g0 + rlane; g < g1; g += rl) {
+      const uint2 ar = *reinterpret_cast<const uint2*>(arg + g * ld + c0);
+      float d[8];
+      bf16_t yv[8];
+      if (c0 + 8 <= C && (out_ld & 3) == 0) {
+        const float4 d0 = *reinterpret_cast<const float4*>(dout + g * out_ld + c0);
+        const float4 d1 = *reinterpret_cast<const float4*>(dout + g * out_ld + c0 + 4);
+        d[0] = d0.x; d[1] = d0.y; d[2] = d0.z; d[3] = d0.w; d[4] = d1.x; d[5] = d1.y; d[6] = d1.z; d[7] = d1.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = c0 + i < C ? dout[g * out_ld + c0 + i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {           // all eight (in-bounds: the pad channels' arg is 0) requested together
+        const int sidx = (int)(((i < 4 ? ar.x : ar.y) >> (8 * (i & 3))) & 0xff);
+        yv[i] = Y[(g * ns + sidx) * ld + c0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float y = bf2f(yv[i]);
+        const float dz = (c0 + i < C && relu_on(aa[i], y, bb[i])) ? bf2f(f2bf(d[i])) : 0.f;
+        s1[i] += dz;
+        s2[i] += dz * ((y - mu[i]) * is[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s_red[(0 * rl + rlane) * ld + c0 + i] = s1[i];
+      s_red[(1 * rl + rlane) * ld + c0 + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rl; ++r) { a += s_red[(0 * rl + r) * ld + c]; b += s_red[(1 * rl + r) * ld + c]; }
+    p1[(size_t)blockIdx.x * ld + c] = a;
+    p2[(size_t)blockIdx.x * ld + c] = b;
+  }
+}
+
+// dY = a.dz + k1.y + k0 for that layer: dz = (s == arg[g][c] and H > 0) ? bf16(dpool[g][c]) : 0
+__global__ void mt_bn_bwd_apply_pooled_kernel(long long G, int ns, int ld, int C, const float* __restrict__ dout,
+                                              long long out_ld, const unsigned char* __restrict__ arg,
+                                              const bf16_t* __restrict__ Y, const float* __restrict__ a,
+                                              const float* __restrict__ b, const float* __restrict__ k1,
+                                              const float* __restrict__ k0, bf16_t* __restrict__ dY) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * ns * cpr) return;
+  long long row, g;
+  int c0, s;
+  split_idx(t, cpr, row, c0);
+  split_row(row, ns, g, s);
+  const uint2 ar = *reinterpret_cast<const uint2*>(arg + g * ld + c0);
+  float y[8], o[8], d[8], av[8], bv[8], k1v[8], k0v[8];
+  unpack8(*reinterpret_cast<const uint4*>(Y + t * 8), y);
+  load8f(a + c0, av); load8f(b + c0, bv); load8f(k1 + c0, k1v); load8f(k0 + c0, k0v);
+  // everything is read unconditionally, up front: a guarded load is a round trip of its own
+  if (c0 + 8 <= C && (out_ld & 3) == 0) {
+    load8f(dout + g * out_ld + c0, d);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = c0 + i < C ? dout[g * out_ld + c0 + i] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sidx = (int)(((i < 4 ? ar.x : ar.y) >> (8 * (i & 3))) & 0xff);
+    const bool on = (c0 + i < C) & (sidx == s) & relu_on(av[i], y[i], bv[i]);
+    const float dz = on ? bf2f(f2bf(d[i])) : 0.f;
+    o[i] = fmaf(av[i], dz, fmaf(k1v[i], y[i], k0v[i]));
+  }
+  *reinterpret_cast<uint4*>(dY + t * 8) = pack8(o);
+}
+
+// last layer forward: out[g][c] = max over the ns rows of bf16(relu(a y + b)) and its arg index, straight from Y
+// (the post-ReLU matrix of that layer is never written: nothing else reads it)
+__global__ void mt_bn_relu_pool_kernel(long long G, int ns, int ld, int C, const bf16_t* __restrict__ Y,
+                                       const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                       long long out_ld, unsigned char* __restrict__ arg) {
+  const int cpr = ld >> 3;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * cpr) return;
+  const long long g = t / cpr;
+  const int c0 = (int)(t % cpr) * 8;
+  float aa[8], bb[8], best[8];
+  int bi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { aa[i] = a[c0 + i]; bb[i] = b[c0 + i]; best[i] = -__builtin_inff(); bi[i] = 0; }
+  for (int s = 0; s < ns; ++s) {
+    float y[8];
+    unpack8(*reinterpret_cast<const uint4*>(Y + (g * ns + s) * ld + c0), y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float h = bf2f(f2bf(fmaxf(fmaf(aa[i], y[i], bb[i]), 0.f)));
+      if (h > best[i]) { best[i] = h; bi[i] = s; }             // first maximum wins (as ATen's max_pool2d)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (c0 + i < C) out[g * out_ld + c0 + i] = best[i];
+    arg[g * ld + c0 + i] = (unsigned char)bi[i];
   }
 }
 
@@ -726,21 +876,23 @@ __global__ __launch_bounds__(1024) void mt_bn_bwd_finalize_kernel(int P, int ld,
 
 // dY = a.dz + k1.y + k0 with dz = dH.[H > 0]
 __global__ void mt_bn_bwd_apply_kernel(long long rows, int ld, const bf16_t* __restrict__ dH,
-                                       const bf16_t* __restrict__ H, const bf16_t* __restrict__ Y,
-                                       const float* __restrict__ a, const float* __restrict__ k1,
+                                       const bf16_t* __restrict__ Y, const float* __restrict__ a,
+                                       const float* __restrict__ b, const float* __restrict__ k1,
                                        const float* __restrict__ k0, bf16_t* __restrict__ dY) {
   const int cpr = ld >> 3;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * cpr) return;
-  const int c0 = (int)(t % cpr) * 8;
-  float g[8], h[8], y[8], o[8];
+  long long row_;
+  int c0;
+  split_idx(t, cpr, row_, c0);
+  float g[8], y[8], o[8], av[8], bv[8], k1v[8], k0v[8];
   unpack8(*reinterpret_cast<const uint4*>(dH + t * 8), g);
-  unpack8(*reinterpret_cast<const uint4*>(H + t * 8), h);
   unpack8(*reinterpret_cast<const uint4*>(Y + t * 8), y);
+  load8f(a + c0, av); load8f(b + c0, bv); load8f(k1 + c0, k1v); load8f(k0 + c0, k0v);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float dz = h[i] > 0.f ? g[i] : 0.f;
-    o[i] = fmaf(a[c0 + i], dz, fmaf(k1[c0 + i], y[i], k0[c0 + i]));
+    const float dz = relu_on(av[i], y[i], bv[i]) ? g[i] : 0.f;
+    o[i] = fmaf(av[i], dz, fmaf(k1v[i], y[i], k0v[i]));
   }
   *reinterpret_cast<uint4*>(dY + t * 8) = pack8(o);
 }
@@ -879,6 +1031,7 @@ extern "C" int pvn3d_mt_bn_finalize(int P, int ld, int C, double count, const fl
 extern "C" int pvn3d_mt_bn_relu_apply(long long rows, int ld, const void* Y, const float* a, const float* b, void* H,
                                       void* stream) {
   if (rows <= 0) return 0;
+  if ((ld & 7) || rows * (ld >> 3) >= 0x7fffffffLL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mt_bn_relu_apply_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld,
                      (const bf16_t*)Y, a, b, (bf16_t*)H);
   PVN3D_LAUNCH_CHECK();
@@ -932,14 +1085,49 @@ extern "C" int pvn3d_mt_bn_bwd_partials(long long rows) {
   return (int)((rows + rpb - 1) / rpb);
 }
 
-extern "C" int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* H, const void* Y,
-                                      const float* mean, const float* invstd, float* p1, float* p2, void* stream) {
+extern "C" int pvn3d_mt_bn_bwd_reduce(long long rows, int ld, const void* dH, const void* Y, const float* a,
+                                      const float* b, const float* mean, const float* invstd, float* p1, float* p2,
+                                      void* stream) {
   if (rows <= 0) return 0;
   if (ld > 2048 || (ld & 7)) return (int)hipErrorInvalidValue;
   const int rl = 256 / (ld >> 3);
   hipLaunchKernelGGL(mt_bn_bwd_reduce_kernel, dim3(pvn3d_mt_bn_bwd_partials(rows)), dim3(256),
-                     (size_t)2 * rl * ld * sizeof(float), MT_ST, rows, ld, mt_bwd_rows_per_block(rows), (const bf16_t*)dH, (const bf16_t*)H,
-                     (const bf16_t*)Y, mean, invstd, p1, p2);
+                     (size_t)2 * rl * ld * sizeof(float), MT_ST, rows, ld, mt_bwd_rows_per_block(rows), (const bf16_t*)dH,
+                     (const bf16_t*)Y, a, b, mean, invstd, p1, p2);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_bwd_reduce_pooled(long long G, int ns, int ld, int C, const float* dout, long long out_ld,
+                                             const void* arg, const void* Y, const float* a, const float* b,
+                                             const float* mean, const float* invstd, float* p1, float* p2, void* stream) {
+  if (G <= 0) return 0;
+  if (ld > 2048 || (ld & 7) || ns <= 0 || ns > 256) return (int)hipErrorInvalidValue;
+  const int rl = 256 / (ld >> 3);
+  hipLaunchKernelGGL(mt_bn_bwd_reduce_pooled_kernel, dim3(pvn3d_mt_bn_bwd_partials(G)), dim3(256),
+                     (size_t)2 * rl * ld * sizeof(float), MT_ST, G, ns, ld, C, mt_bwd_rows_per_block(G), dout, out_ld,
+                     (const unsigned char*)arg, (const bf16_t*)Y, a, b, mean, invstd, p1, p2);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_bwd_apply_pooled(long long G, int ns, int ld, int C, const float* dout, long long out_ld,
+                                            const void* arg, const void* Y, const float* a, const float* b,
+                                            const float* k1, const float* k0, void* dY, void* stream) {
+  if (G <= 0) return 0;
+  if ((ld & 7) || ns <= 0 || ns > 256 || G * ns * (ld >> 3) >= 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_bn_bwd_apply_pooled_kernel, dim3(grid1(G * ns * (ld >> 3), 256)), dim3(256), 0, MT_ST, G, ns, ld,
+                     C, dout, out_ld, (const unsigned char*)arg, (const bf16_t*)Y, a, b, k1, k0, (bf16_t*)dY);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pvn3d_mt_bn_relu_pool(long long G, int ns, int ld, int C, const void* Y, const float* a, const float* b,
+                                     float* out, long long out_ld, void* arg, void* stream) {
+  if (G <= 0) return 0;
+  if ((ld & 7) || ns <= 0 || ns > 256) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mt_bn_relu_pool_kernel, dim3(grid1(G * (ld >> 3), 256)), dim3(256), 0, MT_ST, G, ns, ld, C,
+                     (const bf16_t*)Y, a, b, out, out_ld, (unsigned char*)arg);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
@@ -954,11 +1142,12 @@ extern "C" int pvn3d_mt_bn_bwd_finalize(int P, int ld, int C, double count, cons
   return 0;
 }
 
-extern "C" int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* H, const void* Y,
-                                     const float* a, const float* k1, const float* k0, void* dY, void* stream) {
+extern "C" int pvn3d_mt_bn_bwd_apply(long long rows, int ld, const void* dH, const void* Y, const float* a,
+                                     const float* b, const float* k1, const float* k0, void* dY, void* stream) {
   if (rows <= 0) return 0;
+  if ((ld & 7) || rows * (ld >> 3) >= 0x7fffffffLL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mt_bn_bwd_apply_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, rows, ld,
-                     (const bf16_t*)dH, (const bf16_t*)H, (const bf16_t*)Y, a, k1, k0, (bf16_t*)dY);
+                     (const bf16_t*)dH, (const bf16_t*)Y, a, b, k1, k0, (bf16_t*)dY);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

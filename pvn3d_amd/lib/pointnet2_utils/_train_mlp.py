@@ -66,9 +66,12 @@ class _Chain(object):
         self.weights, self.gammas, self.betas, self.bns = weights, gammas, betas, bns
         self.y, self.h, self.mean, self.invstd, self.a = [], [], [], [], []
 
-    def forward(self, update_running=True):
+    def forward(self, update_running=True, pool=None):
+        """pool = (G, ns, out_ptr, out_ld, arg): the last layer's ReLU output goes straight into the max-pool (its
+        matrix is not materialised); returns None then."""
         dev, rows, st = self.dev, self.rows, None
         prev = self.x0
+        L = len(self.weights)
         for li, w in enumerate(self.weights):
             cin, cout = self.c[li], self.c[li + 1]
             ldi, ldo = _ld(cin), _ld(cout)
@@ -91,31 +94,48 @@ class _Chain(object):
                   "mt_bn_finalize")
             if track and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
+            self.y.append(y)
+            self.mean.append(stats)
+            if pool is not None and li == L - 1:
+                G, ns, out_ptr, out_ld, arg = pool
+                check(lib.pvn3d_mt_bn_relu_pool(G, ns, ldo, cout, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                                out_ptr, out_ld, arg.data_ptr(), st), "mt_bn_relu_pool")
+                self.h.append(None)
+                return None
             h = torch.empty((rows, ldo), dtype=torch.bfloat16, device=dev)
             check(lib.pvn3d_mt_bn_relu_apply(rows, ldo, y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
                                              h.data_ptr(), st), "mt_bn_relu_apply")
-            self.y.append(y)
             self.h.append(h)
-            self.mean.append(stats)
             prev = h
         return prev
 
-    def backward(self, dh, need_input_grad):
-        """dh: bf16 (rows, ld_L) gradient w.r.t. the last layer's output.  Returns (dX0 or None, [dW], [dgamma],
-        [dbeta])."""
+    def backward(self, dh, need_input_grad, pooled=None):
+        """dh: bf16 (rows, ld_L) gradient w.r.t. the last layer's output, or None with pooled = (G, ns, dout_ptr,
+        out_ld, arg): that gradient is the max-pool backward of dout and is never materialised.  Returns (dX0 or
+        None, [dW], [dgamma], [dbeta])."""
         dev, rows = self.dev, self.rows
-        st = _stream(dh)
+        st = _stream(self.x0)
         L = len(self.weights)
         dws, dgs, dbs = [None] * L, [None] * L, [None] * L
         for li in range(L - 1, -1, -1):
             cin, cout = self.c[li], self.c[li + 1]
             ldi, ldo = _ld(cin), _ld(cout)
-            y, h, stats = self.y[li], self.h[li], self.mean[li]
-            P = lib.pvn3d_mt_bn_bwd_partials(rows)
-            pp = torch.empty((2, P, ldo), dtype=torch.float32, device=dev)
-            check(lib.pvn3d_mt_bn_bwd_reduce(rows, ldo, dh.data_ptr(), h.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                                             stats[1].data_ptr(), pp[0].data_ptr(), pp[1].data_ptr(), st),
-                  "mt_bn_bwd_reduce")
+            y, stats = self.y[li], self.mean[li]
+            use_pool = pooled is not None and li == L - 1
+            if use_pool:
+                G, ns, dout_ptr, out_ld, arg = pooled
+                P = lib.pvn3d_mt_bn_bwd_partials(G)
+                pp = torch.empty((2, P, ldo), dtype=torch.float32, device=dev)
+                check(lib.pvn3d_mt_bn_bwd_reduce_pooled(G, ns, ldo, cout, dout_ptr, out_ld, arg.data_ptr(), y.data_ptr(),
+                                                        stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                                        stats[1].data_ptr(), pp[0].data_ptr(), pp[1].data_ptr(), st),
+                      "mt_bn_bwd_reduce_pooled")
+            else:
+                P = lib.pvn3d_mt_bn_bwd_partials(rows)
+                pp = torch.empty((2, P, ldo), dtype=torch.float32, device=dev)
+                check(lib.pvn3d_mt_bn_bwd_reduce(rows, ldo, dh.data_ptr(), y.data_ptr(), stats[2].data_ptr(),
+                                                 stats[3].data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                 pp[0].data_ptr(), pp[1].data_ptr(), st), "mt_bn_bwd_reduce")
             dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
             kk = torch.empty((2, ldo), dtype=torch.float32, device=dev)
             check(lib.pvn3d_mt_bn_bwd_finalize(P, ldo, cout, float(rows), pp[0].data_ptr(), pp[1].data_ptr(),
@@ -123,8 +143,14 @@ class _Chain(object):
                                                dgb[0].data_ptr(), dgb[1].data_ptr(), kk[0].data_ptr(), kk[1].data_ptr(),
                                                st), "mt_bn_bwd_finalize")
             dy = torch.empty((rows, ldo), dtype=torch.bfloat16, device=dev)
-            check(lib.pvn3d_mt_bn_bwd_apply(rows, ldo, dh.data_ptr(), h.data_ptr(), y.data_ptr(), stats[2].data_ptr(),
-                                            kk[0].data_ptr(), kk[1].data_ptr(), dy.data_ptr(), st), "mt_bn_bwd_apply")
+            if use_pool:
+                check(lib.pvn3d_mt_bn_bwd_apply_pooled(G, ns, ldo, cout, dout_ptr, out_ld, arg.data_ptr(), y.data_ptr(),
+                                                       stats[2].data_ptr(), stats[3].data_ptr(), kk[0].data_ptr(),
+                                                       kk[1].data_ptr(), dy.data_ptr(), st), "mt_bn_bwd_apply_pooled")
+            else:
+                check(lib.pvn3d_mt_bn_bwd_apply(rows, ldo, dh.data_ptr(), y.data_ptr(), stats[2].data_ptr(),
+                                                stats[3].data_ptr(), kk[0].data_ptr(), kk[1].data_ptr(), dy.data_ptr(), st),
+                      "mt_bn_bwd_apply")
             dgs[li], dbs[li] = dgb[0], dgb[1]
             # weight gradient: dW (cout, cin) = dY^T . H_prev, K = rows
             prev = self.h[li - 1] if li > 0 else self.x0
@@ -214,10 +240,8 @@ class SALevelTrain(torch.autograd.Function):
                                              fsb, fsc, fsn, idx.data_ptr(), x0.data_ptr(), _ld(c0), _stream(xyz)),
                       "mt_gather_sa")
                 ch = _Chain(x0, c0, ws, gs, bs, [bn for _, bn in layers])
-                h = ch.forward()
                 arg = torch.empty((B * m, _ld(width)), dtype=torch.uint8, device=dev)
-                check(lib.pvn3d_mt_pool_max(B * m, ns, _ld(width), width, h.data_ptr(), out.data_ptr() + 4 * off, total,
-                                            arg.data_ptr(), _stream(xyz)), "mt_pool_max")
+                ch.forward(pool=(B * m, ns, out.data_ptr() + 4 * off, total, arg))
                 chains.append(ch)
                 args.append((arg, idx, use_xyz, ns, width, off))
                 off += width
@@ -238,11 +262,7 @@ class SALevelTrain(torch.autograd.Function):
         with on_device(dev):
             st = _stream(gout)
             for ch, (arg, idx, use_xyz, ns, width, off) in zip(ctx.chains, ctx.args):
-                ldw = _ld(width)
-                dh = torch.empty((ch.rows, ldw), dtype=torch.bfloat16, device=dev)
-                check(lib.pvn3d_mt_pool_bwd(B * m, ns, ldw, width, gout.data_ptr() + 4 * off, total, arg.data_ptr(),
-                                            dh.data_ptr(), st), "mt_pool_bwd")
-                dx0, dws, dgs, dbs = ch.backward(dh, fneeds)
+                dx0, dws, dgs, dbs = ch.backward(None, fneeds, pooled=(B * m, ns, gout.data_ptr() + 4 * off, total, arg))
                 if point_major:
                     # point-major (B, N, C) gradient, handed back as the transposed view the previous level produced
                     first = dfeat is None
