@@ -29,13 +29,18 @@ typedef unsigned short bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ bf16_t f2bf(float f) {      // round to nearest even (inputs are finite)
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {      // round to nearest even: v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// two fp32 -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32 (the software form is five VALU
+// instructions per value, and the epilogues / elementwise kernels here are bound by VALU issue)
+typedef float mt_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mt_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const mt_f2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mt_bf2));
+}
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -64,8 +69,11 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
                                                          float* __restrict__ stat_sq, int stat_ld, int klen) {
   constexpr int NB = NT / 32;                 // 32-column blocks per wave
   constexpr int BL = (NT * 4 + 255) / 256;    // 16-byte B loads per thread and chunk
-  __shared__ __attribute__((aligned(16))) bf16_t sA[2][128 * GEMM_LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16_t sB[2][NT * GEMM_LDS_STRIDE];
+  // one allocation: [2][128 x 40] A chunks, [2][NT x 40] B chunks; the bf16 epilogue reuses it as four per-wave
+  // [32 rows][EC + 8] patches (EC = min(NT, 128) columns per pass)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (128 + NT) * GEMM_LDS_STRIDE];
+  bf16_t (*sA)[128 * GEMM_LDS_STRIDE] = reinterpret_cast<bf16_t (*)[128 * GEMM_LDS_STRIDE]>(smem);
+  bf16_t (*sB)[NT * GEMM_LDS_STRIDE] = reinterpret_cast<bf16_t (*)[NT * GEMM_LDS_STRIDE]>(smem + 2 * 128 * GEMM_LDS_STRIDE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * NT;
   const int kb = blockIdx.z * klen, ke = min(K, kb + klen);
@@ -75,16 +83,10 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
 #pragma unroll
   for (int i = 0; i < NB; ++i) { tsum[i] = 0.f; tsq[i] = 0.f; }
 
-  for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
-  const int m0 = mt * 128;
-  f32x16 acc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
+  // (requesting chunk 0 of the next row tile under the current tile's epilogue was measured: no gain for K <= 64 --
+  // the co-resident workgroups already cover the round trip -- and 5-25 % slower for the 256-column tiles)
   uint4 ra[2], rb[BL];
-  auto gload = [&](int c) {
+  auto gload = [&](int m0, int c) {
     const int k0 = kb + c * 32;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -115,16 +117,23 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
       if (row < NT) *reinterpret_cast<uint4*>(&sB[buf][row * GEMM_LDS_STRIDE + seg * 8]) = rb[p];
     }
   };
+  for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+  const int m0 = mt * 128;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   if (nchunks > 0) {
-    gload(0);
-    __syncthreads();           // (the previous tile's fragment reads are done)
+    gload(m0, 0);
+    __syncthreads();           // (the previous tile's patch / fragment reads are done)
     lstore(0);
     __syncthreads();
   }
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) gload(c + 1);
+    if (c + 1 < nchunks) gload(m0, c + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks * 16 + (lane >> 5) * 8;
@@ -144,21 +153,38 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int rbase = m0 + wave * 32 + 4 * (lane >> 5);
   if (EPI == 0) {
+    // The accumulators hold one column per lane (2-byte stores, 128 B per wave instruction); the tile goes
+    // through a per-wave LDS patch instead and leaves as 16-byte row-contiguous stores.
     bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
+    constexpr int EC = NT < 128 ? NT : 128;       // columns per pass
+    constexpr int PS = EC + 8;                    // patch row stride (elements): 16-byte aligned rows
+    constexpr int SEG = EC / 8;                   // 16-byte segments per row
+    static_assert(4 * 32 * PS <= 2 * (128 + NT) * GEMM_LDS_STRIDE, "patch fits the chunk buffers");
+    bf16_t* patch = smem + wave * 32 * PS;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int col = n0 + nb * 32 + (lane & 31);
-      if (col < ldc) {
+    for (int pass = 0; pass < NT / EC; ++pass) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < M) C[(size_t)row * ldc + col] = f2bf(acc[nb][r]);
+      for (int nbl = 0; nbl < EC / 32; ++nbl) {
+        const int nb = pass * (EC / 32) + nbl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PS + nbl * 32 + (lane & 31)] = f2bf(acc[nb][r]);
+        if (stat_sum) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tsum[nb] += acc[nb][r]; tsq[nb] += acc[nb][r] * acc[nb][r]; }
         }
       }
-      if (stat_sum) {
+      __syncthreads();
+      const int cbase = n0 + pass * EC;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { tsum[nb] += acc[nb][r]; tsq[nb] += acc[nb][r] * acc[nb][r]; }
+      for (int it = 0; it < (32 * SEG) / 64; ++it) {
+        const int q = it * 64 + lane;
+        const int rr = q / SEG, seg = q % SEG;
+        const int row = m0 + wave * 32 + rr, col = cbase + seg * 8;
+        if (row < M && col < ldc)
+          *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = *reinterpret_cast<const uint4*>(patch + rr * PS + seg * 8);
       }
+      __syncthreads();
     }
   } else {
     float* C = reinterpret_cast<float*>(Cv);
