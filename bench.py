@@ -164,8 +164,7 @@ def run_ops(inp, timer, scale):
         i0, i1 = _ext.ball_query_pair(new_xyz, xyz, radii[0], nss[0], radii[1], nss[1])
         timer.stop(t)
         t = timer.start("group")
-        g0 = _ext.group_xyz_features(xyz, new_xyz, feats, i0, True)
-        g1 = _ext.group_xyz_features(xyz, new_xyz, feats, i1, True)
+        g0, g1 = _ext.group_xyz_features_pair(xyz, new_xyz, feats, i0, i1)      # both radii of the level, one launch
         timer.stop(t)
         keep.append((g0, g1))
         xyz = new_xyz

@@ -160,6 +160,12 @@ int pvn3d_ball_query_pair_grid(int b, int n, int m, float radius0, int nsample0,
 int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample, int use_xyz,
                              const float* xyz, const float* new_xyz, const float* features,
                              const int* idx, float* out, void* stream);
+/* Both scales of a multi-scale-grouping level in one launch (pointnet2_modules.py:47-71 runs QueryAndGroup once per
+ * radius on the same xyz / new_xyz / features): every staged row group serves both index lists.  use_xyz = 1 and
+ * features != NULL; out_s: (b, 3 + c, m, nsample_s).  Same values as two pvn3d_group_xyz_features calls. */
+int pvn3d_group_xyz_features_pair(int b, int n, int m, int c, int nsample0, int nsample1, const float* xyz,
+                                  const float* new_xyz, const float* features, const int* idx0, const int* idx1,
+                                  float* out0, float* out1, void* stream);
 
 /* Fused set abstraction for inference: gather (QueryAndGroup, pointnet2_utils.py:311-321) ->
  * SharedMLP = [1x1 conv -> BatchNorm (eval) -> ReLU] x n_layers (pytorch_utils.py:25-50) ->

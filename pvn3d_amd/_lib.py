@@ -38,6 +38,7 @@ SIGNATURES = {
     "pvn3d_ball_query_grid_workspace_bytes": (_sz, [_i, _i]),
     "pvn3d_ball_query_pair_grid": (_i, [_i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pvn3d_group_xyz_features": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "pvn3d_group_xyz_features_pair": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "pvn3d_sa_mlp_maxpool": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_fp_interp_mlp": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_transpose_bcn_to_bnc": (_i, [_i, _i, _i, _p, _p, _i, _p]),

@@ -55,11 +55,20 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(
 // more row blocks (gridDim.y = ceil(c/CPB) + 3), block ceil(c/CPB) + k stages coordinate k of the cloud
 // (AoS (b,n,3), strided read) and writes out[b][k][p] = xyz[idx[p]][k] - new_xyz[p / nsample][k]; the
 // feature rows then start at channel 3 (pointnet2_utils.py:311-321: grouped_xyz -= new_xyz; cat).
+// One position stream of a launch: a QueryAndGroup scale (idx, its output, P = npoint * nsample positions cut into
+// spans of pchunk).  A launch carries one or two of them: the two scales of an MSG level gather from the SAME staged
+// rows, so the pair launch stages every row group once instead of twice (and is one launch instead of two).
+struct GpScale {
+  const int* idx;
+  float* out;
+  size_t out_batch_stride;
+  int P, pchunk, nsample;
+};
+
 template <int CPB, int NTHR>
 __global__ __launch_bounds__(NTHR) void group_points_rows_kernel(
-    int c, int n, int P, int pchunk, const float* __restrict__ points,
-    const int* __restrict__ idx, float* __restrict__ out, size_t out_batch_stride,
-    const float* __restrict__ xyz, const float* __restrict__ new_xyz, int nsample) {
+    int c, int n, int nscale, GpScale sc0, GpScale sc1, const float* __restrict__ points,
+    const float* __restrict__ xyz, const float* __restrict__ new_xyz) {
   extern __shared__ float s_row[];  // [CPB][n]
   const int tid = threadIdx.x;
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in
@@ -81,21 +90,25 @@ __global__ __launch_bounds__(NTHR) void group_points_rows_kernel(
     const float* xb = xyz + (size_t)bi * n * 3 + k;
     for (int q = tid; q < n; q += NTHR) s_row[q] = xb[(size_t)q * 3];
     __syncthreads();
-    const int* ip = idx + (size_t)bi * P;
-    const float* cb = new_xyz + (size_t)bi * (P / nsample) * 3 + k;
-    float* o = out + (size_t)bi * out_batch_stride + (size_t)k * P;
-    const int p_end = min(bx * pchunk + pchunk, P);
-    for (int p = bx * pchunk + tid * 4; p < p_end; p += 4 * NTHR) {
-      const int4 id = *reinterpret_cast<const int4*>(ip + p);
-      v4f val;
-      if ((nsample & 3) == 0) {      // the four positions share one centre
-        const float cc = cb[(size_t)(p / nsample) * 3];
-        val = v4f{s_row[id.x] - cc, s_row[id.y] - cc, s_row[id.z] - cc, s_row[id.w] - cc};
-      } else {
-        val = v4f{s_row[id.x] - cb[(size_t)(p / nsample) * 3], s_row[id.y] - cb[(size_t)((p + 1) / nsample) * 3],
-                  s_row[id.z] - cb[(size_t)((p + 2) / nsample) * 3], s_row[id.w] - cb[(size_t)((p + 3) / nsample) * 3]};
+    for (int si = 0; si < nscale; ++si) {
+      // (field by field: a reference to `si ? sc1 : sc0` would be a pointer select and push the arguments to scratch)
+      const int P = si ? sc1.P : sc0.P, pchunk = si ? sc1.pchunk : sc0.pchunk, nsample = si ? sc1.nsample : sc0.nsample;
+      const int* ip = (si ? sc1.idx : sc0.idx) + (size_t)bi * P;
+      const float* cb = new_xyz + (size_t)bi * (P / nsample) * 3 + k;
+      float* o = (si ? sc1.out : sc0.out) + (size_t)bi * (si ? sc1.out_batch_stride : sc0.out_batch_stride) + (size_t)k * P;
+      const int p_end = min(bx * pchunk + pchunk, P);
+      for (int p = bx * pchunk + tid * 4; p < p_end; p += 4 * NTHR) {
+        const int4 id = *reinterpret_cast<const int4*>(ip + p);
+        v4f val;
+        if ((nsample & 3) == 0) {      // the four positions share one centre
+          const float cc = cb[(size_t)(p / nsample) * 3];
+          val = v4f{s_row[id.x] - cc, s_row[id.y] - cc, s_row[id.z] - cc, s_row[id.w] - cc};
+        } else {
+          val = v4f{s_row[id.x] - cb[(size_t)(p / nsample) * 3], s_row[id.y] - cb[(size_t)((p + 1) / nsample) * 3],
+                    s_row[id.z] - cb[(size_t)((p + 2) / nsample) * 3], s_row[id.w] - cb[(size_t)((p + 3) / nsample) * 3]};
+        }
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + p));
       }
-      __builtin_nontemporal_store(val, reinterpret_cast<v4f*>(o + p));
     }
     return;
   }
@@ -106,10 +119,14 @@ __global__ __launch_bounds__(NTHR) void group_points_rows_kernel(
   float4* s4 = reinterpret_cast<float4*>(s_row);
   for (int q = tid; q < nc * n4; q += NTHR) s4[q] = row[q];
   __syncthreads();
+  for (int si = 0; si < nscale; ++si) {
+  const int P = si ? sc1.P : sc0.P, pchunk = si ? sc1.pchunk : sc0.pchunk;
   const int p_begin = bx * pchunk;
+  if (p_begin >= P) continue;
   const int p_end = min(p_begin + pchunk, P);
-  const int* ip = idx + (size_t)bi * P;
-  float* o = out + (size_t)bi * out_batch_stride + (size_t)(c0 + (xyz ? 3 : 0)) * P;
+  const int* ip = (si ? sc1.idx : sc0.idx) + (size_t)bi * P;
+  float* o = (si ? sc1.out : sc0.out) + (size_t)bi * (si ? sc1.out_batch_stride : sc0.out_batch_stride) +
+             (size_t)(c0 + (xyz ? 3 : 0)) * P;
   // idx is loaded one iteration ahead: gfx950 counts loads and stores in the same in-order
   // vmcnt, so waiting for an idx load issued AFTER the previous iteration's stores would wait
   // for their write acknowledgements too; issued before them it only needs vmcnt(#stores).
@@ -184,6 +201,7 @@ __global__ __launch_bounds__(NTHR) void group_points_rows_kernel(
       }
     }
   }
+  }   // scales
 }
 
 // any-P fallback, one output element per thread.  grid: (ceil(P/256), c, b)
@@ -275,15 +293,22 @@ __global__ __launch_bounds__(256) void group_points_grad_rows_kernel(
   }
 }
 
+// second scale (idx1 != nullptr): same points / xyz / new_xyz, its own idx, output and nsample
 int launch_group(int b, int c, int n, int P, const float* points, const int* idx, float* out,
                  size_t out_batch_stride, hipStream_t st, const float* xyz = nullptr,
-                 const float* new_xyz = nullptr, int nsample = 1) {
+                 const float* new_xyz = nullptr, int nsample = 1, int P1 = 0, const int* idx1 = nullptr,
+                 float* out1 = nullptr, size_t out_batch_stride1 = 0, int nsample1 = 1) {
   if (b <= 0 || c <= 0 || P <= 0) return 0;
-  const bool aligned = (P % 4 == 0) && (out_batch_stride % 4 == 0) &&
-                       (((uintptr_t)out & 15) == 0) && (((uintptr_t)idx & 15) == 0);
+  const bool pair = idx1 != nullptr;
+  bool aligned = (P % 4 == 0) && (out_batch_stride % 4 == 0) &&
+                 (((uintptr_t)out & 15) == 0) && (((uintptr_t)idx & 15) == 0);
+  if (pair)
+    aligned = aligned && (P1 % 4 == 0) && (out_batch_stride1 % 4 == 0) && (((uintptr_t)out1 & 15) == 0) &&
+              (((uintptr_t)idx1 & 15) == 0);
   // (at n = 12288 -- level 0, 9 channels -- a workgroup stages a 48 KiB row for 16-32 KiB of output; the
   // direct-gather kernel below was measured there too and is slower still: 66 + 104 us vs 49 + 62 us)
   const bool rows_ok = aligned && (n % 4 == 0) && (size_t)n * 4 <= 128 * 1024 && (((uintptr_t)points & 15) == 0);
+  if (pair && !rows_ok) return 2;      // the caller falls back to two single launches
   if (rows_ok) {
     // rows per workgroup: up to 8 rows in at most 32 KiB of LDS (idx is re-read once per row group, so
     // more rows per group = less L2 traffic per output byte; past 32 KiB the lost occupancy costs more).
@@ -299,16 +324,20 @@ int launch_group(int b, int c, int n, int P, const float* points, const int* idx
     const int nthr = cpb == 1 ? 1024 : 256;
     int pch = pvn3d_ceil_div(cpb == 1 ? 1024 : 4096, rows * b);
     if (pch < 1) pch = 1;
-    int pchunk = pvn3d_ceil_div(pvn3d_ceil_div(P, pch), 4 * nthr) * 4 * nthr;
-    if (pchunk < 16 * nthr) pchunk = 16 * nthr;
-    pch = pvn3d_ceil_div(P, pchunk);
+    auto span = [&](int Ps, int& pchunk_s) {          // -> number of spans of this scale
+      pchunk_s = pvn3d_ceil_div(pvn3d_ceil_div(Ps, pch), 4 * nthr) * 4 * nthr;
+      if (pchunk_s < 16 * nthr) pchunk_s = 16 * nthr;
+      return pvn3d_ceil_div(Ps, pchunk_s);
+    };
+    GpScale s0{idx, out, out_batch_stride, P, 0, nsample}, s1{idx1, out1, out_batch_stride1, P1, 0, nsample1};
+    int gx = span(P, s0.pchunk);
+    if (pair) gx = std::max(gx, span(P1, s1.pchunk));
     const size_t lds = (size_t)cpb * n * sizeof(float);
 #define GP_LAUNCH(CPB, NTHR)                                                                      \
   do {                                                                                            \
     auto gk = group_points_rows_kernel<CPB, NTHR>;                                                \
     PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(gk));                                     \
-    hipLaunchKernelGGL(gk, dim3(pch, rows, b), dim3(NTHR), lds, st, c, n, P, pchunk, points, idx, \
-                       out, out_batch_stride, xyz, new_xyz, nsample);                             \
+    hipLaunchKernelGGL(gk, dim3(gx, rows, b), dim3(NTHR), lds, st, c, n, pair ? 2 : 1, s0, s1, points, xyz, new_xyz); \
   } while (0)
     if (cpb == 8) GP_LAUNCH(8, 256); else if (cpb == 4) GP_LAUNCH(4, 256); else if (cpb == 2) GP_LAUNCH(2, 256); else GP_LAUNCH(1, 1024);
 #undef GP_LAUNCH
@@ -364,6 +393,22 @@ extern "C" int pvn3d_group_xyz_features(int b, int n, int m, int c, int nsample,
     return launch_group(b, c, n, P, features, idx, out + (use_xyz ? (size_t)3 * P : 0), bstride,
                         st);
   return 0;
+}
+
+extern "C" int pvn3d_group_xyz_features_pair(int b, int n, int m, int c, int nsample0, int nsample1,
+                                             const float* xyz, const float* new_xyz, const float* features,
+                                             const int* idx0, const int* idx1, float* out0, float* out1,
+                                             void* stream) {
+  if (b <= 0 || m <= 0 || nsample0 <= 0 || nsample1 <= 0) return 0;
+  if (!xyz || !new_xyz || !features || c <= 0 || !idx0 || !idx1 || !out0 || !out1) return (int)hipErrorInvalidValue;
+  const int rc = launch_group(b, c, n, m * nsample0, features, idx0, out0, (size_t)(3 + c) * m * nsample0,
+                              (hipStream_t)stream, xyz, new_xyz, nsample0, m * nsample1, idx1, out1,
+                              (size_t)(3 + c) * m * nsample1, nsample1);
+  if (rc != 1 && rc != 2) return rc;
+  // shapes the row kernel does not take: the two single-scale calls
+  const int r0 = pvn3d_group_xyz_features(b, n, m, c, nsample0, 1, xyz, new_xyz, features, idx0, out0, stream);
+  if (r0) return r0;
+  return pvn3d_group_xyz_features(b, n, m, c, nsample1, 1, xyz, new_xyz, features, idx1, out1, stream);
 }
 
 extern "C" int pvn3d_group_points_grad(int b, int c, int n, int npoints, int nsample,

@@ -359,6 +359,27 @@ def group_xyz_features(xyz, new_xyz, features, idx, use_xyz=True):
     return out
 
 
+def group_xyz_features_pair(xyz, new_xyz, features, idx0, idx1):
+    """QueryAndGroup (use_xyz=True) for both radii of a multi-scale level in one launch ->
+    ((B, 3 + C, npoint, ns0), (B, 3 + C, npoint, ns1)); same values as two group_xyz_features calls."""
+    for t, name, dt in ((xyz, "xyz", torch.float32), (new_xyz, "new_xyz", torch.float32), (features, "features", torch.float32),
+                        (idx0, "idx0", torch.int32), (idx1, "idx1", torch.int32)):
+        _chk(t, name, dt)
+        _same_dev(xyz, t, name)
+    B, N = xyz.size(0), xyz.size(1)
+    C = features.size(1)
+    m = idx0.size(1)
+    assert idx1.size(1) == m and idx0.size(0) == B and idx1.size(0) == B
+    ns0, ns1 = idx0.size(2), idx1.size(2)
+    out0 = torch.empty((B, 3 + C, m, ns0), dtype=torch.float32, device=xyz.device)
+    out1 = torch.empty((B, 3 + C, m, ns1), dtype=torch.float32, device=xyz.device)
+    with on_device(xyz.device):
+        check(lib.pvn3d_group_xyz_features_pair(B, N, m, C, ns0, ns1, xyz.data_ptr(), new_xyz.data_ptr(),
+                                                features.data_ptr(), idx0.data_ptr(), idx1.data_ptr(), out0.data_ptr(),
+                                                out1.data_ptr(), _stream(xyz)), "group_xyz_features_pair")
+    return out0, out1
+
+
 def _point_major(t):
     """(B, C, n) tensor -> (base tensor, ld) of a point-major (B, n, ld) table holding it.
     Zero-copy when `t` already is a transposed view of a point-major buffer (what the fused

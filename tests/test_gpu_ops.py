@@ -247,6 +247,22 @@ def test_group_xyz_features_equals_reference_composition(ext, orc, dev):
     assert np.array_equal(got3.cpu().numpy(), want[:, 3:])
 
 
+@pytest.mark.parametrize("b,n,m,c,ns0,ns1", [(2, 1500, 256, 20, 16, 32), (8, 2048, 1024, 96, 16, 32), (1, 12288, 2048, 6, 16, 32),
+                                              (3, 1001, 77, 5, 3, 7), (8, 512, 128, 512, 32, 16)])
+def test_group_xyz_features_pair_equals_two_single_calls(ext, dev, b, n, m, c, ns0, ns1):
+    """Both radii of an MSG level in one launch (every staged row group serves both index lists): bit-identical to the
+    two single-scale calls, at the row-kernel shapes (one / four / eight rows per workgroup, XCD-mapped batch of 8) and
+    at an unaligned shape that takes the fallback."""
+    g = np.random.default_rng(n + c)
+    xyz = T(clouds(n, b, n, 0.1), dev)
+    new_xyz = xyz[:, :m].contiguous()
+    feats = T(g.normal(size=(b, c, n)).astype(np.float32), dev)
+    i0, i1 = ext.ball_query_pair(new_xyz, xyz, 0.03, ns0, 0.06, ns1)
+    g0, g1 = ext.group_xyz_features_pair(xyz, new_xyz, feats, i0, i1)
+    assert torch.equal(g0, ext.group_xyz_features(xyz, new_xyz, feats, i0, True))
+    assert torch.equal(g1, ext.group_xyz_features(xyz, new_xyz, feats, i1, True))
+
+
 @pytest.mark.parametrize("b,c,m,n", [(2, 7, 50, 200), (1, 256, 2048, 12288), (1, 5, 20, 101)])
 def test_three_interpolate_exact(ext, orc, dev, b, c, m, n):
     g = np.random.default_rng(m)
