@@ -334,11 +334,14 @@ int pvn3d_three_interpolate_grad_det(int b, int c, int n, int m, const float* gr
  * chain; with one frame per call the deep levels are 8 - 64 workgroups.  Same arithmetic (fp32 MFMA, eval
  * BatchNorm folded into W', b'), one layer per launch, one wave per 32 x 32 output tile, activations as
  * point-major fp32 matrices [columns][channels].
- * pvn3d_sb_linear: C[M][ldc] = act(A[M][K] . W[N][K]^T + bias[N]) (relu != 0: max(.,0)).
+ * pvn3d_sb_linear: C[M][ldc] = act(A[M][K] . W[N][K]^T + bias[N]) (relu != 0: max(.,0)).  splits > 1 cuts K into
+ * that many slices (partials in part[splits][M][N], caller's scratch; added in ascending slice order, then bias and
+ * ReLU: deterministic) -- pvn3d_sb_linear_splits(M, N, K) is the library's choice for a launch with few output tiles.
  * pvn3d_sb_gather_sa / _fp: the layer-0 input rows (as pvn3d_mt_gather_*, fp32).  pvn3d_sb_pool_max: max over
  * the ns rows of every group -> out[g*out_ld + c]. */
+int pvn3d_sb_linear_splits(int M, int N, int K);
 int pvn3d_sb_linear(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias, int relu,
-                    float* C, int ldc, void* stream);
+                    float* C, int ldc, float* part, int splits, void* stream);
 int pvn3d_sb_gather_sa(int b, int n, int m, int ns, int C, int use_xyz, const float* xyz, const float* new_xyz,
                        const float* feat, long long fsb, long long fsc, long long fsn, const int* idx, float* X0, int ld,
                        void* stream);

@@ -57,7 +57,8 @@ SIGNATURES = {
     "pvn3d_add_adds_workspace_bytes": (_sz, [_i, _i]),
     "pvn3d_add_adds_batch": (_i, [_i, _i, _p, _p, _p, _p, _p, _sz, _p, _p, _p]),
     # layer-by-layer fp32-MFMA SharedMLP for small launches (csrc/small_batch.hip)
-    "pvn3d_sb_linear": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "pvn3d_sb_linear": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "pvn3d_sb_linear_splits": (_i, [_i, _i, _i]),
     "pvn3d_sb_gather_sa": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _ll, _ll, _ll, _p, _p, _i, _p]),
     "pvn3d_sb_gather_fp": (_i, [_i, _i, _i, _i, _i, _p, _ll, _ll, _ll, _p, _ll, _ll, _ll, _p, _p, _p, _i, _p]),
     "pvn3d_sb_pool_max": (_i, [_ll, _i, _i, _i, _p, _p, _ll, _p]),

@@ -19,10 +19,15 @@ constexpr int SB_LS = SB_KC + 1;   // LDS row stride (floats): the 32 rows of a 
 // C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]); A [M][lda], W [N][ldw], C [M][ldc] fp32.  Workgroup = 64 x 64
 // output tile, four waves of one 32 x 32 MFMA tile each; K in 32-chunks through double-buffered LDS (a single
 // wave staging its own operands spent 8x the MFMA time on loads and LDS writes).
+// Split-K (gridDim.z > 1): slice z owns the K range [z * klen, (z + 1) * klen) and writes its raw partial sums to
+// part[z][M][N]; sb_splitk_reduce_kernel adds the slices in ascending z (deterministic), then bias and ReLU.  One frame
+// gives the deep levels 64 - 256 output tiles of K = 512 - 1536: without the split a tile is 16 - 48 dependent
+// load -> LDS -> MFMA round trips on one CU while the other CUs idle.
 __global__ __launch_bounds__(256) void sb_linear_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                         const float* __restrict__ W, int ldw,
                                                         const float* __restrict__ bias, int relu,
-                                                        float* __restrict__ C, int ldc) {
+                                                        float* __restrict__ C, int ldc, int klen,
+                                                        float* __restrict__ part) {
   __shared__ float sA[2][64 * SB_LS];
   __shared__ float sW[2][64 * SB_LS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -30,11 +35,13 @@ __global__ __launch_bounds__(256) void sb_linear_kernel(int M, int N, int K, con
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nchunks = (K + SB_KC - 1) / SB_KC;
+  const int kb = blockIdx.z * klen;
+  K = min(K, kb + klen);                                 // this slice's end
+  const int nchunks = (K - kb + SB_KC - 1) / SB_KC;
   const bool vec = ((lda | ldw) & 3) == 0;
   float4 ra[2], rw[2];
   auto gload = [&](int c) {
-    const int k0 = c * SB_KC;
+    const int k0 = kb + c * SB_KC;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int t = tid + p * 256;
@@ -82,6 +89,17 @@ __global__ __launch_bounds__(256) void sb_linear_kernel(int M, int N, int K, con
   }
   // C/D layout: column (n) = lane & 31, row (m) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int n = n0 + nr + (lane & 31);
+  if (part) {
+    if (n < N) {
+      float* P = part + (size_t)blockIdx.z * M * N;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) P[(size_t)m * N + n] = acc[r];
+      }
+    }
+    return;
+  }
   if (n < N) {
     const float b = bias ? bias[n] : 0.f;
 #pragma unroll
@@ -94,6 +112,18 @@ __global__ __launch_bounds__(256) void sb_linear_kernel(int M, int N, int K, con
       }
     }
   }
+}
+
+__global__ void sb_splitk_reduce_kernel(int M, int N, int S, const float* __restrict__ part,
+                                        const float* __restrict__ bias, int relu, float* __restrict__ C, int ldc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * N) return;
+  const int m = t / N, n = t - m * N;
+  float v = part[t];
+  for (int z = 1; z < S; ++z) v += part[(size_t)z * M * N + t];
+  if (bias) v += bias[n];
+  if (relu) v = fmaxf(v, 0.f);
+  C[(size_t)m * ldc + n] = v;
 }
 
 // SA input rows (fp32): X0[(b*m + j)*ns + s][c] = relative xyz (c < 3 when use_xyz) ++ feat[b, c, idx] (strided source)
@@ -173,12 +203,31 @@ inline unsigned sb_grid1(long long work, int block) { return (unsigned)((work + 
 
 #define SB_ST ((hipStream_t)stream)
 
+extern "C" int pvn3d_sb_linear_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  const long long tiles = (long long)pvn3d_ceil_div(M, 64) * pvn3d_ceil_div(N, 64);
+  int s = 1;
+  while (s < 8 && tiles * s < 512 && K / (s * 2) >= 128) s *= 2;      // >= 128 of K per slice, <= 8 slices
+  return s;
+}
+
 extern "C" int pvn3d_sb_linear(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
-                               int relu, float* C, int ldc, void* stream) {
+                               int relu, float* C, int ldc, float* part, int splits, void* stream) {
   if (M <= 0 || N <= 0) return 0;
-  if (K <= 0 || !A || !W || !C) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sb_linear_kernel, dim3(pvn3d_ceil_div(M, 64), pvn3d_ceil_div(N, 64)), dim3(256), 0, SB_ST, M, N, K,
-                     A, lda, W, ldw, bias, relu, C, ldc);
+  if (K <= 0 || !A || !W || !C || splits < 1 || (splits > 1 && !part)) return (int)hipErrorInvalidValue;
+  if (splits == 1) {
+    hipLaunchKernelGGL(sb_linear_kernel, dim3(pvn3d_ceil_div(M, 64), pvn3d_ceil_div(N, 64), 1), dim3(256), 0, SB_ST, M, N,
+                       K, A, lda, W, ldw, bias, relu, C, ldc, K, (float*)nullptr);
+    PVN3D_LAUNCH_CHECK();
+    return 0;
+  }
+  const int klen = pvn3d_ceil_div(pvn3d_ceil_div(K, splits), SB_KC) * SB_KC;
+  const int gz = pvn3d_ceil_div(K, klen);
+  hipLaunchKernelGGL(sb_linear_kernel, dim3(pvn3d_ceil_div(M, 64), pvn3d_ceil_div(N, 64), gz), dim3(256), 0, SB_ST, M, N,
+                     K, A, lda, W, ldw, bias, relu, C, ldc, klen, part);
+  PVN3D_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sb_splitk_reduce_kernel, dim3(sb_grid1((long long)M * N, 256)), dim3(256), 0, SB_ST, M, N, gz, part,
+                     bias, relu, C, ldc);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

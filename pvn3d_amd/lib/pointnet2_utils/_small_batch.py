@@ -54,8 +54,11 @@ def _chain(x, layers, st):
     for W, b in layers:
         cout, cin = W.shape
         y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+        splits = int(lib.pvn3d_sb_linear_splits(rows, cout, cin))        # few output tiles: cut K (deterministic)
+        part = torch.empty((splits, rows, cout), dtype=torch.float32, device=x.device) if splits > 1 else None
         check(lib.pvn3d_sb_linear(rows, cout, cin, x.data_ptr(), x.size(1), W.data_ptr(), cin, b.data_ptr(), 1,
-                                  y.data_ptr(), cout, st), "sb_linear")
+                                  y.data_ptr(), cout, part.data_ptr() if part is not None else None, splits, st),
+              "sb_linear")
         x = y
     return x
 
