@@ -318,8 +318,8 @@ extern "C" int pvn3d_three_interpolate(int b, int c, int m, int n, const float* 
                        (((uintptr_t)idx & 15) == 0) && (((uintptr_t)weight & 15) == 0);
   const bool rows_ok = aligned && (m % 4 == 0) && m <= TI_LDS_MAX_M && m > 0 && (((uintptr_t)points & 15) == 0);
   if (rows_ok) {
-    // 4 rows per workgroup measured best (idx/weight are 24 B per point, read once per 4 rows);
-    // tile-owner and direct-gather variants measured slower and were removed
+    // up to 8 rows per workgroup in at most 64 KiB of LDS (idx/weight are 24 B per point, read once per row
+    // group); tile-owner and direct-gather variants measured slower and were removed
     int cpb = 8;
     while (cpb > 1 && (size_t)cpb * m * 4 > 64 * 1024) cpb >>= 1;
     while (cpb > 1 && cpb > c) cpb >>= 1;

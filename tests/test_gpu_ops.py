@@ -38,6 +38,40 @@ def test_fps_index_exact(ext, orc, dev, b, n, m, wrap):
     assert np.array_equal(got, orc.furthest_point_sampling(xyz, m))
 
 
+def test_large_lds_opt_in_is_per_kernel_not_per_signature(dev):
+    """Kernels with more than 64 KiB of dynamic LDS opt in through hipFuncSetAttribute, once per kernel.  Several
+    instantiations share one C++ signature (grid_build_kernel<4,..>/<5,..>, fps_cells_kernel<2>/<3>, the fused-MLP
+    variants): in a FRESH process the small instantiation runs first, then the large one of the same signature --
+    a cache keyed on the signature would skip the second opt-in and the launch would fail."""
+    import subprocess, sys, os
+    code = r"""
+import numpy as np, torch
+from pvn3d_amd.lib.pointnet2_utils import _ext
+from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+dev = torch.device("cuda:0")
+g = np.random.default_rng(0)
+mk = lambda b, n: torch.from_numpy(g.uniform(-0.2, 0.2, size=(b, n, 3)).astype(np.float32)).to(dev)
+for n, m in ((2048, 512), (12288, 2048)):              # 16^3 bucket table (16 KiB), then 32^3 (132 KiB)
+    x = mk(2, n)
+    i0, i1 = _ext.ball_query_pair(x[:, :m].contiguous(), x, 0.03, 16, 0.06, 32)
+    assert int(i0.max()) < n and int(i1.max()) < n
+for n, m in ((5000, 300), (12288, 2048)):              # fps_cells_kernel<2> (147 KiB), then <3> (160 KiB)
+    s = _ext.furthest_point_sampling(mk(2, n), m)
+    assert int(s.max()) < n and len(set(s[0].tolist())) == m
+torch.manual_seed(0)
+net = Pointnet2MSG(input_channels=6).to(dev).eval()   # small-batch (B = 1) path first, then the fused chains at B = 8
+with torch.no_grad():
+    for b in (1, 8):
+        pc = torch.cat([mk(b, 12288), torch.randn(b, 12288, 6, device=dev)], 2)
+        assert torch.isfinite(net(pc)).all()
+torch.cuda.synchronize()
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", ["odd_sizes", "lattice", "few_unique", "skipped_most", "all_skipped", "nonfinite",
                                   "collinear", "far_offset", "full_run"])
 def test_fps_culled_kernel_index_exact(ext, orc, dev, case):
