@@ -501,6 +501,47 @@ def test_fused_sa_mlp_matches_unfused_modules(dev, c_in, mlps, nsamples, npoint,
     assert not out_v.is_contiguous() and torch.equal(out_v, out_f)
 
 
+@pytest.mark.parametrize("c_in,mlps,nsamples,npoint,n", [
+    (6, [[6, 16, 16, 32], [6, 32, 32, 64]], [16, 32], 128, 900),
+    (256, [[256, 128, 196, 256]], [32], 64, 400),
+])
+def test_fused_sa_mlp_against_independent_fp64(dev, orc, c_in, mlps, nsamples, npoint, n):
+    """The fused gather -> SharedMLP -> max-pool kernels against a float64 numpy evaluation that shares nothing with the
+    package but the module's parameters: neighbour lists from the C oracle, grouping by numpy indexing, the 1x1
+    convolutions as float64 matrix products, eval BatchNorm from its definition (pytorch_utils.py:25-50,
+    pointnet2_modules.py:57-71).  fp32 MFMA accumulation over K <= 259 against fp64: 2e-5 of the output scale."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    torch.manual_seed(3)
+    radii = [0.05, 0.1][:len(nsamples)]
+    sa = pm.PointnetSAModuleMSG(npoint=npoint, radii=radii, nsamples=nsamples, mlps=[list(x) for x in mlps]).to(dev).eval()
+    _randomize_bn(sa)
+    xyz_np = clouds(11, 2, n, 0.1)
+    feats_np = np.random.default_rng(4).normal(size=(2, c_in, n)).astype(np.float32)
+    with torch.no_grad():
+        new_xyz, out = sa(T(xyz_np, dev), T(feats_np, dev))
+    new_xyz_np = new_xyz.cpu().numpy()
+    want = []
+    for si, (radius, ns) in enumerate(zip(radii, nsamples)):
+        idx = orc.ball_query(new_xyz_np, xyz_np, radius, ns)                      # (B, npoint, ns)
+        b_ix = np.arange(2)[:, None, None]
+        gx = xyz_np[b_ix, idx].astype(np.float64) - new_xyz_np[:, :, None, :].astype(np.float64)     # (B, m, ns, 3)
+        gf = np.transpose(feats_np, (0, 2, 1))[b_ix, idx].astype(np.float64)                          # (B, m, ns, C)
+        h = np.concatenate([gx, gf], -1)
+        for layer in sa.mlps[si].children():
+            W = layer.conv.weight.detach().cpu().double().numpy()[:, :, 0, 0]
+            bn = layer.normlayer.bn
+            mu, var = bn.running_mean.cpu().double().numpy(), bn.running_var.cpu().double().numpy()
+            ga, be = bn.weight.detach().cpu().double().numpy(), bn.bias.detach().cpu().double().numpy()
+            h = h @ W.T
+            h = (h - mu) / np.sqrt(var + bn.eps) * ga + be
+            h = np.maximum(h, 0.0)
+        want.append(h.max(axis=2))                                                # (B, m, C_out)
+    want = np.transpose(np.concatenate(want, -1), (0, 2, 1))                     # (B, C_total, m)
+    got = out.cpu().double().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
 def test_fused_fp_mlp_and_full_pointnet2msg(dev):
     from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
