@@ -75,6 +75,66 @@ def test_inverse_gather_is_the_scatter_add(dev, n_src, E, div, C, c_off):
     assert float((out.cpu().double() - 2 * want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("G,ns,C", [(300, 16, 32), (1000, 32, 64), (77, 5, 200), (64, 32, 512)])
+def test_pooled_batchnorm_backward_equals_the_dense_passes(dev, G, ns, C):
+    """The last layer of a set-abstraction chain: ReLU + max-pool straight from Y (mt_bn_relu_pool) and the two
+    BatchNorm-backward passes fed from the pooled gradient and the arg indices (mt_bn_bwd_*_pooled) against the dense
+    sequence they replace -- relu_apply, pool_max, pool_bwd, bwd_reduce, bwd_apply on materialised matrices.  Pooled
+    values, arg indices and dY are bit-identical; the channel sums agree to fp32 summation order."""
+    from pvn3d_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    ld = (C + 15) // 16 * 16
+    rows = G * ns
+    g = torch.Generator(device="cpu").manual_seed(G + C)
+    Y = torch.zeros(rows, ld)
+    Y[:, :C] = torch.randn(rows, C, generator=g)
+    Y = Y.to(dev).to(torch.bfloat16)
+    stats = torch.zeros(4, ld)                      # mean, invstd, a, b
+    stats[0, :C] = torch.randn(C, generator=g) * 0.1
+    stats[1, :C] = torch.rand(C, generator=g) + 0.5
+    stats[2, :C] = (torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.2, -1.0, 1.0)
+    stats[3, :C] = torch.randn(C, generator=g) * 0.3
+    stats = stats.to(dev)
+    total = C + 8                                   # the pooled tensor is a channel slice of a wider buffer
+    dout = torch.randn(G, total, generator=g).to(dev)
+    off = 8
+    # dense sequence
+    H = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+    check(lib.pvn3d_mt_bn_relu_apply(rows, ld, Y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), H.data_ptr(), st), "a")
+    out_d = torch.zeros((G, total), device=dev)
+    arg_d = torch.empty((G, ld), dtype=torch.uint8, device=dev)
+    check(lib.pvn3d_mt_pool_max(G, ns, ld, C, H.data_ptr(), out_d.data_ptr() + 4 * off, total, arg_d.data_ptr(), st), "p")
+    dH = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+    check(lib.pvn3d_mt_pool_bwd(G, ns, ld, C, dout.data_ptr() + 4 * off, total, arg_d.data_ptr(), dH.data_ptr(), st), "pb")
+    P = lib.pvn3d_mt_bn_bwd_partials(rows)
+    pd = torch.empty((2, P, ld), device=dev)
+    check(lib.pvn3d_mt_bn_bwd_reduce(rows, ld, dH.data_ptr(), Y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                     stats[0].data_ptr(), stats[1].data_ptr(), pd[0].data_ptr(), pd[1].data_ptr(), st), "r")
+    kk = (torch.randn(2, ld, generator=g) * 0.05).to(dev)
+    dY_d = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+    check(lib.pvn3d_mt_bn_bwd_apply(rows, ld, dH.data_ptr(), Y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                    kk[0].data_ptr(), kk[1].data_ptr(), dY_d.data_ptr(), st), "ap")
+    # pooled sequence
+    out_p = torch.zeros((G, total), device=dev)
+    arg_p = torch.empty((G, ld), dtype=torch.uint8, device=dev)
+    check(lib.pvn3d_mt_bn_relu_pool(G, ns, ld, C, Y.data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                    out_p.data_ptr() + 4 * off, total, arg_p.data_ptr(), st), "rp")
+    Pp = lib.pvn3d_mt_bn_bwd_partials(G)
+    pp = torch.empty((2, Pp, ld), device=dev)
+    check(lib.pvn3d_mt_bn_bwd_reduce_pooled(G, ns, ld, C, dout.data_ptr() + 4 * off, total, arg_p.data_ptr(), Y.data_ptr(),
+                                            stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                            stats[1].data_ptr(), pp[0].data_ptr(), pp[1].data_ptr(), st), "rpool")
+    dY_p = torch.empty((rows, ld), dtype=torch.bfloat16, device=dev)
+    check(lib.pvn3d_mt_bn_bwd_apply_pooled(G, ns, ld, C, dout.data_ptr() + 4 * off, total, arg_p.data_ptr(), Y.data_ptr(),
+                                           stats[2].data_ptr(), stats[3].data_ptr(), kk[0].data_ptr(), kk[1].data_ptr(),
+                                           dY_p.data_ptr(), st), "appool")
+    assert torch.equal(out_p, out_d) and torch.equal(arg_p[:, :C], arg_d[:, :C])
+    assert torch.equal(dY_p.view(torch.int16), dY_d.view(torch.int16))
+    for k in range(2):
+        a, b = pp[k].double().sum(0)[:C], pd[k].double().sum(0)[:C]
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
 def _grads(mod, inputs, out):
     g = torch.randn_like(out) if not hasattr(_grads, "g") else None
     return g
