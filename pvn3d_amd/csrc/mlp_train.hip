@@ -51,6 +51,28 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
 }
 
+// H > 0 without reading H: H = bf16(relu(a y + b)) (mt_bn_relu_apply), so the mask is recomputed from y -- the
+// backward passes stream two matrices instead of three
+// (a positive fp32 a y + b rounds to a positive bf16 unless it is a subnormal below 2^-134, where the derivative of
+// the ReLU is 1 anyway)
+__device__ __forceinline__ bool relu_on(float a, float y, float b) { return fmaf(a, y, b) > 0.f; }
+// thread index -> (row, 8-channel chunk) and row -> (group, sample) in 32-bit arithmetic (the entry points refuse
+// launches beyond 2^31 chunks; a 64-bit division costs more than the rest of these kernels)
+__device__ __forceinline__ void split_idx(long long t, int cpr, long long& row, int& c0) {
+  const unsigned u = (unsigned)t, r = u / (unsigned)cpr;
+  row = r;
+  c0 = (int)(u - r * (unsigned)cpr) * 8;
+}
+__device__ __forceinline__ void split_row(long long row, int ns, long long& g, int& s) {
+  const unsigned u = (unsigned)row, q = u / (unsigned)ns;
+  g = q;
+  s = (int)(u - q * (unsigned)ns);
+}
+__device__ __forceinline__ void load8f(const float* __restrict__ p, float (&v)[8]) {
+  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+}
+
 // ------------------------------------------------------------------------------------------------ GEMM
 // C[M][N] = A[M][K] . B[N][K]^T, A / B bf16 with K contiguous (lda, ldb in elements, multiples of 8; K a multiple
 // of 16; rows of B beyond N and rows of A beyond M read as zero).  Workgroup tile 128 x NT, four waves of 32 rows
@@ -293,6 +315,13 @@ __global__ void mt_pack_weight_kernel(int rows, int cols, const float* __restric
 // SA level input: X0[(b*m + j)*ns + s][c] = (c < 3: xyz[b, idx] - new_xyz[b, j]) | (c < 3 + C: feat[b, c - 3, idx])
 // | 0.  feat element (b, c, n) at feat[b*fsb + c*fsc + n*fsn] (fp32: channel-major tensors and transposed views of
 // point-major ones alike).  One thread = 8 consecutive channels of one row.
+// eight consecutive floats from a 4-byte-aligned address: two 16-byte loads (global memory takes dword-aligned vectors)
+struct __attribute__((packed, aligned(4))) mt_f4u { float x, y, z, w; };
+__device__ __forceinline__ void load8u(const float* __restrict__ p, float (&v)[8]) {
+  const mt_f4u a = *reinterpret_cast<const mt_f4u*>(p), c = *reinterpret_cast<const mt_f4u*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+}
+
 __global__ void mt_gather_sa_kernel(int b, int n, int m, int ns, int C, int use_xyz, const float* __restrict__ xyz,
                                     const float* __restrict__ new_xyz, const float* __restrict__ feat, long long fsb,
                                     long long fsc, long long fsn, const int* __restrict__ idx,
@@ -301,20 +330,36 @@ __global__ void mt_gather_sa_kernel(int b, int n, int m, int ns, int C, int use_
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long rows = (long long)b * m * ns;
   if (t >= rows * cpr) return;
-  const long long row = t / cpr;
-  const int c0 = (int)(t % cpr) * 8;
-  const int bi = (int)(row / ((long long)m * ns));
-  const int j = (int)((row / ns) % m);
+  long long row;
+  int c0;
+  split_idx(t, cpr, row, c0);
+  const unsigned mns = (unsigned)m * (unsigned)ns;
+  const int bi = (int)((unsigned)row / mns);
+  const int j = (int)(((unsigned)row - (unsigned)bi * mns) / (unsigned)ns);
   const int k = idx[row];
   const int nx = use_xyz ? 3 : 0;
   float v[8];
+  const float* fb = feat ? feat + bi * fsb + k * fsn : nullptr;
+  if (fb && fsc == 1 && c0 >= nx && c0 - nx + 8 <= C) {
+    // interior chunk of a point-major feature row: eight consecutive floats
+    load8u(fb + (c0 - nx), v);
+  } else {
+    // every load is issued unconditionally at a clamped (valid) address and selected afterwards: a guarded load is a
+    // branch with a round trip of its own
+    float f[8], g[3];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    float x = 0.f;
-    if (c < nx) x = xyz[((size_t)bi * n + k) * 3 + c] - new_xyz[((size_t)bi * m + j) * 3 + c];
-    else if (c < nx + C) x = feat[bi * fsb + (c - nx) * fsc + k * fsn];
-    v[i] = x;
+    for (int i = 0; i < 8; ++i) {
+      int fc = c0 + i - nx;
+      fc = fc < 0 ? 0 : (fc >= C ? C - 1 : fc);
+      f[i] = (fb && C > 0) ? fb[fc * fsc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = xyz[((size_t)bi * n + k) * 3 + i] - new_xyz[((size_t)bi * m + j) * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      v[i] = c < nx ? g[c < 3 ? c : 0] : (c < nx + C ? f[i] : 0.f);
+    }
   }
   *reinterpret_cast<uint4*>(X0 + row * ld + c0) = pack8(v);
 }
@@ -367,23 +412,40 @@ __global__ void mt_gather_fp_kernel(int b, int n, int mk, int C2, int C1, const 
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long rows = (long long)b * n;
   if (t >= rows * cpr) return;
-  const long long row = t / cpr;
-  const int c0 = (int)(t % cpr) * 8;
-  const int bi = (int)(row / n), i0 = (int)(row % n);
+  long long row;
+  int c0;
+  split_idx(t, cpr, row, c0);
+  const int bi = (int)((unsigned)row / (unsigned)n), i0 = (int)((unsigned)row - (unsigned)bi * (unsigned)n);
   const int k0 = idx[row * 3], k1 = idx[row * 3 + 1], k2 = idx[row * 3 + 2];
   const float w0 = w[row * 3], w1 = w[row * 3 + 1], w2 = w[row * 3 + 2];
+  const float* kb = known + bi * ksb;
   float v[8];
+  if (ksc == 1 && c0 + 8 <= C2) {
+    // point-major known features: three rows, eight consecutive channels each (same expression as the generic path)
+    float a0[8], a1[8], a2[8];
+    load8u(kb + k0 * ksn + c0, a0);
+    load8u(kb + k1 * ksn + c0, a1);
+    load8u(kb + k2 * ksn + c0, a2);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = c0 + i;
-    float x = 0.f;
-    if (c < C2) {
-      const float* p = known + bi * ksb + c * ksc;
-      x = p[k0 * ksn] * w0 + p[k1 * ksn] * w1 + p[k2 * ksn] * w2;
-    } else if (c < C2 + C1) {
-      x = unknown[bi * usb + (c - C2) * usc + i0 * usn];
+    for (int i = 0; i < 8; ++i) v[i] = a0[i] * w0 + a1[i] * w1 + a2[i] * w2;
+  } else {
+    // unconditional loads at clamped addresses, selected afterwards (a guarded load is a branch with its own round trip)
+    float a0[8], a1[8], a2[8], u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int kc = c0 + i;
+      kc = kc >= C2 ? C2 - 1 : kc;
+      const float* p = kb + kc * ksc;
+      a0[i] = p[k0 * ksn]; a1[i] = p[k1 * ksn]; a2[i] = p[k2 * ksn];
+      int uc = c0 + i - C2;
+      uc = uc < 0 ? 0 : (uc >= C1 ? C1 - 1 : uc);
+      u[i] = (unknown && C1 > 0) ? unknown[bi * usb + uc * usc + i0 * usn] : 0.f;
     }
-    v[i] = x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      v[i] = c < C2 ? a0[i] * w0 + a1[i] * w1 + a2[i] * w2 : (c < C2 + C1 ? u[i] : 0.f);
+    }
   }
   *reinterpret_cast<uint4*>(X0 + row * ld + c0) = pack8(v);
 }
@@ -548,27 +610,6 @@ __global__ __launch_bounds__(1024) void mt_bn_finalize_kernel(int P, int ld, int
   }
 }
 
-// H > 0 without reading H: H = bf16(relu(a y + b)) (mt_bn_relu_apply), so the mask is recomputed from y -- the
-// backward passes stream two matrices instead of three
-// (a positive fp32 a y + b rounds to a positive bf16 unless it is a subnormal below 2^-134, where the derivative of
-// the ReLU is 1 anyway)
-__device__ __forceinline__ bool relu_on(float a, float y, float b) { return fmaf(a, y, b) > 0.f; }
-// thread index -> (row, 8-channel chunk) and row -> (group, sample) in 32-bit arithmetic (the entry points refuse
-// launches beyond 2^31 chunks; a 64-bit division costs more than the rest of these kernels)
-__device__ __forceinline__ void split_idx(long long t, int cpr, long long& row, int& c0) {
-  const unsigned u = (unsigned)t, r = u / (unsigned)cpr;
-  row = r;
-  c0 = (int)(u - r * (unsigned)cpr) * 8;
-}
-__device__ __forceinline__ void split_row(long long row, int ns, long long& g, int& s) {
-  const unsigned u = (unsigned)row, q = u / (unsigned)ns;
-  g = q;
-  s = (int)(u - q * (unsigned)ns);
-}
-__device__ __forceinline__ void load8f(const float* __restrict__ p, float (&v)[8]) {
-  const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-}
 // H = relu(a y + b), 8 channels per thread
 __global__ void mt_bn_relu_apply_kernel(long long rows, int ld, const bf16_t* __restrict__ Y,
                                         const float* __restrict__ a, const float* __restrict__ b,
@@ -979,7 +1020,8 @@ extern "C" int pvn3d_mt_gather_sa(int b, int n, int m, int ns, int C, int use_xy
                                   const int* idx, void* X0, int ld, void* stream) {
   const long long rows = (long long)b * m * ns;
   if (rows <= 0) return 0;
-  if ((ld & 15) || ld < (use_xyz ? 3 : 0) + C) return (int)hipErrorInvalidValue;
+  if ((ld & 15) || ld < (use_xyz ? 3 : 0) + C || rows * (ld >> 3) >= 0x7fffffffLL || (long long)m * ns >= 0x7fffffffLL)
+    return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mt_gather_sa_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, b, n, m, ns, C,
                      use_xyz, xyz, new_xyz, feat, fsb, fsc, fsn, idx, (bf16_t*)X0, ld);
   PVN3D_LAUNCH_CHECK();
@@ -1037,7 +1079,7 @@ extern "C" int pvn3d_mt_gather_fp(int b, int n, int mk, int C2, int C1, const fl
                                   const int* idx, const float* w, void* X0, int ld, void* stream) {
   const long long rows = (long long)b * n;
   if (rows <= 0) return 0;
-  if ((ld & 15) || ld < C2 + C1) return (int)hipErrorInvalidValue;
+  if ((ld & 15) || ld < C2 + C1 || C2 <= 0 || rows * (ld >> 3) >= 0x7fffffffLL) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mt_gather_fp_kernel, dim3(grid1(rows * (ld >> 3), 256)), dim3(256), 0, MT_ST, b, n, mk, C2, C1,
                      known, ksb, ksc, ksn, unknown, usb, usc, usn, idx, w, (bf16_t*)X0, ld);
   PVN3D_LAUNCH_CHECK();
