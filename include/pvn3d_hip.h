@@ -369,6 +369,11 @@ int pvn3d_mt_gemm_nt_splitk(int M, int N, int K, const void* A, int lda, const v
                             int ksplit, void* stream);
 /* X bf16 [rows][ld] -> XT [ld][ldt]; W fp32 [rows][cols] (row stride lds) -> bf16 [out_rows][ld] zero-padded,
  * transposed when `transpose`; bf16 [B*R][ld] channels [c_off, c_off+C) <-> fp32 channel-major [B][C][R]. */
+/* Weight gradient without transposed copies, for layers of at most 512 x 544 channels (pvn3d_mt_wgrad_tn_ok):
+ * dW (M, N) fp32 += dY^T . H over `rows` rows of the row-major bf16 matrices dY [rows][ldy] and H [rows][ldh]. */
+int pvn3d_mt_wgrad_tn_ok(int M, int N);
+int pvn3d_mt_wgrad_tn(long long rows, int M, int N, const void* dY, int ldy, const void* H, int ldh, float* dW, int ldw,
+                      void* stream);
 int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream);
 int pvn3d_mt_pack_weight(int rows, int cols, const float* W, int lds, int transpose, void* out, int out_rows, int ld,
                          void* stream);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "pvn3d_mt_gemm_nt_stat_rows": (_i, [_i]),
     "pvn3d_mt_gemm_nt_splitk": (_i, [_i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p]),
     "pvn3d_mt_transpose": (_i, [_ll, _i, _p, _p, _ll, _p]),
+    "pvn3d_mt_wgrad_tn_ok": (_i, [_i, _i]),
+    "pvn3d_mt_wgrad_tn": (_i, [_ll, _i, _i, _p, _i, _p, _i, _p, _i, _p]),
     "pvn3d_mt_pack_weight": (_i, [_i, _i, _p, _i, _i, _p, _i, _i, _p]),
     "pvn3d_mt_gather_sa": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _ll, _ll, _ll, _p, _p, _i, _p]),
     "pvn3d_mt_unpack_cm": (_i, [_i, _i, _i, _i, _i, _p, _p, _p]),

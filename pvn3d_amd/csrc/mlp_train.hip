@@ -269,6 +269,133 @@ int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ wgrad, TN form
+// dW[m][n] += sum over rows k of dY[k][m] * H[k][n]: the contraction runs over ROWS, which both operands store as
+// their slow dimension.  The NT kernel above needs K contiguous, i.e. transposed copies of dY and H (a write and a
+// re-read of both matrices per layer: 1.7 ms of a 20 ms step, plus 3.1 ms in split-K NT launches whose 128-row tiles
+// are mostly padding when a layer has 16 - 64 channels).  This kernel reads the row-major matrices directly (layers of
+// up to 512 x 544 channels; wider ones keep the NT path): every WAVE is an independent worker over its own range of 16-row steps -- it stages the
+// step's [16 rows][channels] slices in a wave-private LDS patch with 16-byte stores and pulls the MFMA fragments out
+// column-wise (eight 2-byte reads per fragment: the k index of an operand is the row).  No workgroup barrier in the
+// loop; the work is HBM-bound (6 KB per step and wave against ~100 instructions), so the narrow LDS reads do not
+// matter.  The four waves of a workgroup add their tiles in LDS, then one fp32 atomicAdd per element to dW.
+// grid (tiles_m * tiles_n, workers / 4); MB x NB 32-blocks per tile, MB * NB <= 8.
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void mt_wgrad_tn_kernel(long long rows, int M, int N, const bf16_t* __restrict__ dY,
+                                                          int ldy, const bf16_t* __restrict__ H, int ldh,
+                                                          float* __restrict__ dW, int ldw, int tiles_n,
+                                                          int steps_per_wave) {
+  constexpr int SA = 32 * MB + 8, SB = 32 * NB + 8;             // patch row strides (elements)
+  constexpr int PATCH = 16 * (SA + SB);                         // one step of one wave
+  constexpr int TILE_F = 32 * MB * 32 * NB;                     // floats of the output tile
+  constexpr int LDS_E = (2 * 4 * PATCH * 2 > TILE_F * 4 ? 2 * 4 * PATCH : TILE_F * 2);   // elements (2 B)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[LDS_E];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * 32 * MB, n0 = tn * 32 * NB;
+  // worker w takes the steps w, w + W, w + 2W, ... (W = all workers of this tile): at any moment the waves in flight
+  // read one contiguous moving window of the matrices, like a streaming kernel, instead of W separate streams
+  const long long total_steps = (rows + 15) >> 4;
+  const long long W = (long long)gridDim.y * 4;
+  const long long s_begin = (long long)blockIdx.y * 4 + wave;
+  const long long s_end = total_steps;
+  (void)steps_per_wave;
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16_t* const mine = smem + wave * 2 * PATCH;
+  uint4 ra[MB], rb[NB];
+  auto gload = [&](long long step) {
+    const long long r0 = step << 4;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int q = i * 64 + lane, row = q / (4 * MB), seg = q - row * (4 * MB);
+      const int ch = m0 + seg * 8;
+      ra[i] = (r0 + row < rows && ch < ldy) ? *reinterpret_cast<const uint4*>(dY + (r0 + row) * ldy + ch) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = i * 64 + lane, row = q / (4 * NB), seg = q - row * (4 * NB);
+      const int ch = n0 + seg * 8;
+      rb[i] = (r0 + row < rows && ch < ldh) ? *reinterpret_cast<const uint4*>(H + (r0 + row) * ldh + ch) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* pa = mine + buf * PATCH;
+    bf16_t* pb = pa + 16 * SA;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int q = i * 64 + lane, row = q / (4 * MB), seg = q - row * (4 * MB);
+      *reinterpret_cast<uint4*>(pa + row * SA + seg * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = i * 64 + lane, row = q / (4 * NB), seg = q - row * (4 * NB);
+      *reinterpret_cast<uint4*>(pb + row * SB + seg * 8) = rb[i];
+    }
+  };
+  // fragment = rows kb*8 .. kb*8+7 of column c, packed pairwise
+  auto frag = [&](const bf16_t* base, int stride, int c) {
+    const bf16_t* p = base + ((lane >> 5) * 8) * stride + c + (lane & 31);
+    uint4 v;
+    v.x = (unsigned)p[0] | ((unsigned)p[stride] << 16);
+    v.y = (unsigned)p[2 * stride] | ((unsigned)p[3 * stride] << 16);
+    v.z = (unsigned)p[4 * stride] | ((unsigned)p[5 * stride] << 16);
+    v.w = (unsigned)p[6 * stride] | ((unsigned)p[7 * stride] << 16);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  if (s_begin < s_end) {
+    gload(s_begin);
+    lstore(0);
+    int buf = 0;
+    for (long long st = s_begin; st < s_end; st += W, buf ^= 1) {
+      if (st + W < s_end) gload(st + W);
+      const bf16_t* pa = mine + buf * PATCH;
+      const bf16_t* pb = pa + 16 * SA;
+      bf16x8 b[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = frag(pb, SB, j * 32);
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const bf16x8 a = frag(pa, SA, i * 32);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[i][j], 0, 0, 0);
+      }
+      if (st + W < s_end) lstore(buf ^ 1);
+    }
+  }
+  // the four waves add their tiles in LDS one after the other (plain read-add-write: the wave whose turn it is owns the
+  // tile; ds_add_f32 from four waves at once measured ~14 us per workgroup, more than the whole K loop), then one
+  // global atomic per element
+  float* tile = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  for (int i = tid; i < TILE_F; i += 256) tile[i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && s_begin < s_end) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = j * 32 + (lane & 31);
+            tile[m * (32 * NB) + n] += acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < TILE_F; i += 256) {
+    const int m = i / (32 * NB), n = i - m * (32 * NB);
+    const float v = tile[i];
+    if (m0 + m < M && n0 + n < N && v != 0.f) atomicAdd(&dW[(size_t)(m0 + m) * ldw + n0 + n], v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ layout helpers
 // X [rows][ld] bf16 -> XT [ld][ldt] (ldt >= rows, both multiples of 8): (4096 / TC) x TC tiles through LDS, TC = 16 /
 // 32 / 64 columns so that narrow matrices (ld = 16: the first SA level) still fill the tile.  16-byte global loads
@@ -988,6 +1115,48 @@ extern "C" int pvn3d_mt_gemm_nt_splitk(int M, int N, int K, const void* A, int l
   if (K <= 0 || (K & 15) || (lda & 7) || (ldb & 7) || !A || !B || !C || ksplit < 1) return (int)hipErrorInvalidValue;
   return launch_gemm_nt<1>(M, N, K, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, nullptr, nullptr, 0, ksplit,
                            MT_ST);
+}
+
+extern "C" int pvn3d_mt_wgrad_tn_ok(int M, int N) { return M > 0 && N > 0 && M <= 512 && N <= 544; }
+
+// dW (M, N) fp32 += dY^T . H over `rows` rows; dY [rows][ldy], H [rows][ldh] bf16 row-major (ld multiples of 8,
+// pad channels zero); M, N <= 128.  dW must be initialised by the caller (it is accumulated into).
+extern "C" int pvn3d_mt_wgrad_tn(long long rows, int M, int N, const void* dY, int ldy, const void* H, int ldh, float* dW,
+                                 int ldw, void* stream) {
+  if (rows <= 0 || M <= 0 || N <= 0) return 0;
+  if (!pvn3d_mt_wgrad_tn_ok(M, N) || (ldy & 7) || (ldh & 7) || ldy < M || ldh < N || !dY || !H || !dW)
+    return (int)hipErrorInvalidValue;
+  const int mb_all = pvn3d_ceil_div(M, 32), nb_all = pvn3d_ceil_div(N, 32);
+  // tile = MB x NB 32-blocks per wave, MB * NB <= 8 (128 accumulator registers); wider layers are cut into several
+  // tiles, whose workers sweep the rows at the same pace, so the re-read operand slices are L2 hits
+  int MB, NB;
+  if (nb_all <= 2) { MB = mb_all >= 3 ? 4 : mb_all; NB = nb_all; }
+  else { MB = mb_all >= 2 ? 2 : 1; NB = 4; }
+  if (MB == 1 && NB == 3) NB = 4;
+  const int tiles_m = pvn3d_ceil_div(M, 32 * MB), tiles_n = pvn3d_ceil_div(N, 32 * NB);
+  const long long steps = (rows + 15) >> 4;
+  // ~3000 workers (waves) over the chip (every workgroup ends with a tile reduction + atomics: 6000 measured slower), at least 8 steps each
+  long long workers = 3072 / (tiles_m * tiles_n);
+  if (workers < 4) workers = 4;
+  long long spw = (steps + workers - 1) / workers;
+  if (spw < 8) spw = 8;
+  workers = (steps + spw - 1) / spw;
+  const dim3 grid(tiles_m * tiles_n, (unsigned)((workers + 3) / 4));
+#define MT_WG(MB_, NB_)                                                                                             \
+  hipLaunchKernelGGL((mt_wgrad_tn_kernel<MB_, NB_>), grid, dim3(256), 0, MT_ST, rows, M, N, (const bf16_t*)dY, ldy,  \
+                     (const bf16_t*)H, ldh, dW, ldw, tiles_n, (int)spw)
+  if (MB == 1 && NB == 1) MT_WG(1, 1);
+  else if (MB == 1 && NB == 2) MT_WG(1, 2);
+  else if (MB == 1 && NB == 4) MT_WG(1, 4);
+  else if (MB == 2 && NB == 1) MT_WG(2, 1);
+  else if (MB == 2 && NB == 2) MT_WG(2, 2);
+  else if (MB == 2 && NB == 4) MT_WG(2, 4);
+  else if (MB == 4 && NB == 1) MT_WG(4, 1);
+  else if (MB == 4 && NB == 2) MT_WG(4, 2);
+  else return (int)hipErrorInvalidValue;
+#undef MT_WG
+  PVN3D_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream) {

@@ -154,17 +154,22 @@ class _Chain(object):
             dgs[li], dbs[li] = dgb[0], dgb[1]
             # weight gradient: dW (cout, cin) = dY^T . H_prev, K = rows
             prev = self.h[li - 1] if li > 0 else self.x0
-            dyt = torch.empty((ldo, rows), dtype=torch.bfloat16, device=dev)
-            pvt = torch.empty((ldi, rows), dtype=torch.bfloat16, device=dev)
-            check(lib.pvn3d_mt_transpose(rows, ldo, dy.data_ptr(), dyt.data_ptr(), rows, st), "mt_transpose")
-            check(lib.pvn3d_mt_transpose(rows, ldi, prev.data_ptr(), pvt.data_ptr(), rows, st), "mt_transpose")
             dw = torch.zeros((cout, cin), dtype=torch.float32, device=dev)
-            tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-            ksplit = max(1, min(rows // 512, 1024 // tiles))
-            check(lib.pvn3d_mt_gemm_nt_splitk(cout, cin, rows, dyt.data_ptr(), rows, pvt.data_ptr(), rows,
-                                              dw.data_ptr(), cin, ksplit, st), "mt_gemm_nt_splitk")
+            if WGRAD_TN and lib.pvn3d_mt_wgrad_tn_ok(cout, cin):
+                # straight from the row-major matrices (no transposed copies)
+                check(lib.pvn3d_mt_wgrad_tn(rows, cout, cin, dy.data_ptr(), ldo, prev.data_ptr(), ldi, dw.data_ptr(), cin,
+                                            st), "mt_wgrad_tn")
+            else:
+                dyt = torch.empty((ldo, rows), dtype=torch.bfloat16, device=dev)
+                pvt = torch.empty((ldi, rows), dtype=torch.bfloat16, device=dev)
+                check(lib.pvn3d_mt_transpose(rows, ldo, dy.data_ptr(), dyt.data_ptr(), rows, st), "mt_transpose")
+                check(lib.pvn3d_mt_transpose(rows, ldi, prev.data_ptr(), pvt.data_ptr(), rows, st), "mt_transpose")
+                tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+                ksplit = max(1, min(rows // 512, 1024 // tiles))
+                check(lib.pvn3d_mt_gemm_nt_splitk(cout, cin, rows, dyt.data_ptr(), rows, pvt.data_ptr(), rows,
+                                                  dw.data_ptr(), cin, ksplit, st), "mt_gemm_nt_splitk")
+                del dyt, pvt
             dws[li] = dw
-            del dyt, pvt
             # input gradient: dH_prev (rows, ldi) = dY . W
             if li > 0 or need_input_grad:
                 wt = torch.empty((cin, ldo), dtype=torch.bfloat16, device=dev)
@@ -182,6 +187,9 @@ class _Chain(object):
 # Backward of the layer-0 gathers through inverted index lists (csrc/mlp_train.hip mt_csr_build / mt_inv_gather)
 # instead of the atomic scatter kernels; False restores mt_unpack_cm + group_points_grad / three_interpolate_grad.
 INVERSE_GATHER = True
+# Weight gradients straight from the row-major matrices (mt_wgrad_tn; layers of up to 512 x 544 channels);
+# False: transposed copies + the split-K NT GEMM for every layer.
+WGRAD_TN = True
 
 
 def _inv_gather(dx0, B, n_src, idx, div, C, c_off, w, out, accumulate, st):

@@ -75,6 +75,30 @@ def test_inverse_gather_is_the_scatter_add(dev, n_src, E, div, C, c_off):
     assert float((out.cpu().double() - 2 * want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("rows,M,N", [(4096, 16, 9), (100000, 32, 32), (50001, 64, 99), (3000, 128, 128), (777, 96, 64),
+                                      (20000, 128, 33), (15, 7, 5), (9000, 256, 259), (5000, 196, 128), (4000, 200, 70), (3000, 512, 528)])
+def test_wgrad_tn_matches_torch(dev, rows, M, N):
+    """dW = dY^T . H straight from the row-major bf16 matrices (mt_wgrad_tn: per-wave LDS patches, column-wise
+    fragment reads, no transposed copies) against fp64 on the same bf16 values; asymmetric operands, ragged row counts,
+    channel counts that are not multiples of 32, accumulation into a non-zero dW."""
+    from pvn3d_amd._lib import lib, check
+    g = torch.Generator(device="cpu").manual_seed(rows + M + N)
+    ldy, ldh = (M + 15) // 16 * 16, (N + 15) // 16 * 16
+    dY = torch.zeros(rows, ldy)
+    dY[:, :M] = torch.randn(rows, M, generator=g) * torch.linspace(0.5, 2.0, M)
+    H = torch.zeros(rows, ldh)
+    H[:, :N] = torch.rand(rows, N, generator=g) + torch.linspace(-0.3, 0.3, N)
+    dY, H = dY.to(torch.bfloat16), H.to(torch.bfloat16)
+    want = dY.double()[:, :M].t() @ H.double()[:, :N] + 1.0
+    dW = torch.ones((M, N), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.pvn3d_mt_wgrad_tn_ok(M, N) == 1
+    dY_d, H_d = dY.to(dev), H.to(dev)
+    check(lib.pvn3d_mt_wgrad_tn(rows, M, N, dY_d.data_ptr(), ldy, H_d.data_ptr(), ldh, dW.data_ptr(), N, st), "wgrad")
+    err = float((dW.cpu().double() - want).abs().max())
+    assert err <= 2e-6 * max(1.0, float(want.abs().max())) * max(1.0, (rows / 4096.0) ** 0.5)
+
+
 @pytest.mark.parametrize("G,ns,C", [(300, 16, 32), (1000, 32, 64), (77, 5, 200), (64, 32, 512)])
 def test_pooled_batchnorm_backward_equals_the_dense_passes(dev, G, ns, C):
     """The last layer of a set-abstraction chain: ReLU + max-pool straight from Y (mt_bn_relu_pool) and the two
