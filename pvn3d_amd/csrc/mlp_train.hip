@@ -851,16 +851,19 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
     float mu[8], is[8], aa[8], bb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { mu[i] = mean[c0 + i]; is[i] = invstd[c0 + i]; aa[i] = av[c0 + i]; bb[i] = bv[c0 + i]; }
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    const long long r1 = min(rows, r0 + rows_per_block);
-    // four rows in flight per thread (eight 16-byte loads): one row at a time is latency-bound at a third of the
-    // HBM rate
-    long long r = r0 + rlane;
-    for (; r + 3LL * rl < r1; r += 4LL * rl) {
+    // Block b takes the row groups b, b + P, b + 2P, ... of 4 rl rows (P = gridDim.x): the blocks in flight read one
+    // moving window of the matrices instead of P separate streams (mt_wgrad_tn: 2.6x on cold data).  Four rows in
+    // flight per thread (eight 16-byte loads): one row at a time is latency-bound at a third of the HBM rate.
+    (void)rows_per_block;
+    const long long group = 4LL * rl;
+    for (long long base = (long long)blockIdx.x * group; base < rows; base += (long long)gridDim.x * group) {
       uint4 vg[4], vy[4];
+      bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long o = (r + (long long)u * rl) * ld + c0;
+        const long long r = base + rlane + (long long)u * rl;
+        ok[u] = r < rows;
+        const long long o = (ok[u] ? r : rows - 1) * ld + c0;          // (clamped: the load itself is unconditional)
         vg[u] = *reinterpret_cast<const uint4*>(dH + o);
         vy[u] = *reinterpret_cast<const uint4*>(Y + o);
       }
@@ -871,21 +874,10 @@ __global__ __launch_bounds__(256) void mt_bn_bwd_reduce_kernel(long long rows, i
         unpack8(vy[u], y);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float dz = relu_on(aa[i], y[i], bb[i]) ? g[i] : 0.f;
+          const float dz = (ok[u] & relu_on(aa[i], y[i], bb[i])) ? g[i] : 0.f;
           s1[i] += dz;
           s2[i] += dz * ((y[i] - mu[i]) * is[i]);
         }
-      }
-    }
-    for (; r < r1; r += rl) {
-      float g[8], y[8];
-      unpack8(*reinterpret_cast<const uint4*>(dH + r * ld + c0), g);
-      unpack8(*reinterpret_cast<const uint4*>(Y + r * ld + c0), y);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float dz = relu_on(aa[i], y[i], bb[i]) ? g[i] : 0.f;
-        s1[i] += dz;
-        s2[i] += dz * ((y[i] - mu[i]) * is[i]);
       }
     }
 #pragma unroll
