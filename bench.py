@@ -470,15 +470,19 @@ def extra_configs(net, dev, poll_every, with_cpu):
                                               "bf16: SA/FP SharedMLP forward+backward on csrc/mlp_train.hip (bf16 MFMA GEMM + fused "
                                               "BatchNorm/ReLU/pool kernels); bf16_library_mlp / fp32: torch Conv2d/BatchNorm2d "
                                               "(MIOpen/hipBLASLt)" % B)
-    for tag, dt, fused in (("fp32", None, False), ("bf16_library_mlp", torch.bfloat16, False),
-                           ("bf16_autocast", torch.bfloat16, True)):
+    # bf16_autocast_prefetch: the same step with the NEXT batch's xyz-only geometry (FPS, ball query, three_nn) enqueued
+    # under this step's backward, as a training loop with a data loader can (here the next batch is the same tensor)
+    for tag, dt, fused, pre in (("fp32", None, False, False), ("bf16_library_mlp", torch.bfloat16, False, False),
+                                ("bf16_autocast", torch.bfloat16, True, False),
+                                ("bf16_autocast_prefetch", torch.bfloat16, True, True)):
         torch.manual_seed(1)
         model = ts.PointVoteNet().to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         losses = []
         _train_mlp.TRAIN_FUSED = fused
         try:
-            ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt)), 5, warm=2)
+            ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt,
+                                                                prefetch=batch["pc"] if pre else None)), 5, warm=2)
         finally:
             _train_mlp.TRAIN_FUSED = True
         entry[tag] = dict(ms_per_step=ms, frames_per_s=B * 1e3 / ms, loss_first=float(losses[0]), loss_last=float(losses[-1]),

@@ -150,16 +150,21 @@ class Pointnet2MSG(nn.Module):
 
     def forward(self, pointcloud, geometry=None):
         """pointcloud (B, N, 3 + input_channels) -> per-point features (B, 128, N).
-        geometry: optional handle from ``geometry_ahead(pointcloud)`` (inference fast path only)."""
+        geometry: optional handle from ``geometry_ahead(pointcloud)``: the xyz-only work (FPS, ball query, three_nn) of
+        THIS cloud, enqueued earlier on the geometry stream -- by an evaluator for the next batch, or by a training loop
+        for the next step's batch while the current step's backward runs (train_step.py's ``prefetch``).  The indices
+        are what an inline run would compute (no parameters are involved), so training results do not change."""
         xyz, features = self._break_up_pc(pointcloud)
         if features is not None and not self.training and _pm.FUSED_INFERENCE and not torch.is_grad_enabled():
             features = pointcloud[..., 3:].transpose(1, 2)   # same values, point-major in place
         ahead = (GEOMETRY_STREAM and _pm.FUSED_INFERENCE and not self.training and xyz.is_cuda
                  and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]
+        if geometry is not None and not ahead and not (self.training and xyz.is_cuda and GEOMETRY_STREAM):
+            raise RuntimeError("a geometry handle is used by the eval fast path (GEOMETRY_STREAM, FUSED_INFERENCE, no "
+                               "autograd) and by training on CUDA: drop it or change the mode")
         if geometry is not None and not ahead:
-            raise RuntimeError("a geometry handle is only used by the eval fast path (GEOMETRY_STREAM, "
-                               "FUSED_INFERENCE, no autograd): drop it or switch the module to eval / no_grad")
+            ahead = True                   # training with a handle prepared ahead (train_step's prefetch)
         if not ahead:
             nest = None
             for li, sa in enumerate(self.SA_modules):

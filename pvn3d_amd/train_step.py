@@ -42,8 +42,8 @@ class PointVoteNet(nn.Module):
         self.ctr_head = nn.Sequential(nn.Conv1d(128, width, 1), nn.BatchNorm1d(width), nn.ReLU(inplace=True),
                                       nn.Conv1d(width, 3, 1))
 
-    def forward(self, pointcloud):
-        feats = self.backbone(pointcloud)                      # (B, 128, N)
+    def forward(self, pointcloud, geometry=None):
+        feats = self.backbone(pointcloud, geometry=geometry)   # (B, 128, N)
         B, _, N = feats.shape
         kp = self.kp_head(feats).view(B, self.n_kps, 3, N).permute(0, 1, 3, 2).contiguous()
         ctr = self.ctr_head(feats).view(B, 1, 3, N).permute(0, 1, 3, 2).contiguous()
@@ -56,18 +56,34 @@ def vote_loss(pred_kp_of, pred_ctr_of, kp_targ_ofst, ctr_targ_ofst, labels):
     return crit(pred_kp_of, kp_targ_ofst, labels).sum() + crit(pred_ctr_of, ctr_targ_ofst, labels).sum()
 
 
-def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_bytes=64 << 20):
+def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_bytes=64 << 20, prefetch=None):
     """forward + vote loss + backward + gradient all-reduce + optimizer step.  batch: dict(pc (B,N,3+C),
-    kp_targ_ofst (B,N,K,3), ctr_targ_ofst (B,N,1,3), labels (B,N,1)).  Returns the (detached) loss."""
+    kp_targ_ofst (B,N,K,3), ctr_targ_ofst (B,N,1,3), labels (B,N,1)).  Returns the (detached) loss.
+
+    prefetch: the NEXT step's point-cloud tensor (the data loader has it while this step runs).  Its xyz-only work --
+    furthest point sampling, ball queries, three_nn: no parameters involved -- is enqueued on the geometry stream
+    under this step's backward (FPS is one workgroup per cloud: 1.5 ms during which most of the chip idles) and the
+    next call picks the handle up when it is handed the same tensor, unmodified."""
     model.train()
     optimizer.zero_grad(set_to_none=True)
+    pc = batch["pc"]
+    geo = None
+    held = getattr(model, "_geometry_prefetched", None)
+    if held is not None:
+        model._geometry_prefetched = None
+        if held[0] == (pc.data_ptr(), tuple(pc.shape), pc._version):
+            geo = held[1]
     if autocast_dtype is not None:
         with torch.autocast(device_type="cuda", dtype=autocast_dtype):
-            kp, ctr = model(batch["pc"])
+            kp, ctr = model(pc, geometry=geo)
             loss = vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
     else:
-        kp, ctr = model(batch["pc"])
+        kp, ctr = model(pc, geometry=geo)
         loss = vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
+    if prefetch is not None and prefetch.is_cuda:
+        with torch.no_grad():
+            model._geometry_prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape), prefetch._version),
+                                          model.backbone.geometry_ahead(prefetch))
     loss.backward()
     sharding.all_reduce_gradients(model.parameters(), bucket_bytes=bucket_bytes, group=group)
     optimizer.step()

@@ -852,6 +852,18 @@ def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     losses = [ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16).item() for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # geometry prepared ahead (train_step's prefetch): the same indices as the inline run, so the training-mode forward
+    # is bit-identical; a handle for another tensor is ignored
+    model.train()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        kp_a, ctr_a = model(batch["pc"])
+        handle = model.backbone.geometry_ahead(batch["pc"])
+        kp_b, ctr_b = model(batch["pc"], geometry=handle)
+    assert torch.equal(kp_a, kp_b) and torch.equal(ctr_a, ctr_b)
+    l0 = ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16, prefetch=batch["pc"])
+    assert model._geometry_prefetched is not None
+    l1 = ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16)            # consumes the handle
+    assert model._geometry_prefetched is None and np.isfinite(l0.item()) and np.isfinite(l1.item())
 
 
 def test_small_batch_layerwise_path_matches_fused_chain(dev):

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--prefetch", action="store_true", help="enqueue the next step's geometry under this step's backward")
     ap.add_argument("--library-mlp", action="store_true",
                     help="SharedMLP through torch Conv2d / BatchNorm2d (MIOpen / hipBLASLt) instead of csrc/mlp_train.hip")
     args = ap.parse_args()
@@ -30,11 +31,11 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     dt = torch.bfloat16 if args.dtype == "bf16" else None
     for _ in range(2):
-        ts.train_step(model, opt, batch, autocast_dtype=dt)
+        ts.train_step(model, opt, batch, autocast_dtype=dt, prefetch=batch["pc"] if args.prefetch else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = ts.train_step(model, opt, batch, autocast_dtype=dt)
+        loss = ts.train_step(model, opt, batch, autocast_dtype=dt, prefetch=batch["pc"] if args.prefetch else None)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     print("train_step %s: %.2f ms / step of %d frames = %.1f frames/s, loss %.3f" %
