@@ -305,13 +305,22 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
 #pragma unroll
   for (int w = 0; w < NACC; ++w) acc[w].w = acc[w].x = acc[w].y = acc[w].z = ms_splat(0.f);
 
+  // The next chunk's points are requested (clamped address, unconditional) before the current chunk is walked: when
+  // only a few workgroups still run -- the long tail of a heavy-tailed batch -- a launch lasts as long as ONE
+  // workgroup, and six exposed global round trips (3072 points) were a third of that.
+  constexpr int PPT = MS_CHUNK / MS_THREADS;
+  float4 pre[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) pre[u] = pts[base + min(tid + u * MS_THREADS, n - 1)];
   for (int j0 = 0; j0 < n; j0 += MS_CHUNK) {
     const int cnt = min(MS_CHUNK, n - j0);
     __syncthreads();
-    for (int q = tid; q < MS_CHUNK; q += MS_THREADS) {
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int q = tid + u * MS_THREADS;
       float4 a;
       if (q < cnt) {
-        const float4 r = pts[base + j0 + q];
+        const float4 r = pre[u];
         const float ax = (r.x - org.x) * kappa, ay = (r.y - org.y) * kappa,
                     az = (r.z - org.z) * kappa;
         a = make_float4(ax, ay, az, -fmaf(az, az, fmaf(ay, ay, ax * ax)));   // w = -|a'|^2
@@ -319,6 +328,10 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
         a = make_float4(0.f, 0.f, 0.f, -1e30f);  // exp2(-huge) == 0: padded rows weigh 0
       }
       s_pts[q] = a;
+    }
+    if (j0 + MS_CHUNK < n) {
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) pre[u] = pts[base + min(j0 + MS_CHUNK + tid + u * MS_THREADS, n - 1)];
     }
     __syncthreads();
     const int cnt4 = (cnt + 3) & ~3;
