@@ -15,7 +15,11 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 16, 16), (1000, 70, 112), (257, 200, 528), (4096, 512, 272), (129, 33, 32),
-                                   (64, 384, 64)])
+                                   (64, 384, 64),
+                                   # the streaming kernel (K <= 128, <= 128 columns, M >= 4096): every column-block count,
+                                   # odd K step counts, ragged M
+                                   (5000, 16, 16), (4099, 32, 32), (70001, 64, 32), (9000, 96, 112), (4500, 128, 128),
+                                   (12345, 33, 48), (8192, 100, 80)])
 def test_gemm_nt_matches_torch(dev, M, N, K):
     from pvn3d_amd._lib import lib, check
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
