@@ -79,7 +79,7 @@ __device__ __forceinline__ void load8f(const float* __restrict__ p, float (&v)[8
 // each, K in chunks of 32 through double-buffered LDS (row stride 40 elements = 80 B: sixteen consecutive rows
 // land in sixteen different 16-byte bank groups for the ds_read_b128 fragment loads).
 // EPI 0: C bf16 [M][ldc] (pad columns < ldc written as the zeros they accumulate) and, if stat_sum != nullptr,
-//        stat_sum / stat_sq [gridDim.x][stat_ld] = per-tile column sums of c and c^2 (fp32 accumulators).
+//        stat_sum / stat_sq [row workers][stat_ld] = per-tile column sums of c and c^2 (fp32 accumulators).
 // EPI 1: C fp32 [M][ldc], atomicAdd (split-K: blockIdx.z owns K range [z*klen, (z+1)*klen)).
 constexpr int GEMM_LDS_STRIDE = 40;
 constexpr int GEMM_MAX_GX = 1024;      // row-tile workgroups (each loops over its tiles; bounds the partial statistics)
@@ -89,7 +89,14 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
                                                          const bf16_t* __restrict__ B, int ldb, void* __restrict__ Cv,
                                                          int ldc, float* __restrict__ stat_sum,
                                                          float* __restrict__ stat_sq, int stat_ld, int klen) {
-  constexpr int NB = NT / 32;                 // 32-column blocks per wave
+  // Wave layout inside the 128 x NT tile.  NT <= 128: four waves stacked along M, a wave = 32 rows x NT columns.
+  // NT = 256: 2 x 2 waves, a wave = 64 rows x 128 columns -- per 32-wide K chunk a wave then reads 4 + 8 fragment
+  // vectors from LDS instead of 2 + 16 (the B tile is no longer re-read by all four waves): the 256-column tile was
+  // bound by LDS fragment reads (72 KB per chunk and workgroup against 512 MFMA cycles).
+  constexpr bool W22 = NT == 256;
+  constexpr int RB = W22 ? 2 : 1;             // 32-row blocks per wave
+  constexpr int NB = W22 ? 4 : NT / 32;       // 32-column blocks per wave
+  constexpr int WCOLS = 32 * NB;              // columns per wave
   constexpr int BL = (NT * 4 + 255) / 256;    // 16-byte B loads per thread and chunk
   // one allocation: [2][128 x 40] A chunks, [2][NT x 40] B chunks; the bf16 epilogue reuses it as four per-wave
   // [32 rows][EC + 8] patches (EC = min(NT, 128) columns per pass)
@@ -97,6 +104,10 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
   bf16_t (*sA)[128 * GEMM_LDS_STRIDE] = reinterpret_cast<bf16_t (*)[128 * GEMM_LDS_STRIDE]>(smem);
   bf16_t (*sB)[NT * GEMM_LDS_STRIDE] = reinterpret_cast<bf16_t (*)[NT * GEMM_LDS_STRIDE]>(smem + 2 * 128 * GEMM_LDS_STRIDE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = W22 ? (wave & 1) * 64 : wave * 32;      // this wave's first row / column inside the tile
+  const int wcol = W22 ? (wave >> 1) * 128 : 0;
+  // (grid (row workers, column tiles, K slices); column tiles in x -- adjacent in launch order, to share the A rows
+  // through L2 -- measured 4 % slower per step)
   const int n0 = blockIdx.y * NT;
   const int kb = blockIdx.z * klen, ke = min(K, kb + klen);
   const int nchunks = (ke - kb + 31) / 32;
@@ -107,141 +118,171 @@ __global__ __launch_bounds__(256) void mt_gemm_nt_kernel(int M, int N, int K, co
 
   // (requesting chunk 0 of the next row tile under the current tile's epilogue was measured: no gain for K <= 64 --
   // the co-resident workgroups already cover the round trip -- and 5-25 % slower for the 256-column tiles)
-  uint4 ra[2], rb[BL];
-  auto gload = [&](int m0, int c) {
-    const int k0 = kb + c * 32;
+  // Two chunks in flight: chunk c + 2 is requested at the top of iteration c (into the register set c & 1) and moves to
+  // LDS at the bottom of iteration c + 1 -- with one chunk ahead a K loop of 4 - 17 chunks waited for a cold global
+  // round trip in every iteration (the 16 MFMAs of a chunk are 0.2 us).
+  uint4 rA[2][2], rB[2][BL];
+  // (every load is issued unconditionally at a clamped address and zeroed by a select afterwards: a guarded load
+  // compiles to a branch, and across those branches the compiler falls back to s_waitcnt vmcnt(0) -- which waited for
+  // the prefetched chunk in every iteration and made the loop a chain of exposed global round trips)
+  auto gload = [&](int m0, int c, uint4 (&ra)[2], uint4 (&rb)[BL]) {
+    const int k = kb + c * 32 + (tid & 3) * 8;
+    const int kc = k < ke ? k : 0;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = (tid >> 2) + p * 64, seg = tid & 3;
-      const int k = k0 + seg * 8;
-      ra[p] = (m0 + row < M && k < ke) ? *reinterpret_cast<const uint4*>(A + (size_t)(m0 + row) * lda + k)
-                                       : make_uint4(0, 0, 0, 0);
-    }
+    for (int p = 0; p < 2; ++p)
+      ra[p] = *reinterpret_cast<const uint4*>(A + (size_t)min(m0 + (tid >> 2) + p * 64, M - 1) * lda + kc);
 #pragma unroll
-    for (int p = 0; p < BL; ++p) {
-      const int t = tid + p * 256;
-      const int row = t >> 2, seg = t & 3;
-      const int k = k0 + seg * 8;
-      rb[p] = (row < NT && n0 + row < N && k < ke) ? *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * ldb + k)
-                                                  : make_uint4(0, 0, 0, 0);
-    }
+    for (int p = 0; p < BL; ++p)
+      rb[p] = *reinterpret_cast<const uint4*>(B + (size_t)min(n0 + ((tid + p * 256) >> 2), N - 1) * ldb + kc);
   };
-  auto lstore = [&](int buf) {
+  // out-of-range rows / k read a clamped address; they are zeroed HERE, when the registers move to LDS (an AND with a
+  // mask: masking at load time would wait for the load at once, a select would be turned back into a guarded load)
+  auto lstore = [&](int buf, int m0, int c, const uint4 (&ra)[2], const uint4 (&rb)[BL]) {
+    const int seg = tid & 3;
+    const bool kok = kb + c * 32 + seg * 8 < ke;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int row = (tid >> 2) + p * 64, seg = tid & 3;
-      *reinterpret_cast<uint4*>(&sA[buf][row * GEMM_LDS_STRIDE + seg * 8]) = ra[p];
+      const int row = (tid >> 2) + p * 64;
+      const unsigned mk = (kok && m0 + row < M) ? 0xffffffffu : 0u;
+      *reinterpret_cast<uint4*>(&sA[buf][row * GEMM_LDS_STRIDE + seg * 8]) =
+          make_uint4(ra[p].x & mk, ra[p].y & mk, ra[p].z & mk, ra[p].w & mk);
     }
 #pragma unroll
     for (int p = 0; p < BL; ++p) {
-      const int t = tid + p * 256;
-      const int row = t >> 2, seg = t & 3;
-      if (row < NT) *reinterpret_cast<uint4*>(&sB[buf][row * GEMM_LDS_STRIDE + seg * 8]) = rb[p];
+      const int row = (tid + p * 256) >> 2;
+      const unsigned mk = (kok && n0 + row < N) ? 0xffffffffu : 0u;
+      if (row < NT)
+        *reinterpret_cast<uint4*>(&sB[buf][row * GEMM_LDS_STRIDE + seg * 8]) =
+            make_uint4(rb[p].x & mk, rb[p].y & mk, rb[p].z & mk, rb[p].w & mk);
     }
   };
   for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
   const int m0 = mt * 128;
-  f32x16 acc[NB];
+  f32x16 acc[RB][NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i)
+  for (int j = 0; j < RB; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   if (nchunks > 0) {
-    gload(m0, 0);
+    gload(m0, 0, rA[0], rB[0]);
+    if (nchunks > 1) gload(m0, 1, rA[1], rB[1]);
     __syncthreads();           // (the previous tile's patch / fragment reads are done)
-    lstore(0);
+    lstore(0, m0, 0, rA[0], rB[0]);
     __syncthreads();
   }
-  for (int c = 0; c < nchunks; ++c) {
+  auto chunk = [&](int c, uint4 (&ra_next2)[2], uint4 (&rb_next2)[BL], const uint4 (&ra_next)[2], const uint4 (&rb_next)[BL]) {
+    // LDS holds chunk c in buffer c & 1; (ra_next, rb_next) hold chunk c + 1; (ra_next2, rb_next2) = the set chunk c
+    // came from, free again: chunk c + 2 goes there
     const int buf = c & 1;
-    if (c + 1 < nchunks) gload(m0, c + 1);
+    if (c + 2 < nchunks) gload(m0, c + 2, ra_next2, rb_next2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ko = ks * 16 + (lane >> 5) * 8;
-      const bf16x8 a = __builtin_bit_cast(
-          bf16x8, *reinterpret_cast<const uint4*>(&sA[buf][(wave * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
+      bf16x8 a[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        a[j] = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const uint4*>(&sA[buf][(wrow + j * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const bf16x8 b = __builtin_bit_cast(
-            bf16x8, *reinterpret_cast<const uint4*>(&sB[buf][(nb * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+            bf16x8, *reinterpret_cast<const uint4*>(&sB[buf][(wcol + nb * 32 + (lane & 31)) * GEMM_LDS_STRIDE + ko]));
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b, acc[j][nb], 0, 0, 0);
       }
     }
-    if (c + 1 < nchunks) lstore(buf ^ 1);
+    if (c + 1 < nchunks) lstore(buf ^ 1, m0, c + 1, ra_next, rb_next);
     __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk(c, rA[0], rB[0], rA[1], rB[1]);
+    if (c + 1 < nchunks) chunk(c + 1, rA[1], rB[1], rA[0], rB[0]);
   }
 
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int rbase = m0 + wave * 32 + 4 * (lane >> 5);
   if (EPI == 0) {
     // The accumulators hold one column per lane (2-byte stores, 128 B per wave instruction); the tile goes
     // through a per-wave LDS patch instead and leaves as 16-byte row-contiguous stores.
     bf16_t* C = reinterpret_cast<bf16_t*>(Cv);
-    constexpr int EC = NT < 128 ? NT : 128;       // columns per pass
+    constexpr int EC = WCOLS < 128 ? WCOLS : 128; // columns per pass
     constexpr int PS = EC + 8;                    // patch row stride (elements): 16-byte aligned rows
     constexpr int SEG = EC / 8;                   // 16-byte segments per row
     static_assert(4 * 32 * PS <= 2 * (128 + NT) * GEMM_LDS_STRIDE, "patch fits the chunk buffers");
     bf16_t* patch = smem + wave * 32 * PS;
 #pragma unroll
-    for (int pass = 0; pass < NT / EC; ++pass) {
+    for (int j = 0; j < RB; ++j) {
 #pragma unroll
-      for (int nbl = 0; nbl < EC / 32; ++nbl) {
-        const int nb = pass * (EC / 32) + nbl;
+      for (int pass = 0; pass < WCOLS / EC; ++pass) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PS + nbl * 32 + (lane & 31)] = f2bf(acc[nb][r]);
-        if (stat_sum) {
+        for (int nbl = 0; nbl < EC / 32; ++nbl) {
+          const int nb = pass * (EC / 32) + nbl;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { tsum[nb] += acc[nb][r]; tsq[nb] += acc[nb][r] * acc[nb][r]; }
+          for (int r = 0; r < 16; ++r)
+            patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PS + nbl * 32 + (lane & 31)] = f2bf(acc[j][nb][r]);
+          if (stat_sum) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tsum[nb] += acc[j][nb][r]; tsq[nb] += acc[j][nb][r] * acc[j][nb][r]; }
+          }
         }
-      }
-      __syncthreads();
-      const int cbase = n0 + pass * EC;
+        __syncthreads();
+        const int cbase = n0 + wcol + pass * EC;
 #pragma unroll
-      for (int it = 0; it < (32 * SEG) / 64; ++it) {
-        const int q = it * 64 + lane;
-        const int rr = q / SEG, seg = q % SEG;
-        const int row = m0 + wave * 32 + rr, col = cbase + seg * 8;
-        if (row < M && col < ldc)
-          *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = *reinterpret_cast<const uint4*>(patch + rr * PS + seg * 8);
+        for (int it = 0; it < (32 * SEG) / 64; ++it) {
+          const int q = it * 64 + lane;
+          const int rr = q / SEG, seg = q % SEG;
+          const int row = m0 + wrow + j * 32 + rr, col = cbase + seg * 8;
+          if (row < M && col < ldc)
+            *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = *reinterpret_cast<const uint4*>(patch + rr * PS + seg * 8);
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   } else {
     float* C = reinterpret_cast<float*>(Cv);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int col = n0 + nb * 32 + (lane & 31);
-      if (col < N) {
+    for (int j = 0; j < RB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < M) atomicAdd(&C[(size_t)row * ldc + col], acc[nb][r]);
+      for (int nb = 0; nb < NB; ++nb) {
+        const int col = n0 + wcol + nb * 32 + (lane & 31);
+        if (col < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wrow + j * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+            if (row < M) atomicAdd(&C[(size_t)row * ldc + col], acc[j][nb][r]);
+          }
         }
       }
-    }
   }
   }   // row tiles
 
   if (EPI == 0 && stat_sum) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(&sA[0][0]);     // [2][4][NT] floats <= 8 KiB
+    float* red = reinterpret_cast<float*>(&sA[0][0]);     // [2][4][WCOLS] floats <= 8 KiB
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       float s = tsum[nb], q = tsq[nb];
       s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 32, 64);
       if (lane < 32) {
-        red[(0 * 4 + wave) * NT + nb * 32 + lane] = s;
-        red[(1 * 4 + wave) * NT + nb * 32 + lane] = q;
+        red[(0 * 4 + wave) * WCOLS + nb * 32 + lane] = s;
+        red[(1 * 4 + wave) * WCOLS + nb * 32 + lane] = q;
       }
     }
     __syncthreads();
     for (int t = tid; t < NT; t += 256) {
       if (n0 + t < stat_ld) {
-        const float s = (red[0 * NT + t] + red[1 * NT + t]) + (red[2 * NT + t] + red[3 * NT + t]);
-        const float q = (red[4 * NT + t] + red[5 * NT + t]) + (red[6 * NT + t] + red[7 * NT + t]);
+        float s, q;
+        if (W22) {                                        // column t belongs to the waves (0 | 1) + 2 * (t / 128)
+          const int w0 = 2 * (t >> 7), c = t & 127;
+          s = red[(0 * 4 + w0) * WCOLS + c] + red[(0 * 4 + w0 + 1) * WCOLS + c];
+          q = red[(1 * 4 + w0) * WCOLS + c] + red[(1 * 4 + w0 + 1) * WCOLS + c];
+        } else {
+          s = (red[0 * NT + t] + red[1 * NT + t]) + (red[2 * NT + t] + red[3 * NT + t]);
+          q = (red[4 * NT + t] + red[5 * NT + t]) + (red[6 * NT + t] + red[7 * NT + t]);
+        }
         stat_sum[(size_t)blockIdx.x * stat_ld + n0 + t] = s;
         stat_sq[(size_t)blockIdx.x * stat_ld + n0 + t] = q;
       }
@@ -262,7 +303,10 @@ int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* 
                      M, N, K, A, lda, B, ldb, C, ldc, ssum, ssq, stat_ld, klen)
   if (ncols <= 32) MT_GEMM(32);
   else if (ncols <= 64) MT_GEMM(64);
-  else if (ncols <= 128 || (ncols > 256 && ncols <= 384)) MT_GEMM(128);
+  // bf16 outputs wider than 128 columns also take 128-column tiles: the 256-column tile keeps 128 accumulator
+  // registers on top of ~170 others, i.e. ONE wave per SIMD, and nothing overlaps its load -> barrier -> MFMA -> store
+  // phases (measured 10 - 20 % slower on every wide shape; A is re-read once per column tile, mostly from L2)
+  else if (ncols <= 128 || EPI == 0) MT_GEMM(128);
   else MT_GEMM(256);
 #undef MT_GEMM
   PVN3D_LAUNCH_CHECK();
