@@ -302,7 +302,7 @@ int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* 
   hipLaunchKernelGGL((mt_gemm_nt_kernel<NT, EPI>), dim3(gx, pvn3d_ceil_div(ncols, NT), gz), dim3(256), 0, st, \
                      M, N, K, A, lda, B, ldb, C, ldc, ssum, ssq, stat_ld, klen)
   if (ncols <= 32) MT_GEMM(32);
-  else if (ncols <= 64) MT_GEMM(64);
+  else if (ncols <= 64) MT_GEMM(64);                 // (64-column tiles for wider outputs: 2 % slower per step)
   // bf16 outputs wider than 128 columns also take 128-column tiles: the 256-column tile keeps 128 accumulator
   // registers on top of ~170 others, i.e. ONE wave per SIMD, and nothing overlaps its load -> barrier -> MFMA -> store
   // phases (measured 10 - 20 % slower on every wide shape; A is re-read once per column tile, mostly from L2)
