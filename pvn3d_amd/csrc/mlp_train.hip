@@ -327,8 +327,7 @@ int launch_gemm_nt(int M, int N, int K, const bf16_t* A, int lda, const bf16_t* 
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void mt_wgrad_tn_kernel(long long rows, int M, int N, const bf16_t* __restrict__ dY,
                                                           int ldy, const bf16_t* __restrict__ H, int ldh,
-                                                          float* __restrict__ dW, int ldw, int tiles_n,
-                                                          int steps_per_wave) {
+                                                          float* __restrict__ dW, int ldw, int tiles_n) {
   constexpr int SA = 32 * MB + 8, SB = 32 * NB + 8;             // patch row strides (elements)
   constexpr int PATCH = 16 * (SA + SB);                         // one step of one wave
   constexpr int TILE_F = 32 * MB * 32 * NB;                     // floats of the output tile
@@ -343,7 +342,6 @@ __global__ __launch_bounds__(256) void mt_wgrad_tn_kernel(long long rows, int M,
   const long long W = (long long)gridDim.y * 4;
   const long long s_begin = (long long)blockIdx.y * 4 + wave;
   const long long s_end = total_steps;
-  (void)steps_per_wave;
   f32x16 acc[MB][NB];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
@@ -1180,7 +1178,7 @@ extern "C" int pvn3d_mt_wgrad_tn(long long rows, int M, int N, const void* dY, i
   const dim3 grid(tiles_m * tiles_n, (unsigned)((workers + 3) / 4));
 #define MT_WG(MB_, NB_)                                                                                             \
   hipLaunchKernelGGL((mt_wgrad_tn_kernel<MB_, NB_>), grid, dim3(256), 0, MT_ST, rows, M, N, (const bf16_t*)dY, ldy,  \
-                     (const bf16_t*)H, ldh, dW, ldw, tiles_n, (int)spw)
+                     (const bf16_t*)H, ldh, dW, ldw, tiles_n)
   if (MB == 1 && NB == 1) MT_WG(1, 1);
   else if (MB == 1 && NB == 2) MT_WG(1, 2);
   else if (MB == 1 && NB == 4) MT_WG(1, 4);
