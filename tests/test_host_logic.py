@@ -207,3 +207,27 @@ def test_obj_kps_fixture_equals_reference_text_files():
 
 
 OBJ_KPS_SHA256 = "d037d40a5cdbae7d2fab25de91655a731d9df33ee162a8f9a496906be18f2301"
+
+
+def test_training_chain_only_takes_the_reference_shared_mlp_form():
+    """_train_mlp.shared_mlp_layers: the hand-written training kernels take over exactly the layer form PVN3D builds
+    ([1x1 Conv2d without bias] -> BatchNorm2d (affine, running stats) -> ReLU, pytorch_utils.py:25-50); anything else
+    makes the module fall back to the torch composition."""
+    from pvn3d_amd.lib.pointnet2_utils import _train_mlp
+    from pvn3d_amd.lib.pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPModule
+    from pvn3d_amd.lib.utils import pytorch_utils as pt_utils
+    sa = PointnetSAModuleMSG(npoint=16, radii=[0.1], nsamples=[4], mlps=[[6, 16, 32]], use_xyz=True)
+    layers = _train_mlp.shared_mlp_layers(sa.mlps[0])
+    assert layers is not None and [c.out_channels for c, _ in layers] == [16, 32]
+    assert all(isinstance(b, torch.nn.BatchNorm2d) for _, b in layers)
+    fp = PointnetFPModule(mlp=[32, 16, 16])
+    assert len(_train_mlp.shared_mlp_layers(fp.mlp)) == 2
+    assert _train_mlp.shared_mlp_layers(pt_utils.SharedMLP([8, 16], bn=False)) is None            # no BatchNorm (conv bias)
+    assert _train_mlp.shared_mlp_layers(pt_utils.SharedMLP([8, 16], bn=True, activation=torch.nn.Tanh())) is None
+    odd = pt_utils.SharedMLP([8, 16], bn=True)
+    for m in odd.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = None                                                                   # cumulative average
+    assert _train_mlp.shared_mlp_layers(odd) is None
+    # the row-stride rule of the bf16 matrices: channels rounded up to 16
+    assert [_train_mlp._ld(c) for c in (1, 9, 16, 17, 259, 515)] == [16, 16, 16, 32, 272, 528]
