@@ -40,3 +40,32 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--steps", "1"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The newest committed bench line (profiles/rNN_bench_default.json, produced on an MI355X by `python bench.py`)
+    carries every field of the driver's contract, a roofline whose fraction is achieved / peak, a CPU baseline with its
+    core count, and the BASELINE configs as parity / latency cases -- and nothing claims a published baseline."""
+    import glob
+    import json
+    import os
+    from conftest import ROOT
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert lines, "no committed bench line"
+    d = json.load(open(lines[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    frames = d["config"]["frames_per_step_all_gpus"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r.get("traffic_measured_in_run") is False          # PMC traffic is pasted from a separate profile, and says so
+    for name, rr in d["rooflines"].items():
+        assert rr["bound"] in ("hbm", "mfma", "valu", "valu_fp32"), name
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    names = {c["name"] for c in d["configs"]}
+    assert {"b1_latency", "ycb_multi_instance", "config1_n2048", "train_step", "heavy_tail_votes"} <= names
