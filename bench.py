@@ -484,7 +484,7 @@ def extra_configs(net, dev, poll_every, with_cpu):
             ms = _median_ms(lambda: losses.append(ts.train_step(model, opt, batch, autocast_dtype=dt,
                                                                 prefetch=batch["pc"] if pre else None)), 5, warm=2)
         finally:
-            _train_mlp.TRAIN_FUSED = True
+            _train_mlp.TRAIN_FUSED = "auto"
         entry[tag] = dict(ms_per_step=ms, frames_per_s=B * 1e3 / ms, loss_first=float(losses[0]), loss_last=float(losses[-1]),
                           peak_mem_gb=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
         del model, opt
@@ -492,6 +492,24 @@ def extra_configs(net, dev, poll_every, with_cpu):
         torch.cuda.reset_peak_memory_stats(dev)
     out.append(entry)
     return out
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: re-execute this command line as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 with a free port, stream rank 0's JSON line through, return the exit code.
+    (The driver's own form, `python -m torch.distributed.run ... bench.py --gpus N`, sets WORLD_SIZE and never comes
+    here.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -514,20 +532,42 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="--frames is the TOTAL per step, split over the ranks (BASELINE config 4: 64 frames sharded)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (N=1 only)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch + init_process_group + one all-reduce, then exit (checks the N > 1 launch path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, same flags
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node == --gpus, or without a "
+                         "launcher: bench.py starts its own ranks)" % (world, args.gpus))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL needs it on this host driver)
+        # "nccl" IS RCCL on ROCm; the override exists for the CPU test of the launch path (gloo, no GPU)
+        dist.init_process_group(os.environ.get("PVN3D_BENCH_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    if args.rendezvous_only:
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            if dist.get_backend() == "nccl":
+                torch.cuda.set_device(local_rank)
+                t = t.cuda()
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "rank_sum": float(t.item()),
+                              "backend": dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL needs it on this host driver)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     scale = args.n_pts / 12288.0
     from pvn3d_amd import sharding

@@ -18,8 +18,20 @@ import torch.nn as nn
 from ..._lib import lib, check, on_device
 from . import _ext
 
-# False: SA / FP modules in training mode use the reference's op-by-op composition (torch Conv2d / BatchNorm2d).
-TRAIN_FUSED = True
+# Which SharedMLP path SA / FP modules take in training mode:
+#   "auto" (default): the bf16 chain of this file only under ``torch.autocast(device_type="cuda", dtype=torch.bfloat16)``
+#            -- the caller asked for bf16 arithmetic; plain fp32 training (what the reference's scripts do: no AMP in
+#            train_linemod_pvn3d.py:169-212,375) keeps fp32 numerics;
+#   True:    explicit opt-in, the bf16 chain whatever the autocast state;
+#   False:   always the reference's op-by-op composition (torch Conv2d / BatchNorm2d).
+TRAIN_FUSED = "auto"
+
+
+def train_fused_enabled():
+    """-> whether a module in training mode should take the bf16 MFMA chain right now (see TRAIN_FUSED)."""
+    if TRAIN_FUSED == "auto":
+        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    return bool(TRAIN_FUSED)
 
 
 def _stream(t):

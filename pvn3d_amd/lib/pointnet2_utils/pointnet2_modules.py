@@ -135,7 +135,7 @@ class _PointnetSAModuleBase(nn.Module):
             out = self._forward_fused(xyz, new_xyz, features, idxs)
             if out is not None:
                 return new_xyz, out
-        if (_train_mlp.TRAIN_FUSED and self.training and self.npoint is not None and xyz.is_cuda
+        if (_train_mlp.train_fused_enabled() and self.training and self.npoint is not None and xyz.is_cuda
                 and torch.is_grad_enabled() and (features is None or features.dtype == torch.float32)):
             # training: gather -> bf16 MFMA GEMM + BatchNorm(batch statistics) + ReLU chain -> max-pool, forward and
             # backward on the kernels of csrc/mlp_train.hip
@@ -266,7 +266,7 @@ class PointnetFPModule(nn.Module):
                     with _stage("fp_mlp"):
                         return _ext.fp_interp_mlp(known_feats, unknow_feats, idx, weight.contiguous(), packed,
                                                   point_major_out=getattr(self, "_point_major_out", False))
-            if (_train_mlp.TRAIN_FUSED and self.training and known_feats.is_cuda and torch.is_grad_enabled()
+            if (_train_mlp.train_fused_enabled() and self.training and known_feats.is_cuda and torch.is_grad_enabled()
                     and known_feats.dtype == torch.float32
                     and (unknow_feats is None or unknow_feats.dtype == torch.float32)):
                 out = _train_mlp.fp_train(self, unknow_feats, known_feats, idx, weight)

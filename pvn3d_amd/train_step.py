@@ -8,7 +8,9 @@ What runs where:
     BatchNorm with batch statistics -> ReLU, then max-pool) forward and backward: csrc/mlp_train.hip through
     lib/pointnet2_utils/_train_mlp.py -- point-major bf16 activations, one hand-written bf16 MFMA GEMM kernel
     (fp32 accumulate; BatchNorm statistics in its epilogue; split-K for the weight gradient) and fused
-    BatchNorm / ReLU / pool kernels, fp32 master weights (``_train_mlp.TRAIN_FUSED = False`` restores torch
+    BatchNorm / ReLU / pool kernels, fp32 master weights -- taken under ``autocast(bfloat16)`` only (or with the
+    explicit opt-in ``_train_mlp.TRAIN_FUSED = True``); a plain fp32 step, like the reference's, keeps fp32
+    numerics on torch Conv2d / BatchNorm2d (``_train_mlp.TRAIN_FUSED = False`` forces that path, = torch
     Conv2d / BatchNorm2d = MIOpen / hipBLASLt);
   * the two small per-point heads of this file (not part of the reference's hot path): torch Conv1d / BatchNorm1d
     under ``torch.autocast``;
@@ -68,11 +70,14 @@ def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_
     optimizer.zero_grad(set_to_none=True)
     pc = batch["pc"]
     geo = None
-    held = getattr(model, "_geometry_prefetched", None)
+    net = getattr(model, "module", model)        # a DistributedDataParallel / DataParallel wrapper holds the real model
+    held = getattr(net, "_geometry_prefetched", None)
     if held is not None:
-        model._geometry_prefetched = None
-        if held[0] == (pc.data_ptr(), tuple(pc.shape), pc._version):
-            geo = held[1]
+        net._geometry_prefetched = None
+        # the handle belongs to ONE tensor object (kept alive here, so its address cannot be handed to another cloud
+        # by the caching allocator) in the state it had when the geometry was computed
+        if held[0] is pc and held[1] == pc._version:
+            geo = held[2]
     if autocast_dtype is not None:
         with torch.autocast(device_type="cuda", dtype=autocast_dtype):
             kp, ctr = model(pc, geometry=geo)
@@ -82,8 +87,7 @@ def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_
         loss = vote_loss(kp, ctr, batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
     if prefetch is not None and prefetch.is_cuda:
         with torch.no_grad():
-            model._geometry_prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape), prefetch._version),
-                                          model.backbone.geometry_ahead(prefetch))
+            net._geometry_prefetched = (prefetch, prefetch._version, net.backbone.geometry_ahead(prefetch))
     loss.backward()
     sharding.all_reduce_gradients(model.parameters(), bucket_bytes=bucket_bytes, group=group)
     optimizer.step()

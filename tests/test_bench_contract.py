@@ -69,3 +69,23 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     names = {c["name"] for c in d["configs"]}
     assert {"b1_latency", "ycb_multi_instance", "config1_n2048", "train_step", "heavy_tail_votes"} <= names
+
+
+def test_bench_self_launches_its_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no launcher (the form the driver uses for N = 1) starts 2 ranks under
+    torch.distributed.run itself and reaches init_process_group + a collective (gloo here: no GPU); a WORLD_SIZE that
+    disagrees with --gpus is an error message, not an assert."""
+    import json
+    import subprocess
+    py = os.path.join(os.path.dirname(bench.__file__), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PVN3D_BENCH_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, py, "--gpus", "2", "--rendezvous-only", "--strong"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"rendezvous": 2, "rank_sum": 3.0, "backend": "gloo"}
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, py, "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)

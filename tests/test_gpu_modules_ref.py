@@ -1,0 +1,217 @@
+"""Module level pinned to the REFERENCE'S OWN module code.
+
+tests/golden/pointnet2msg_ref.npz was produced by the reference's pointnet2_modules.py / pointnet2_utils.py /
+pytorch_utils.py and its `Pointnet2MSG` class (lib/pvn3d.py:46-154), imported file-level and run on the CPU over
+oracle/_ref (= the reference's *_gpu.cu kernels compiled for the CPU); generator: tests/golden/make_golden_modules.py.
+Here the SAME state_dict is loaded with strict=True into this package's modules and
+  * every level's FPS / ball-query / three_nn indices must be identical,
+  * every level's features (fused fp32-MFMA kernels) must agree within 1e-4 of the level's output scale
+    (the bar of the review; the measured error is ~1e-6, see the tighter bound asserted on the fp64 run),
+  * training-mode outputs, BatchNorm running statistics and autograd gradients of the fp32 path must match the
+    reference's autograd (with REFERENCE_BUG_COMPAT for what the reference's binding really computes,
+    interpolate.cpp:89-93, and without it for the gradient kernel it defines).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from module_weights import weights, weights_sha  # noqa: E402
+
+LEVELS = ["sa0", "sa1", "sa2", "sa3", "fp3", "fp2", "fp1", "fp0"]
+
+
+def _full_state(z):
+    keys = [str(k) for k in z["full_keys"]]
+    shapes = [tuple(int(x) for x in s.split(",")) if s else () for s in (str(v) for v in z["full_shapes"])]
+    w = weights(keys, shapes, int(z["full_seed"]))
+    return keys, shapes, w
+
+
+def test_fixture_state_dict_is_reproducible_and_loads_strict(golden):
+    """CPU: the deterministic state_dict has the recorded SHA-256, and its keys / shapes are exactly this
+    package's Pointnet2MSG state_dict (the reference's checkpoint layout: SA_modules.<i>.mlps.<j>.layer<k>.conv /
+    .normlayer.bn, FP_modules.<i>.mlp.layer<k>...)."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    z = golden("pointnet2msg_ref.npz")
+    keys, shapes, w = _full_state(z)
+    assert weights_sha(keys, w) == str(z["full_sha256"])
+    net = Pointnet2MSG(input_channels=6)
+    sd = net.state_dict()
+    assert list(sd.keys()) == keys
+    assert [tuple(v.shape) for v in sd.values()] == shapes
+    net.load_state_dict({k: torch.from_numpy(np.asarray(w[k])) for k in keys}, strict=True)
+    # the small modules too
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    sa = pm.PointnetSAModuleMSG(npoint=100, radii=[0.03, 0.07], nsamples=[8, 32], mlps=[[5, 16, 24], [5, 8, 40]])
+    fp = pm.PointnetFPModule(mlp=[64 + 5, 48, 32])
+    for name, mod in (("sa", sa), ("fp", fp)):
+        assert list(mod.state_dict().keys()) == [str(k) for k in z["small_%s_keys" % name]]
+
+
+def _load_small(z, dev):
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    sa = pm.PointnetSAModuleMSG(npoint=100, radii=[0.03, 0.07], nsamples=[8, 32], mlps=[[5, 16, 24], [5, 8, 40]])
+    fp = pm.PointnetFPModule(mlp=[64 + 5, 48, 32])
+    for name, mod in (("sa", sa), ("fp", fp)):
+        sd = {str(k): torch.from_numpy(z["small_%s_w/%s" % (name, k)]) for k in z["small_%s_keys" % name]}
+        mod.load_state_dict(sd, strict=True)
+    return sa.to(dev), fp.to(dev)
+
+
+def _close(got, want, tol, what):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, what
+    err = np.abs(got - want).max()
+    scale = max(1.0, np.abs(want).max())
+    assert err <= tol * scale, "%s: max|diff| %.3g vs scale %.3g (tol %.1e)" % (what, err, scale, tol)
+    return err / scale
+
+
+@pytest.mark.gpu
+def test_full_pointnet2msg_against_reference_module_code(dev, golden):
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    z = golden("pointnet2msg_ref.npz")
+    keys, shapes, w = _full_state(z)
+    assert weights_sha(keys, w) == str(z["full_sha256"])
+    net = Pointnet2MSG(input_channels=6)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(w[k])) for k in keys}, strict=True)
+    net = net.to(dev).eval()
+    pc = torch.from_numpy(z["full_pc"]).to(dev)
+
+    # --- indices of every level, as the model itself computes them (the geometry stream path of the fused forward)
+    xyz = pc[..., :3].contiguous()
+    with torch.no_grad():
+        sa_geo, fp_geo = net._geometry_ahead(xyz)
+    torch.cuda.synchronize()
+    lvl_xyz = [z["full_pc"][0, :, :3]]
+    for l in range(4):
+        (new_xyz, idxs), _ = sa_geo[l]
+        sel = z["full_fps%d" % l].astype(np.int64)
+        want_xyz = lvl_xyz[-1][sel]
+        assert np.array_equal(new_xyz[0].cpu().numpy(), want_xyz), "level %d centres (FPS)" % l
+        for s in range(2):
+            assert np.array_equal(idxs[s][0].cpu().numpy().astype(np.int16), z["full_bq%d_%d" % (l, s)]), \
+                "level %d scale %d ball query" % (l, s)
+        lvl_xyz.append(want_xyz)
+    for l in range(4):                      # FP_modules[l]: unknown = level l cloud, known = level l+1 centres
+        (idx, weight), _ = fp_geo[l - 4]
+        assert np.array_equal(idx[0].cpu().numpy().astype(np.int16), z["full_nn%d_idx" % l]), "three_nn level %d" % l
+        d2 = z["full_nn%d_d2" % l].astype(np.float32)
+        rec = (1.0 / (np.sqrt(d2) + np.float32(1e-8))).astype(np.float32)       # pointnet2_modules.py:184-186
+        want_w = rec / rec.sum(1, keepdims=True)
+        assert np.allclose(weight[0].cpu().numpy(), want_w, rtol=1e-5, atol=1e-7)
+
+    # --- features of every level: fused fp32-MFMA forward vs the reference's module code
+    feats = {}
+    hooks = []
+    for i, m in enumerate(net.SA_modules):
+        hooks.append(m.register_forward_hook(lambda mod, a, r, i=i: feats.__setitem__("sa%d" % i, r[1])))
+    for i, m in enumerate(net.FP_modules):
+        hooks.append(m.register_forward_hook(lambda mod, a, r, i=i: feats.__setitem__("fp%d" % i, r)))
+    with torch.no_grad():
+        y = net(pc)
+    for h in hooks:
+        h.remove()
+    assert y.shape == (1, 128, 12288) and y.is_contiguous()
+    assert torch.equal(y, feats["fp0"])
+    worst = {}
+    for name in LEVELS:
+        t = feats[name][0].double().cpu()                              # (C, n)
+        cols = z["full_%s_cols" % name].astype(np.int64)
+        scale = max(1.0, float(np.abs(z["full_%s_vals" % name]).max()))
+        # 32 seeded point columns, all channels: against the reference fp32 run (1e-4, the review's bar) ...
+        e32 = np.abs(t[:, cols].numpy() - z["full_%s_vals" % name]).max() / scale
+        assert e32 <= 1e-4, "%s: %.3g of the output scale vs the reference fp32 run" % (name, e32)
+        # ... and against the float64 run of the same reference code (truth estimate): the fused fp32 chains are as
+        # close to exact arithmetic as the reference's own fp32 convolutions (measured there: <= 9e-7)
+        e64 = np.abs(t[:, cols].numpy() - z["full_%s_vals_f64" % name]).max() / scale
+        assert e64 <= 1e-5, "%s: %.3g of the output scale vs the reference code in float64" % (name, e64)
+        # two projections that cover EVERY element of the level's output
+        for proj, axis in (("chan", 1), ("pt", 0)):
+            got = t.sum(axis).numpy()
+            want = z["full_%s_%s_sum" % (name, proj)]
+            mass = z["full_%s_%s_abs" % (name, proj)]
+            bound = 1e-5 * np.maximum(mass, mass.max() * 1e-3)
+            assert np.all(np.abs(got - want) <= bound), "%s %s-sum projection" % (name, proj)
+        worst[name] = (e32, e64)
+    print("full Pointnet2MSG vs reference module code, rel. max err per level (vs fp32 run, vs fp64 run):",
+          {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()})
+
+    # the op-by-op composition of this package (what the fused path used to be compared with) agrees as well
+    pm.FUSED_INFERENCE = False
+    try:
+        with torch.no_grad():
+            y_u = net(pc)
+    finally:
+        pm.FUSED_INFERENCE = True
+    cols = z["full_fp0_cols"].astype(np.int64)
+    _close(y_u[0].cpu().numpy()[:, cols], z["full_fp0_vals"], 1e-4, "unfused forward vs reference")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_small_ragged_modules_eval_against_reference(dev, golden, fused):
+    """B = 2, N = 777 (not a multiple of anything), npoint = 100, nsample 8 / 32, 5 feature channels: the fused
+    kernels' ragged paths (fused=True) and this package's op-by-op composition (fused=False)."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    z = golden("pointnet2msg_ref.npz")
+    sa, fp = _load_small(z, dev)
+    sa.eval(); fp.eval()
+    xyz, feats = torch.from_numpy(z["small_xyz"]).to(dev), torch.from_numpy(z["small_feats"]).to(dev)
+    pm.FUSED_INFERENCE = fused
+    try:
+        with torch.no_grad():
+            new_xyz, f1 = sa(xyz, feats)
+            y = fp(xyz, new_xyz, feats, f1.contiguous())
+    finally:
+        pm.FUSED_INFERENCE = True
+    assert np.array_equal(new_xyz.cpu().numpy(), z["small_eval_new_xyz"])
+    _close(f1.cpu().numpy(), z["small_eval_sa"], 1e-5, "SA output")
+    _close(y.cpu().numpy(), z["small_eval_fp"], 1e-5, "FP output")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("refbug", [True, False])
+def test_small_modules_training_against_reference_autograd(dev, golden, refbug):
+    """Training mode, fp32 (what the reference's training scripts run: no AMP): outputs with batch statistics,
+    running-statistics update, and every gradient, against the reference's autograd through its own Functions."""
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    z = golden("pointnet2msg_ref.npz")
+    tag = "refbug" if refbug else "fixed"
+    sa, fp = _load_small(z, dev)
+    sa.train(); fp.train()
+    xyz = torch.from_numpy(z["small_xyz"]).to(dev)
+    feats = torch.from_numpy(z["small_feats"]).to(dev).requires_grad_(True)
+    G = torch.from_numpy(z["small_G"]).to(dev)
+    _ext.REFERENCE_BUG_COMPAT = refbug
+    try:
+        new_xyz, f1 = sa(xyz, feats)
+        y = fp(xyz, new_xyz, feats, f1)
+        (y * G).sum().backward()
+    finally:
+        _ext.REFERENCE_BUG_COMPAT = False
+    _close(f1.detach().cpu().numpy(), z["small_train_sa"], 2e-5, "train SA output")
+    _close(y.detach().cpu().numpy(), z["small_train_fp"], 2e-5, "train FP output")
+    for name, mod in (("sa", sa), ("fp", fp)):
+        for k, b in mod.named_buffers():
+            want = z["small_train_buf_%s/%s" % (name, k)]
+            if want.dtype.kind == "i":
+                assert int(b.item()) == int(want)
+            else:
+                _close(b.cpu().numpy(), want, 2e-5, "buffer %s.%s" % (name, k))
+    gnorm = max(float(np.linalg.norm(z[k])) for k in z if k.startswith("small_train_%s_grad_" % tag))
+    for name, mod in (("sa", sa), ("fp", fp)):
+        for k, p in mod.named_parameters():
+            want = z["small_train_%s_grad_%s/%s" % (tag, name, k)]
+            got = p.grad.cpu().numpy()
+            rel = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-4 * gnorm)
+            assert rel <= 1e-4, "grad %s.%s: rel L2 %.3g" % (name, k, rel)
+    want = z["small_train_%s_dfeats" % tag]
+    rel = np.linalg.norm(feats.grad.cpu().numpy() - want) / np.linalg.norm(want)
+    assert rel <= 1e-4, "d(features): rel L2 %.3g" % rel

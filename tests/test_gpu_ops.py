@@ -542,6 +542,49 @@ def test_fused_sa_mlp_against_independent_fp64(dev, orc, c_in, mlps, nsamples, n
     assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("c2,c1,mlp,n,m", [
+    (64, 10, [74, 48, 40], 900, 250),
+    (1024, 512, [1536, 512, 512], 300, 80),          # widths of FP_modules[3] (lib/pvn3d.py:118)
+    (70, 0, [70, 64], 257, 64),
+])
+def test_fused_fp_mlp_against_independent_fp64(dev, orc, c2, c1, mlp, n, m):
+    """The fused three_interpolate -> (++ skip) -> SharedMLP kernel against a float64 numpy evaluation that shares nothing
+    with the package but the module's parameters: three_nn from the C oracle, inverse-distance weights from their
+    definition (pointnet2_modules.py:183-186) in float64 on the fp32 distances, interpolation and the 1x1 convolutions
+    as float64 products, eval BatchNorm from its definition (pytorch_utils.py:25-50).  fp32 MFMA accumulation over
+    K <= 1536 against fp64: 2e-5 of the output scale."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
+    torch.manual_seed(5)
+    fp = pm.PointnetFPModule(mlp=list(mlp)).to(dev).eval()
+    _randomize_bn(fp)
+    unknown_np = clouds(21, 2, n, 0.1)
+    known_np = np.ascontiguousarray(unknown_np[:, :m])
+    g = np.random.default_rng(6)
+    kf_np = g.normal(size=(2, c2, m)).astype(np.float32)
+    uf_np = g.normal(size=(2, c1, n)).astype(np.float32) if c1 else None
+    with torch.no_grad():
+        out = fp(T(unknown_np, dev), T(known_np, dev), T(uf_np, dev) if c1 else None, T(kf_np, dev))
+    d2, idx = orc.three_nn(unknown_np, known_np)
+    dist = np.sqrt(d2.astype(np.float32))                                       # pointnet2_utils.py:126 (fp32 sqrt)
+    rec = (np.float32(1.0) / (dist + np.float32(1e-8))).astype(np.float32)      # fp32 like the module
+    w = (rec / rec.sum(2, keepdims=True)).astype(np.float64)
+    b_ix = np.arange(2)[:, None, None]
+    nb = np.transpose(kf_np, (0, 2, 1))[b_ix, idx].astype(np.float64)           # (B, n, 3, C2)
+    h = (nb * w[..., None]).sum(2)                                              # (B, n, C2)
+    if c1:
+        h = np.concatenate([h, np.transpose(uf_np, (0, 2, 1)).astype(np.float64)], -1)
+    for layer in fp.mlp.children():
+        W = layer.conv.weight.detach().cpu().double().numpy()[:, :, 0, 0]
+        bn = layer.normlayer.bn
+        mu, var = bn.running_mean.cpu().double().numpy(), bn.running_var.cpu().double().numpy()
+        ga, be = bn.weight.detach().cpu().double().numpy(), bn.bias.detach().cpu().double().numpy()
+        h = np.maximum((h @ W.T - mu) / np.sqrt(var + bn.eps) * ga + be, 0.0)
+    want = np.transpose(h, (0, 2, 1))
+    got = out.cpu().double().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
 def test_fused_fp_mlp_and_full_pointnet2msg(dev):
     from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
@@ -572,7 +615,8 @@ def test_fused_fp_mlp_and_full_pointnet2msg(dev):
         finally:
             pm.FUSED_INFERENCE = True
     assert y.shape == (1, 128, 12288)
-    assert (y - y_ref).abs().max().item() < 2e-4 * max(y_ref.abs().max().item(), 1.0)
+    # (the reference-driven pin of this forward is tests/test_gpu_modules_ref.py; eight levels of fp32 chains)
+    assert (y - y_ref).abs().max().item() < 1e-4 * max(y_ref.abs().max().item(), 1.0)
     # geometry run ahead on its own stream (default) == everything on one stream, bit for bit
     from pvn3d_amd.lib import pointnet2_msg
     pointnet2_msg.GEOMETRY_STREAM = False
@@ -832,7 +876,7 @@ def test_training_step_gradients_match_torch_indexing_and_bf16_runs(dev):
         l_nat, g_nat = grads(True)
         l_ref, g_ref = grads(False)
     finally:
-        _train_mlp.TRAIN_FUSED = True
+        _train_mlp.TRAIN_FUSED = "auto"
     assert abs(l_nat - l_ref) <= 1e-4 * abs(l_ref)
     assert len(g_nat) == len(g_ref) > 50
     names = [n for n, p in model.named_parameters() if p.grad is not None]

@@ -174,7 +174,7 @@ def _run_module(mod, fused, fn):
     try:
         return fn(mod)
     finally:
-        _train_mlp.TRAIN_FUSED = True
+        _train_mlp.TRAIN_FUSED = "auto"
 
 
 def test_sa_module_training_matches_torch(dev):
@@ -286,7 +286,7 @@ def test_full_size_training_gradients_vs_torch_autocast(dev):
             loss = ts.vote_loss(kp.float(), ctr.float(), batch["kp_targ_ofst"], batch["ctr_targ_ofst"], batch["labels"])
             loss.backward()
         finally:
-            _train_mlp.TRAIN_FUSED = True
+            _train_mlp.TRAIN_FUSED = "auto"
         res[mode] = (loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     l32, g32 = res["fp32"]
     for mode in ("autocast", "fused"):
