@@ -455,9 +455,23 @@ def extra_configs(net, dev, poll_every, with_cpu):
     res = post(inph)
     it = res["iters"].cpu().numpy().astype(np.float64)
     cnt = res["counts"].cpu().numpy().astype(np.float64)
+    # the same call with the reference's stop rule run to the end (no winner stop): the iteration counts the reference
+    # would run on these votes, the time they cost, and that the poses are the same bits
+    from pvn3d_amd.lib.utils import _vote_engine
+    saved = _vote_engine.DEFAULT_KERNEL
+    _vote_engine.DEFAULT_KERNEL = "nowin"
+    try:
+        ms_full = _median_ms(lambda: post(inph), 3)
+        res_full = post(inph)
+    finally:
+        _vote_engine.DEFAULT_KERNEL = saved
+    itf = res_full["iters"].cpu().numpy().astype(np.float64)
     out.append(dict(name="heavy_tail_votes", workload="config 2 frames with 10 % vote outliers of sigma = 30 cm, 16 frames per call",
                     ms_per_frame=ms / 16, frames_per_s=16e3 / ms,
                     meanshift_iters=dict(min=int(it.min()), max=int(it.max()), mean=float(it.mean())),
+                    meanshift_iters_reference_stop_rule=dict(min=int(itf.min()), max=int(itf.max()), mean=float(itf.mean())),
+                    ms_per_frame_reference_stop_rule=ms_full / 16,
+                    poses_identical_to_reference_stop_rule=bool(torch.equal(res["poses"], res_full["poses"])),
                     valu_tflops_16flop_per_pair=16.0 * float((it * cnt * cnt).sum()) / (ms * 1e-3) / 1e12,
                     pose_err_vs_ground_truth=pose_err(res, fh)))
     # (vi) config 5: one training step of the voting branch, mini_batch_size = 24 (common.py:37), fp32 and bf16

@@ -217,7 +217,8 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * seg_off / seg_cnt are DEVICE int arrays (counts may come from an on-device compaction);
  * max_cnt_host >= every seg_cnt is the host-known bound that sizes the grid.
  * Outputs per segment: ctr (n_seg,3); labels (total) uint8 aligned with pts rows;
- * iters (n_seg) number of mean-shift iterations run (== the reference's `it`).
+ * iters (n_seg) number of mean-shift iterations run (== the reference's `it` under PVN3D_MS_NO_WINNER_STOP;
+ * otherwise <= it, see "Winner stop" below).
  * A segment with cnt == 0 yields ctr = 0, iters = 0.
  * workspace: >= pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter) bytes of device
  * scratch.  poll_host: optional PINNED host int[2] used to stop enqueuing once every fit
@@ -234,7 +235,13 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * Exact early-out: from iteration 5 on, seeds whose update returned their own position bit for bit
  * (fixed points of the iteration function: shift 0 in every later iteration) are dropped from the
  * iterated set every fourth iteration -- same centres, labels and iteration counts, bit for bit;
- * PVN3D_MS_NO_EARLY_OUT iterates every seed every time (tests, A/B timing). */
+ * PVN3D_MS_NO_EARLY_OUT iterates every seed every time (tests, A/B timing).
+ * Winner stop (exact): the output is C[max_idx] only (meanshift_pytorch.py:46-51); max_idx depends on the original
+ * points alone and a seed's trajectory on no other seed.  Once the update of seed max_idx returns its own position
+ * bit for bit (a fixed point of the iteration function) the fit's centre is known; the remaining iterations, which
+ * only wait for slower seeds to pass the reference's stop test, are not run.  PVN3D_MS_NO_WINNER_STOP runs them
+ * (iters == the reference's `it`; tests); the centre is taken from the same record, so both modes return identical
+ * bits.  Fits whose winner never reaches a bitwise fixed point stop by the reference's rule. */
 #define PVN3D_MS_ALIGNED32 1
 #define PVN3D_MS_NO_EARLY_OUT 2
 #define PVN3D_MS_FORCE_SCALAR 4
@@ -246,6 +253,7 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * fused-MLP kernels (which keep the LDS pipe busy); PVN3D_MS_WAVE_CAP(n) bounds the launch to n waves that stride
  * over the work, i.e. chooses how many SIMD wave slots the iterations occupy (0 = one wave per tile). */
 #define PVN3D_MS_SGPR_POINTS 64
+#define PVN3D_MS_NO_WINNER_STOP 128
 #define PVN3D_MS_WAVE_CAP(n) (((n) & 0xfffff) << 8)
 size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
 int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,

@@ -50,6 +50,10 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* act_form;        // [n_seg]  arithmetic form (1 exact, 2 fast) the list was built for
   int* act_idx;         // [total]  per segment: the seeds that are not fixed points under act_form, ascending
   float4* apts;         // [total + 32]  scaled+centred points (x', y', z', -|a'|^2) for the LDS-free iteration kernel
+  // winner record (ms_iter kernels): the position of seed max_idx at the first iteration whose update returned its
+  // own position bit for bit, and that iteration (0: not yet)
+  float4* win_pos;      // [n_seg]
+  int* win_it;          // [n_seg]
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -74,6 +78,8 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_fcm = take(sizeof(unsigned) * (size_t)n_seg);
   const size_t o_acnt = take(sizeof(int) * (size_t)n_seg);
   const size_t o_aform = take(sizeof(int) * (size_t)n_seg);
+  const size_t o_wpos = take(sizeof(float4) * (size_t)n_seg);
+  const size_t o_wit = take(sizeof(int) * (size_t)n_seg);
   if (st) {
     st->cbuf[0] = (float4*)(base + o_c0);
     st->cbuf[1] = (float4*)(base + o_c1);
@@ -91,6 +97,8 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->act_form = (int*)(base + o_aform);
     st->act_idx = (int*)(base + o_aidx);
     st->apts = (float4*)(base + o_apts);
+    st->win_pos = (float4*)(base + o_wpos);
+    st->win_it = (int*)(base + o_wit);
   }
   (void)o_small;
   return off;
@@ -186,6 +194,15 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 //             of an iteration launch once only a few fits are still running (one wave alone needs 74 us
 //             for 3072 points) -- drops four-fold, for four times as many workgroups.  The
 //             default (host side, pvn3d_meanshift_fit_batch).
+// Winner stop (exact): only C[max_idx] reaches the output (meanshift_pytorch.py:46-51), max_idx depends on the
+// ORIGINAL points only (it is computed before the first iteration here), and a seed's trajectory depends on no
+// other seed.  The first time the update of seed max_idx returns its own position bit for bit, that position is
+// recorded (win_pos / win_it): it is a fixed point of the iteration function, every later iteration would return
+// the same bits, so the fit's result is known and its remaining iterations -- which only wait for slower seeds
+// (far outliers creeping towards the mode, tens to hundreds of iterations on heavy-tailed votes) to pass the
+// reference's stop test -- are not run (stop_on_win; without it they run, for the iteration-count parity tests,
+// and the output still comes from the record, so both modes return identical bits).  A fit whose winner never
+// lands on a bitwise fixed point stops by the reference's rule as before.
 // Canonical summation order (all four variants, so that they give identical bits): per seed four
 // partial sums, one per quarter [128 w, 128 w + 128) of every 512-point chunk, each accumulated in
 // point order across the chunks; total = (P0 + P1) + (P2 + P3).
@@ -239,7 +256,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const int* __restrict__ seg_cnt, const float4* __restrict__ cin, float4* __restrict__ cout,
     unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
     int max_iter, float thresh, float kappa, float inv_kappa, unsigned* __restrict__ frozen_cm,
-    const int* __restrict__ act_cnt, const int* __restrict__ act_form, const int* __restrict__ act_idx) {
+    const int* __restrict__ act_cnt, const int* __restrict__ act_form, const int* __restrict__ act_idx,
+    const unsigned long long* __restrict__ best, float4* __restrict__ win_pos, int* __restrict__ win_it,
+    int stop_on_win) {
   constexpr int S = PK ? 2 : 1;
   constexpr int LANES = SPLIT ? 64 : MS_THREADS;     // distinct seed lanes of the workgroup
   __shared__ float4 s_pts[MS_CHUNK];
@@ -254,6 +273,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     const float prev = __uint_as_float(ms[t - 1]);
     if (!(prev >= thresh) || (t - 1) > max_iter) return;  // converged / capped (:42)
   }
+  const int won = win_it[seg];
+  if (stop_on_win && won) return;                         // the result is known (winner stop)
+  const int max_idx = (int)(~(unsigned)(best[seg] & 0xffffffffULL));
   unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
   // The weight exp2(-|c'-a'|^2) = exp2(2c'.a' - |a'|^2) * exp2(-|c'|^2) and the last factor is
   // constant per seed, so it cancels in new_c = sum(w a) / sum(w): when every seed of the fit has
@@ -382,6 +404,10 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
       const bool fixed = nx == cx[s] && ny == cy[s] && nz == cz[s];
       cout[base + i] = make_float4(nx, ny, nz, fixed ? (float)form : 0.f);
       if (fixed) fcm = fmaxf(fcm, ncm);
+      if (fixed && i == max_idx && !won) {       // one thread of one workgroup owns seed max_idx
+        win_pos[seg] = make_float4(nx, ny, nz, 0.f);
+        win_it[seg] = t;
+      }
 #ifdef MS_FROZEN_PROBE
       if (t < 512) {
         atomicAdd(&g_ms_probe[512 + t], 1);
@@ -554,7 +580,8 @@ __global__ __launch_bounds__(64) void ms_iter_sgpr_kernel(
     unsigned* __restrict__ maxshift, unsigned* __restrict__ cmmax, int* __restrict__ iters, int t,
     int max_iter, float thresh, float kappa, float inv_kappa, unsigned* __restrict__ frozen_cm,
     const int* __restrict__ act_cnt, const int* __restrict__ act_form, const int* __restrict__ act_idx,
-    int tiles_per_seg, int n_items) {
+    int tiles_per_seg, int n_items, const unsigned long long* __restrict__ best, float4* __restrict__ win_pos,
+    int* __restrict__ win_it, int stop_on_win) {
   constexpr int S = 2;
   const int sl = threadIdx.x;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -567,6 +594,9 @@ __global__ __launch_bounds__(64) void ms_iter_sgpr_kernel(
       const float prev = __uint_as_float(ms[t - 1]);
       if (!(prev >= thresh) || (t - 1) > max_iter) continue;
     }
+    const int won = win_it[seg];
+    if (stop_on_win && won) continue;
+    const int max_idx = (int)(~(unsigned)(best[seg] & 0xffffffffULL));
     unsigned* cmx = cmmax + (size_t)seg * (max_iter + 2);
     const bool fast = t > 1 && fmaxf(__uint_as_float(cmx[t - 1]), __uint_as_float(frozen_cm[seg])) <= 64.f;
     const int form = fast ? 2 : 1;
@@ -634,6 +664,10 @@ __global__ __launch_bounds__(64) void ms_iter_sgpr_kernel(
         const bool fixed = nx == cx[s] && ny == cy[s] && nz == cz[s];
         cout[base + i] = make_float4(nx, ny, nz, fixed ? (float)form : 0.f);
         if (fixed) fcm = fmaxf(fcm, ncm);
+        if (fixed && i == max_idx && !won) {
+          win_pos[seg] = make_float4(nx, ny, nz, 0.f);
+          win_it[seg] = t;
+        }
       }
     }
 #pragma unroll
@@ -657,7 +691,7 @@ __global__ __launch_bounds__(1024) void ms_compact_kernel(
     const int* __restrict__ seg_off, const int* __restrict__ seg_cnt, const float4* __restrict__ cur,
     const unsigned* __restrict__ maxshift, const unsigned* __restrict__ cmmax,
     const unsigned* __restrict__ frozen_cm, int t, int max_iter, float thresh, int* __restrict__ act_cnt,
-    int* __restrict__ act_form, int* __restrict__ act_idx) {
+    int* __restrict__ act_form, int* __restrict__ act_idx, const int* __restrict__ win_it, int stop_on_win) {
   __shared__ int s_wave[16];
   __shared__ int s_run;
   const int seg = blockIdx.x;
@@ -665,6 +699,7 @@ __global__ __launch_bounds__(1024) void ms_compact_kernel(
   if (n <= 0) return;
   const float prev = __uint_as_float(maxshift[(size_t)seg * (max_iter + 2) + t]);
   if (!(prev >= thresh) || t > max_iter) return;        // no iteration t+1 for this fit
+  if (stop_on_win && win_it[seg]) return;
   const bool fast = fmaxf(__uint_as_float(cmmax[(size_t)seg * (max_iter + 2) + t]),
                           __uint_as_float(frozen_cm[seg])) <= 64.f;
   const float code = fast ? 2.f : 1.f;
@@ -698,7 +733,8 @@ __global__ __launch_bounds__(1024) void ms_compact_kernel(
 // number of fits that would still run iteration t+1.  grid 1, block 256.
 __global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
                                const int* __restrict__ seg_cnt, int n_seg, int t, int max_iter,
-                               float thresh, int* __restrict__ active_slot) {
+                               float thresh, const int* __restrict__ win_it, int stop_on_win,
+                               int* __restrict__ active_slot) {
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
@@ -706,7 +742,7 @@ __global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
   for (int s = threadIdx.x; s < n_seg; s += blockDim.x) {
     if (seg_cnt[s] <= 0) continue;
     const float prev = __uint_as_float(maxshift[(size_t)s * (max_iter + 2) + t]);
-    if (prev >= thresh && t <= max_iter) mine++;
+    if (prev >= thresh && t <= max_iter && !(stop_on_win && win_it[s])) mine++;
   }
   if (mine) atomicAdd(&s_any, mine);
   __syncthreads();
@@ -882,8 +918,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off,
     const int* __restrict__ seg_cnt, const float4* __restrict__ c0,
     const float4* __restrict__ c1, const unsigned long long* __restrict__ best,
-    const int* __restrict__ iters_ws, float d2_max,
-    float inv_kappa, float* __restrict__ ctr, uint8_t* __restrict__ labels,
+    const int* __restrict__ iters_ws, const float4* __restrict__ win_pos, const int* __restrict__ win_it,
+    float d2_max, float inv_kappa, float* __restrict__ ctr, uint8_t* __restrict__ labels,
     int* __restrict__ iters) {
   const int seg = blockIdx.y;
   const int n = seg_cnt[seg];
@@ -909,7 +945,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
   if (blockIdx.x == 0 && tid == 0) {
     const int it = iters_ws[seg];
     const float4 org = pts[base];   // frame origin used by the iterations
-    const float4 m = (it & 1) ? c1[base + max_idx] : c0[base + max_idx];
+    // the winner's recorded fixed point if there is one, else its position after the last iteration run
+    const float4 m = win_it[seg] ? win_pos[seg] : ((it & 1) ? c1[base + max_idx] : c0[base + max_idx]);
     ctr[seg * 3 + 0] = m.x * inv_kappa + org.x;
     ctr[seg * 3 + 1] = m.y * inv_kappa + org.y;
     ctr[seg * 3 + 2] = m.z * inv_kappa + org.z;
@@ -1006,6 +1043,25 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
                        P, seg_off, seg_cnt, kappa, S.apts);
   const dim3 grid_1(pvn3d_ceil_div(max_cnt_host, MS_THREADS), n_seg);
 
+  // max_idx = arg-max of the neighbour counts of the ORIGINAL points (meanshift_pytorch.py:46-49): independent of the
+  // iterations, so it is computed first -- the iteration kernels watch that seed (winner stop, above)
+  {
+    const float r_core = 0.499f * bandwidth;
+    hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
+                       S.core_idx, S.nc_idx, S.n_core);
+    const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
+    hipLaunchKernelGGL(ms_count_pruned_kernel<false>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+    hipLaunchKernelGGL(ms_count_pruned_kernel<true>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+    hipLaunchKernelGGL(ms_count_addcore_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, S.core_idx,
+                       S.n_core, S.counts);
+    hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts,
+                       S.best);
+  }
+  PVN3D_LAUNCH_CHECK();
+  const int stop_on_win = (flags & PVN3D_MS_NO_WINNER_STOP) ? 0 : 1;
+
   hipEvent_t ev[2] = {nullptr, nullptr};
   int pending[2] = {0, 0};
   int slot = 0;
@@ -1022,11 +1078,11 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
 #define MS_ITER(PK_, SP_)                                                                                    \
   hipLaunchKernelGGL((ms_iter_kernel<PK_, SP_>), grid_it, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt, cin, cout, \
                      S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa, S.frozen_cm, S.act_cnt,   \
-                     S.act_form, S.act_idx)
+                     S.act_form, S.act_idx, S.best, S.win_pos, S.win_it, stop_on_win)
 #define MS_ITER_SGPR()                                                                                         \
   hipLaunchKernelGGL(ms_iter_sgpr_kernel, dim3(sg_grid), dim3(64), 0, st, P, S.apts, seg_off, seg_cnt, cin, cout, \
                      S.maxshift, S.cmmax, S.iters, t, max_iter, thresh, kappa, inv_kappa, S.frozen_cm, S.act_cnt,   \
-                     S.act_form, S.act_idx, sg_tiles, sg_items)
+                     S.act_form, S.act_idx, sg_tiles, sg_items, S.best, S.win_pos, S.win_it, stop_on_win)
     if (sgpr) MS_ITER_SGPR();
     else if (packed) { if (split) MS_ITER(true, true); else MS_ITER(true, false); }
     else { if (split) MS_ITER(false, true); else MS_ITER(false, false); }
@@ -1042,7 +1098,8 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     // batch stays (iterations) x (that floor).
     if (!(flags & PVN3D_MS_NO_EARLY_OUT) && t >= 5 && (t & 3) == 1 && t <= max_iter) {
       hipLaunchKernelGGL(ms_compact_kernel, dim3(n_seg), dim3(1024), 0, st, seg_off, seg_cnt, cout, S.maxshift,
-                         S.cmmax, S.frozen_cm, t, max_iter, thresh, S.act_cnt, S.act_form, S.act_idx);
+                         S.cmmax, S.frozen_cm, t, max_iter, thresh, S.act_cnt, S.act_form, S.act_idx, S.win_it,
+                         stop_on_win);
       if ((rc = (int)hipGetLastError()) != 0) break;
     }
     // Poll schedule: every poll_every iterations at first, then geometrically sparser (x1.5).  Late iterations
@@ -1051,7 +1108,7 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     if (poll && t == next_poll && t <= max_iter) {
       next_poll = t + (t / 2 > poll_every ? t / 2 : poll_every);
       hipLaunchKernelGGL(ms_poll_kernel, dim3(1), dim3(256), 0, st, S.maxshift, seg_cnt, n_seg,
-                         t, max_iter, thresh, S.active + slot);
+                         t, max_iter, thresh, S.win_it, stop_on_win, S.active + slot);
       if ((rc = (int)hipMemcpyAsync(poll_host + slot, S.active + slot, sizeof(int),
                                     hipMemcpyDeviceToHost, st)) != 0) break;
       if ((rc = (int)hipEventRecord(ev[slot], st)) != 0) break;
@@ -1074,23 +1131,9 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     (void)hipEventDestroy(ev[1]);
   }
   if (rc) return rc;
-  {
-    const float r_core = 0.499f * bandwidth;
-    hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
-                       S.core_idx, S.nc_idx, S.n_core);
-    const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
-    hipLaunchKernelGGL(ms_count_pruned_kernel<false>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL(ms_count_pruned_kernel<true>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL(ms_count_addcore_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, S.core_idx,
-                       S.n_core, S.counts);
-    hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts,
-                       S.best);
-  }
   PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(ms_final_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                     S.cbuf[0], S.cbuf[1], S.best, S.iters, d2_max,
+                     S.cbuf[0], S.cbuf[1], S.best, S.iters, S.win_pos, S.win_it, d2_max,
                      inv_kappa, ctr, labels, iters);
   PVN3D_LAUNCH_CHECK();
   return 0;

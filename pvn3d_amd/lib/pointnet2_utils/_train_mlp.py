@@ -30,7 +30,7 @@ TRAIN_FUSED = "auto"
 def train_fused_enabled():
     """-> whether a module in training mode should take the bf16 MFMA chain right now (see TRAIN_FUSED)."""
     if TRAIN_FUSED == "auto":
-        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
     return bool(TRAIN_FUSED)
 
 

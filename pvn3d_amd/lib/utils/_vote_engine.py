@@ -39,6 +39,7 @@ MS_FORCE_PACKED = 8  # PVN3D_MS_FORCE_PACKED: two seeds per lane (packed fp32 ma
 MS_FORCE_WHOLE = 16  # PVN3D_MS_FORCE_WHOLE: every wave walks all points of the fit
 MS_FORCE_SPLIT = 32  # PVN3D_MS_FORCE_SPLIT: the four waves of a workgroup split the points
 MS_SGPR_POINTS = 64  # PVN3D_MS_SGPR_POINTS: LDS-free iteration kernel (points as scalar operands); needs ALIGNED32
+MS_NO_WINNER_STOP = 128  # PVN3D_MS_NO_WINNER_STOP: run the reference's full iteration count (iters == its `it`)
 # Iteration-kernel choice used when a call does not name one (None: the library default).  A pipelined evaluator
 # that runs the vote stage beside the fused-MLP kernels sets "sgpr+cap<waves>" here (bench.py does).
 DEFAULT_KERNEL = None
@@ -54,6 +55,8 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows.
     kernel: None (library default) or a '+'-joined choice of "scalar" | "packed", "whole" | "split" and
     "noearly" (no early-out of converged seeds) -- pins the iteration kernel variant (all give identical results);
+    "nowin" = no winner stop: iterate until the reference's stop rule says so (iters == the reference's `it`; same
+    centres and labels, bit for bit);
     "sgpr" = the LDS-free kernel (needs aligned32), "cap<n>" bounds its launch to n waves (PVN3D_MS_WAVE_CAP).
     """
     flags = MS_ALIGNED32 if aligned32 else 0
@@ -67,7 +70,8 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
                 flags |= (int(k[3:]) & 0xfffff) << 8
                 continue
             flags |= {"scalar": MS_FORCE_SCALAR, "packed": MS_FORCE_PACKED, "whole": MS_FORCE_WHOLE,
-                      "split": MS_FORCE_SPLIT, "noearly": MS_NO_EARLY_OUT, "sgpr": MS_SGPR_POINTS}[k]
+                      "split": MS_FORCE_SPLIT, "noearly": MS_NO_EARLY_OUT, "sgpr": MS_SGPR_POINTS,
+                      "nowin": MS_NO_WINNER_STOP}[k]
     dev = pts4.device
     assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
     n_seg = int(seg_off.numel())

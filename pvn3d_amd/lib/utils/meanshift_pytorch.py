@@ -8,7 +8,10 @@ kernels (pvn3d_amd/csrc/meanshift.hip): same Gaussian kernel, same stop rule
 (max seed shift < bandwidth*1e-3 or it > max_iter), same cluster pick (converged position of
 the first seed whose ORIGINAL position has the most original neighbours within bandwidth).
 ``fit_batch`` runs many independent fits in one batched launch sequence; ``last_iters`` holds
-the iteration count(s) of the most recent call.  The reference's ``fit_batch_npts`` is broken
+the number of iterations the most recent call ran: by default a fit stops as soon as the winning seed has
+landed on a bitwise fixed point (its centre is known then; csrc/meanshift.hip "winner stop"), which is at
+most the reference's ``it``; with ``full_iterations = True`` the remaining iterations of the reference's
+stop rule are run as well (same centre and labels, bit for bit) and ``last_iters`` equals that ``it``.  The reference's ``fit_batch_npts`` is broken
 upstream (undefined name, never called) and is not reproduced.
 """
 import torch
@@ -22,6 +25,7 @@ class MeanShiftTorch(object):
         self.stop_thresh = bandwidth * 1e-3
         self.max_iter = max_iter
         self.last_iters = None
+        self.full_iterations = False
 
     @staticmethod
     def _pack(A):
@@ -42,7 +46,8 @@ class MeanShiftTorch(object):
         seg_cnt = torch.full((1,), N, dtype=torch.int32, device=A.device)
         ctr, labels, iters = _eng.meanshift_fit_batch(pts4, seg_off, seg_cnt, max(N, 1),
                                                       self.bandwidth, self.max_iter,
-                                                      aligned32=True)
+                                                      aligned32=True,
+                                                      kernel="nowin" if self.full_iterations else None)
         self.last_iters = iters
         return ctr[0].to(A.dtype), labels[:N].bool()
 
@@ -62,6 +67,7 @@ class MeanShiftTorch(object):
         seg_cnt = torch.tensor(cnts, dtype=torch.int32, device=dev)
         ctr, labels, iters = _eng.meanshift_fit_batch(pts4, seg_off, seg_cnt, max(max(cnts), 1),
                                                       self.bandwidth, self.max_iter,
-                                                      aligned32=True)
+                                                      aligned32=True,
+                                                      kernel="nowin" if self.full_iterations else None)
         self.last_iters = iters
         return ctr, [labels[o:o + n].bool() for o, n in zip(offs, cnts)]

@@ -137,7 +137,9 @@ def test_full_pointnet2msg_against_reference_module_code(dev, golden):
             got = t.sum(axis).numpy()
             want = z["full_%s_%s_sum" % (name, proj)]
             mass = z["full_%s_%s_abs" % (name, proj)]
-            bound = 1e-5 * np.maximum(mass, mass.max() * 1e-3)
+            # element errors of <= 1e-5 of the level's scale adding up like a random walk over the summed terms,
+            # plus 1e-6 of the summed magnitude (the reference's own fp32-vs-fp64 distance)
+            bound = 1e-5 * scale * np.sqrt(t.shape[axis]) + 1e-6 * mass
             assert np.all(np.abs(got - want) <= bound), "%s %s-sum projection" % (name, proj)
         worst[name] = (e32, e64)
     print("full Pointnet2MSG vs reference module code, rel. max err per level (vs fp32 run, vs fp64 run):",

@@ -27,8 +27,14 @@ def test_meanshift_vs_reference_golden(dev, golden):
         ctr, labels = ms.fit(T(A, dev))
         assert ctr.shape == (3,) and labels.shape == (len(A),) and labels.dtype == torch.bool
         assert np.abs(ctr.cpu().numpy() - z["ctr%d" % i]).max() < TOL, i
-        assert abs(int(ms.last_iters[0]) - int(z["iters%d" % i])) <= 1, (i, int(ms.last_iters[0]))
         assert np.array_equal(labels.cpu().numpy(), z["labels%d" % i]), i
+        # default: the fit stops once the winning seed sits on a bitwise fixed point (<= the reference's count);
+        # full_iterations runs the reference's stop rule to the end: its iteration count, the same bits
+        assert int(ms.last_iters[0]) <= int(z["iters%d" % i]) + 1
+        ms.full_iterations = True
+        ctr_f, labels_f = ms.fit(T(A, dev))
+        assert torch.equal(ctr_f, ctr) and torch.equal(labels_f, labels)
+        assert abs(int(ms.last_iters[0]) - int(z["iters%d" % i])) <= 1, (i, int(ms.last_iters[0]))
 
 
 @pytest.mark.parametrize("n,sig_out,frac", [(3072, 0.05, 0.1), (3072, 0.3, 0.1), (5000, 0.3, 0.3), (257, 0.3, 0.2)])
@@ -42,6 +48,10 @@ def test_meanshift_vs_oracle(dev, orc, n, sig_out, frac):
     ctr, labels = ms.fit(T(A, dev))
     assert np.abs(ctr.cpu().numpy() - octr).max() < TOL
     assert np.array_equal(labels.cpu().numpy(), olab)
+    assert int(ms.last_iters[0]) <= oit + 1            # winner stop: never more than the reference's count
+    ms.full_iterations = True
+    ctr_f, labels_f = ms.fit(T(A, dev))
+    assert torch.equal(ctr_f, ctr) and torch.equal(labels_f, labels)
     # The iteration COUNT is only well defined when the stop decision has margin: a slowly
     # creeping far outlier whose per-iteration shift sits within ~10 % of the threshold
     # (here 7.5e-5 vs 8e-5 for the sig_out=0.3 case) makes the count chaotic under fp32
@@ -108,7 +118,16 @@ def test_frames_vs_reference_driven_golden(dev, golden):
                                 T(f["pred_kp_of"], dev)[None], True, 2, False, 1)
     assert np.abs(res["poses"][0].cpu().numpy() - z["lm0_pose"]).max() < TOL
     assert np.abs(res["cls_kps"][0].cpu().numpy() - z["lm0_cls_kps"]).max() < TOL
-    assert np.abs(res["iters"][0].cpu().numpy() - z["lm0_iters"]).max() <= 1
+    assert (res["iters"][0].cpu().numpy() <= z["lm0_iters"] + 1).all()      # winner stop: at most the reference's count
+    from pvn3d_amd.lib.utils import _vote_engine as _eng
+    _eng.DEFAULT_KERNEL = "nowin"            # the reference's stop rule run to the end: its count, the same bits
+    try:
+        full = ev.cal_batch_poses_lm(T(f["pcld"], dev)[None], T(f["mask"], dev)[None], T(f["ctr_of"], dev)[None],
+                                     T(f["pred_kp_of"], dev)[None], True, 2, False, 1)
+    finally:
+        _eng.DEFAULT_KERNEL = None
+    assert np.abs(full["iters"][0].cpu().numpy() - z["lm0_iters"]).max() <= 1
+    assert torch.equal(full["cls_kps"], res["cls_kps"]) and torch.equal(full["poses"], res["poses"])
     poses = ev.cal_frame_poses_lm(T(f["pcld"], dev), T(f["mask"], dev), T(f["ctr_of"], dev),
                                   T(f["pred_kp_of"], dev), True, 2, False, 1)
     assert isinstance(poses, list) and poses[0].shape == (3, 4)
@@ -160,7 +179,16 @@ def test_full_size_frame_vs_oracle_and_ground_truth(dev, orc):
                                                   f["mesh_kps"], return_debug=True)
     assert np.abs(res["poses"][0].cpu().numpy() - want[0]).max() < TOL
     assert np.abs(res["cls_kps"][0].cpu().numpy() - kps).max() < TOL
-    assert np.abs(res["iters"][0].cpu().numpy() - iters).max() <= 1
+    assert (res["iters"][0].cpu().numpy() <= iters + 1).all()
+    from pvn3d_amd.lib.utils import _vote_engine as _eng
+    _eng.DEFAULT_KERNEL = "nowin"
+    try:
+        full = ev.cal_batch_poses_lm(T(f["pcld"], dev)[None], T(f["mask"], dev)[None], T(f["ctr_of"], dev)[None],
+                                     T(f["pred_kp_of"], dev)[None], True, 2, False, 1)
+    finally:
+        _eng.DEFAULT_KERNEL = None
+    assert np.abs(full["iters"][0].cpu().numpy() - iters).max() <= 1
+    assert torch.equal(full["cls_kps"], res["cls_kps"]) and torch.equal(full["poses"], res["poses"])
     assert (res["counts"][0].cpu().numpy() == 3072).all()
     pose = res["poses"][0].cpu().numpy()
     assert np.abs(pose[:, :3] - f["R"]).max() < 2e-2 and np.abs(pose[:, 3] - f["t"]).max() < 2e-3
@@ -212,17 +240,24 @@ def test_iteration_kernel_variants_are_bit_identical(dev):
     # "+noearly": every seed iterated in every iteration; without it seeds that are bitwise fixed points of the
     # iteration function leave the iterated set from iteration 5 on (exact: same bits)
     # "sgpr": the LDS-free kernel (points as scalar operands, one wave per 128 seeds), "+cap7": 7 waves stride over the work
+    # "+nowin": no winner stop -- the iterations that only wait for slower seeds to pass the reference's stop test are run
+    # too: same centres and labels bit for bit, iteration count = the reference's
     kerns = ("scalar+whole+noearly", "packed+whole", "scalar+split", "packed+split", "packed+split+noearly", "scalar+whole",
              "sgpr", "sgpr+noearly", "sgpr+cap7")
+    kerns = kerns + tuple(k + "+nowin" for k in kerns)
     for kern in kerns:
         c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern, aligned32=True)
         l = l.cpu().numpy()
         valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)])     # rows past a segment's count are scratch
         outs[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
     for kern in kerns[1:]:
-        for x, y in zip(outs[kerns[0]], outs[kern]):
+        for x, y in zip(outs[kerns[0]][:2], outs[kern][:2]):                     # centres, labels: every variant
             assert np.array_equal(x, y), kern
-    assert outs["packed+split"][2].max() > 20       # the heavy-tailed fits really iterate
+        same_mode = kerns[0] + "+nowin" if kern.endswith("+nowin") else kerns[0]
+        assert np.array_equal(outs[same_mode][2], outs[kern][2]), kern           # iteration counts: per stop mode
+    assert outs["packed+split+nowin"][2].max() > 20      # the heavy-tailed fits really iterate under the reference's rule
+    assert (outs["packed+split"][2] <= outs["packed+split+nowin"][2]).all()
+    print("iterations run (winner stop / reference's stop rule):", outs["packed+split"][2], outs["packed+split+nowin"][2])
 
 
 def test_stress_all_points_on_object_vs_oracle(dev, orc):
@@ -237,11 +272,13 @@ def test_stress_all_points_on_object_vs_oracle(dev, orc):
     so = torch.tensor([0, 12288], dtype=torch.int32, device=dev)
     sc = torch.tensor([12288, 12288], dtype=torch.int32, device=dev)
     c, l, it = eng.meanshift_fit_batch(T(pts4, dev), so, sc, 12288, 0.08, 300)
-    c, l, it = c.cpu().numpy(), l.cpu().numpy().reshape(2, 12288), it.cpu().numpy()
+    cf, lf, itf = eng.meanshift_fit_batch(T(pts4, dev), so, sc, 12288, 0.08, 300, kernel="nowin")
+    assert torch.equal(c, cf) and torch.equal(l, lf)
+    c, l, it, itf = c.cpu().numpy(), l.cpu().numpy().reshape(2, 12288), it.cpu().numpy(), itf.cpu().numpy()
     for i, v in enumerate(votes):
         oc, ol, oit = orc.meanshift_fit(v, 0.08, 300)
         assert np.abs(c[i] - oc).max() < TOL
-        assert abs(int(it[i]) - oit) <= 1
+        assert abs(int(itf[i]) - oit) <= 1 and int(it[i]) <= int(itf[i])
         assert np.array_equal(l[i].astype(bool), ol)
 
 
