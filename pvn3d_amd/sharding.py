@@ -49,7 +49,9 @@ def gather_frame_results(local, n_items, group=None, skip_single=True):
 # xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is bound by one
 # link: buckets are large (default 64 MiB, a few hundred microseconds of wire time each) to
 # amortise the per-collective latency, and are issued asynchronously in reverse parameter order
-# (the order backward produces them) so the first buckets fly while later ones are still packed.
+# (the order backward produces them).  all_reduce_gradients() does it after backward() has returned;
+# OverlappedGradientReducer issues every bucket from inside backward, as soon as its last gradient exists
+# (train_step uses it).
 # ---------------------------------------------------------------------------------------------
 
 def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=True, skip_single=True):
@@ -86,6 +88,109 @@ def all_reduce_gradients(parameters, bucket_bytes=64 << 20, group=None, average=
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
     return len(buckets)
+
+
+class OverlappedGradientReducer(object):
+    """The same bucketed gradient averaging, issued DURING backward: every parameter carries a post-accumulate-grad
+    hook; when the last gradient of a bucket has been accumulated the bucket is flattened and its all-reduce is
+    started asynchronously (RCCL runs it on its own stream over xGMI), so the buckets of the late layers -- the first
+    ones backward produces -- are on the wire while the early layers' gradients are still being computed.  The
+    reference reduces inside nn.DataParallel's backward (train_linemod_pvn3d.py:480); this is the one-process-per-GPU
+    equivalent.  Buckets are laid out once, in reverse parameter order, and are issued in the order they complete:
+    every rank runs the same model, so autograd visits the same graph in the same order and the ranks issue the same
+    collectives in the same order (a rank-dependent graph -- data-dependent control flow in the model -- would break
+    that, exactly as it breaks DistributedDataParallel without find_unused_parameters).  ``finalize()`` (after
+    ``backward()``) issues what is left in bucket order -- buckets holding a parameter that received no gradient
+    this step, which therefore never completed -- waits, averages and writes the results back into ``.grad``.
+
+        red = OverlappedGradientReducer(model.parameters(), group=group)     # once
+        loss.backward(); red.finalize(); optimizer.step()                     # every step
+    """
+
+    def __init__(self, parameters, bucket_bytes=64 << 20, group=None, average=True):
+        self.group, self.average = group, average
+        params = [p for p in parameters if p.requires_grad]
+        params.reverse()
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in params:
+            nb = p.numel() * p.element_size()
+            if cur and (cur_bytes + nb > bucket_bytes or p.dtype != cur[0].dtype):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, bk in enumerate(self.buckets):
+            for p in bk:
+                self._bucket_of[id(p)] = bi
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self.launched_during_backward = 0
+        self._reset()
+
+    def _reset(self):
+        self._ready = [0] * len(self.buckets)
+        self._issued = [False] * len(self.buckets)
+        self._pending = []                  # (work, flat, params with a gradient)
+        self._in_backward = True
+
+    def _issue(self, bi):
+        self._issued[bi] = True
+        bk = [p for p in self.buckets[bi] if p.grad is not None]
+        if not bk:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in bk])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, flat, bk))
+        if self._in_backward:
+            self.launched_during_backward += 1
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[id(p)]
+        self._ready[bi] += 1
+        if self._ready[bi] == len(self.buckets[bi]) and not self._issued[bi]:
+            self._issue(bi)
+
+    def finalize(self):
+        """Call after backward(): issue the remaining buckets, wait for all, average, write back.  Returns the number
+        of buckets that were exchanged."""
+        self._in_backward = False
+        for bi in range(len(self.buckets)):
+            if not self._issued[bi]:
+                self._issue(bi)
+        ws = dist.get_world_size(self.group)
+        n = len(self._pending)
+        for work, flat, bk in self._pending:
+            work.wait()
+            if self.average:
+                flat.div_(ws)
+            off = 0
+            for p in bk:
+                k = p.grad.numel()
+                p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                off += k
+        self._reset()
+        return n
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def overlapped_reducer(model, bucket_bytes=64 << 20, group=None, skip_single=True):
+    """The model's OverlappedGradientReducer (created on first use, kept on the model), or None when there is no
+    process group / a group of one (nothing to exchange)."""
+    if _single(group, skip_single):
+        return None
+    red = getattr(model, "_pvn3d_grad_reducer", None)
+    if red is None or red.group is not group:
+        if red is not None:
+            red.remove()
+        red = OverlappedGradientReducer(model.parameters(), bucket_bytes=bucket_bytes, group=group)
+        model._pvn3d_grad_reducer = red
+    return red
 
 
 def broadcast_parameters(module, src=0, group=None, skip_single=True):

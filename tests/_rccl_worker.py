@@ -43,6 +43,31 @@ def main():
     for p, w in zip(net.parameters(), before):
         assert torch.equal(p, w)
 
+    # one real training step whose gradient buckets are all-reduced over RCCL from inside backward
+    # (sharding.OverlappedGradientReducer through train_step): same loss and weights as the step without a group
+    import copy
+    from pvn3d_amd import train_step as ts
+    torch.manual_seed(0)
+    batch = ts.synthetic_batch(2, 2048, dev, seed_base=90, n_obj=512)
+    m_a = ts.PointVoteNet().to(dev)
+    m_b = copy.deepcopy(m_a)
+    opt_a = torch.optim.SGD(m_a.parameters(), lr=1e-3)
+    opt_b = torch.optim.SGD(m_b.parameters(), lr=1e-3)
+    red = sharding.overlapped_reducer(m_a, bucket_bytes=1 << 20, skip_single=False)
+    assert red is not None and len(red.buckets) > 3
+    orig = sharding.overlapped_reducer
+    sharding.overlapped_reducer = lambda net, bucket_bytes=0, group=None: red      # world size 1: force the RCCL path
+    try:
+        loss_a = ts.train_step(m_a, opt_a, batch)
+    finally:
+        sharding.overlapped_reducer = orig
+    during = red.launched_during_backward
+    assert during >= 1, "no bucket was issued from inside backward"
+    loss_b = ts.train_step(m_b, opt_b, batch)                                      # no exchange (single process)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_b))
+    worst = max(float((pa - pb).abs().max()) for pa, pb in zip(m_a.parameters(), m_b.parameters()))
+    assert worst <= 1e-5, worst          # atomics in the scatter gradients: not bit-identical run to run
+
     # bench.py's timing reduction
     dist.barrier()
     torch.cuda.synchronize()
@@ -51,7 +76,7 @@ def main():
     assert float(t.item()) == 1.25
     dist.barrier()
     dist.destroy_process_group()
-    print("RCCL_WORLD1_OK buckets=%d" % n_buckets)
+    print("RCCL_WORLD1_OK buckets=%d overlapped_buckets_during_backward=%d" % (n_buckets, during))
 
 
 if __name__ == "__main__":

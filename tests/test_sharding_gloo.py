@@ -151,3 +151,64 @@ def test_bench_step_gather_strong_ragged():
 
 def test_bench_step_gather_weak():
     _run_bench_gather(4, False)
+
+
+def _overlap_worker(rank, ws, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from pvn3d_amd.sharding import OverlappedGradientReducer, all_reduce_gradients, broadcast_parameters
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                              torch.nn.Linear(64, 33), torch.nn.ReLU(), torch.nn.Linear(33, 5))
+    unused = torch.nn.Parameter(torch.zeros(11))               # a parameter that never receives a gradient
+    broadcast_parameters(net)
+    params = list(net.parameters()) + [unused]
+    torch.manual_seed(70 + rank)
+    x, y = torch.randn(6, 7), torch.randn(6, 5)
+
+    def backward():
+        for p in params:
+            p.grad = None
+        ((net(x) - y) ** 2).mean().backward()
+
+    backward()                                                  # reference: exchange after backward has returned
+    all_reduce_gradients(params, bucket_bytes=6000)
+    want = [p.grad.clone() for p in net.parameters()]
+    red = OverlappedGradientReducer(params, bucket_bytes=6000)  # several buckets
+    in_flight = []
+    h = net[0].weight.register_hook(lambda g: in_flight.append(red.launched_during_backward))   # first layer: last gradient
+    backward()
+    h.remove()
+    during = red.launched_during_backward
+    n = red.finalize()
+    got = [p.grad.clone() for p in net.parameters()]
+    same = all(torch.equal(a, b) for a, b in zip(got, want))    # same buckets, same summation: identical bits
+    backward()                                                  # a second step reuses the reducer
+    n2 = red.finalize()
+    same2 = all(torch.equal(p.grad, b) for p, b in zip(net.parameters(), want))
+    q.put((rank, same and same2, len(red.buckets), n, n2, during, in_flight[0] if in_flight else -1,
+           unused.grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_are_exchanged_during_backward():
+    """OverlappedGradientReducer: the all-reduce of a bucket starts from inside backward() as soon as its last gradient
+    has been accumulated (before the first layer's gradient even exists), the results equal the after-backward
+    exchange bit for bit, and a parameter without a gradient neither blocks nor receives one."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(ws)]
+    for p in procs:
+        p.join(timeout=60)
+    for _, same, n_buckets, n, n2, during, before_first_layer, unused_none in res:
+        assert same and unused_none
+        assert n_buckets >= 3 and n == n2 and 1 <= n <= n_buckets
+        assert during >= 1                      # issued while backward was still running ...
+        assert before_first_layer >= 1          # ... before the first layer's gradient had been produced
