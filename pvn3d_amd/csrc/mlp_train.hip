@@ -1196,6 +1196,9 @@ extern "C" int pvn3d_mt_wgrad_tn(long long rows, int M, int N, const void* dY, i
 extern "C" int pvn3d_mt_transpose(long long rows, int ld, const void* X, void* XT, long long ldt, void* stream) {
   if (rows <= 0 || ld <= 0) return 0;
   if (rows > 0x7fffffffLL || ldt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+  // the kernel writes 8 rows per 16-byte store at XT[c * ldt + r]: anything else is misaligned and runs into the next
+  // channel row (and past the buffer in the last one)
+  if ((rows & 7) || (ldt & 7) || ldt < rows) return (int)hipErrorInvalidValue;
   if (ld <= 16)
     hipLaunchKernelGGL(mt_transpose_kernel<16>, dim3(pvn3d_ceil_div((int)rows, 256), pvn3d_ceil_div(ld, 16)), dim3(256), 0,
                        MT_ST, (int)rows, ld, (const bf16_t*)X, (bf16_t*)XT, (int)ldt);

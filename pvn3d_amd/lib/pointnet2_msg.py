@@ -31,11 +31,30 @@ class GraphedForward(object):
     -- become one graph launch.  The reference evaluates one frame per call (test_mini_batch_size = 1,
     pvn3d/common.py:41): at B = 1 the forward is launch-bound outside FPS.
     ``g = GraphedForward(net, example); out = g(pc)``: `pc` is copied into the captured input buffer, the returned
-    tensor is the captured output buffer (overwritten by the next call)."""
+    tensor is the captured output buffer (overwritten by the next call).
+    The graph bakes in the folded Conv+BatchNorm weights of the capture: a later ``load_state_dict`` / optimizer or
+    training step / ``broadcast_parameters`` is detected (tensor versions + the package's weights epoch) and the
+    graph is captured again before the replay; ``check_weights=False`` skips that check (~15 us per call)."""
 
-    def __init__(self, net, example, warmup=3):
+    def __init__(self, net, example, warmup=3, check_weights=True):
         assert not net.training and example.is_cuda
         self.net = net
+        self.check_weights = check_weights
+        self._warmup = warmup
+        self._capture(example)
+
+    def _signature(self):
+        from .pointnet2_utils import _fused_mlp
+        sig = [_fused_mlp._WEIGHTS_EPOCH[0]]
+        for t in self.net.parameters():
+            sig.append(t._version)
+        for t in self.net.buffers():
+            sig.append(t._version)
+        return tuple(sig)
+
+    def _capture(self, example):
+        net, warmup = self.net, self._warmup
+        self._sig = self._signature()
         self.static_in = example.clone()
         cur = torch.cuda.current_stream(example.device)
         side = torch.cuda.Stream(device=example.device)
@@ -52,6 +71,10 @@ class GraphedForward(object):
     def __call__(self, pointcloud):
         if pointcloud.shape != self.static_in.shape:
             raise RuntimeError("GraphedForward was captured for shape %s" % (tuple(self.static_in.shape),))
+        if self.check_weights and self._signature() != self._sig:
+            if self.net.training:
+                raise RuntimeError("GraphedForward replays the eval forward: the network is in training mode")
+            self._capture(self.static_in)          # the weights changed since the capture
         self.static_in.copy_(pointcloud)
         self.graph.replay()
         return self.static_out

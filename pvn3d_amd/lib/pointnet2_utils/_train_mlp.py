@@ -38,6 +38,16 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _bump_version(t):
+    """Advance t._version without launching a kernel (the data was written by a raw-pointer kernel)."""
+    torch._C._autograd._unsafe_set_version_counter([t], [t._version + 1])
+
+
+# kernel limits of csrc/mlp_train.hip (pool / BatchNorm passes): beyond them the modules keep the op-by-op composition
+MAX_NSAMPLE = 256
+MAX_LD = 2048
+
+
 def _ld(c):
     return (int(c) + 15) // 16 * 16
 
@@ -49,7 +59,9 @@ def _strides3(t):
 
 def shared_mlp_layers(mlp):
     """SharedMLP -> [(conv, bn)] when every layer is exactly [1x1 Conv2d without bias] -> BatchNorm2d -> ReLU
-    (the only form PVN3D builds); None otherwise."""
+    (the only form PVN3D builds) with the BatchNorm in training mode (a frozen / eval BatchNorm inside a module that
+    is in training mode normalises with its running statistics and must not update them: that composition is left
+    to torch); None otherwise."""
     out = []
     for layer in mlp.children():
         names = [n for n, _ in layer.named_children()]
@@ -60,7 +72,7 @@ def shared_mlp_layers(mlp):
         if (names[:1] != ["conv"] or not isinstance(conv, nn.Conv2d) or conv.kernel_size != (1, 1)
                 or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.groups != 1 or conv.bias is not None
                 or not isinstance(bn, nn.BatchNorm2d) or not bn.affine or not bn.track_running_stats
-                or bn.momentum is None or not isinstance(act, nn.ReLU)):
+                or bn.momentum is None or not bn.training or not isinstance(act, nn.ReLU)):
             return None
         out.append((conv, bn))
     return out or None
@@ -104,8 +116,13 @@ class _Chain(object):
                                            bn.running_var.data_ptr() if track else None, stats[0].data_ptr(),
                                            stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), st),
                   "mt_bn_finalize")
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            if track:
+                # the kernel wrote the running statistics through raw pointers: tell everything that caches on
+                # (data_ptr, _version) -- the folded eval weights of the fused inference kernels -- that they changed
+                _bump_version(bn.running_mean)
+                _bump_version(bn.running_var)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
             self.y.append(y)
             self.mean.append(stats)
             if pool is not None and li == L - 1:
@@ -172,15 +189,24 @@ class _Chain(object):
                 check(lib.pvn3d_mt_wgrad_tn(rows, cout, cin, dy.data_ptr(), ldo, prev.data_ptr(), ldi, dw.data_ptr(), cin,
                                             st), "mt_wgrad_tn")
             else:
-                dyt = torch.empty((ldo, rows), dtype=torch.bfloat16, device=dev)
-                pvt = torch.empty((ldi, rows), dtype=torch.bfloat16, device=dev)
-                check(lib.pvn3d_mt_transpose(rows, ldo, dy.data_ptr(), dyt.data_ptr(), rows, st), "mt_transpose")
-                check(lib.pvn3d_mt_transpose(rows, ldi, prev.data_ptr(), pvt.data_ptr(), rows, st), "mt_transpose")
+                # the transposed copies hold the contraction dimension (rows) contiguously: it has to be a multiple of
+                # 16 (8 rows per 16-byte store of the transpose, K % 16 of the GEMM) -- zero rows add nothing to dW
+                r16 = (rows + 15) // 16 * 16
+                dy_s, pv_s = dy, prev
+                if r16 != rows:
+                    dy_s = torch.zeros((r16, ldo), dtype=torch.bfloat16, device=dev)
+                    dy_s[:rows] = dy
+                    pv_s = torch.zeros((r16, ldi), dtype=torch.bfloat16, device=dev)
+                    pv_s[:rows] = prev
+                dyt = torch.empty((ldo, r16), dtype=torch.bfloat16, device=dev)
+                pvt = torch.empty((ldi, r16), dtype=torch.bfloat16, device=dev)
+                check(lib.pvn3d_mt_transpose(r16, ldo, dy_s.data_ptr(), dyt.data_ptr(), r16, st), "mt_transpose")
+                check(lib.pvn3d_mt_transpose(r16, ldi, pv_s.data_ptr(), pvt.data_ptr(), r16, st), "mt_transpose")
                 tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-                ksplit = max(1, min(rows // 512, 1024 // tiles))
-                check(lib.pvn3d_mt_gemm_nt_splitk(cout, cin, rows, dyt.data_ptr(), rows, pvt.data_ptr(), rows,
+                ksplit = max(1, min(r16 // 512, 1024 // tiles))
+                check(lib.pvn3d_mt_gemm_nt_splitk(cout, cin, r16, dyt.data_ptr(), r16, pvt.data_ptr(), r16,
                                                   dw.data_ptr(), cin, ksplit, st), "mt_gemm_nt_splitk")
-                del dyt, pvt
+                del dyt, pvt, dy_s, pv_s
             dws[li] = dw
             # input gradient: dH_prev (rows, ldi) = dY . W
             if li > 0 or need_input_grad:
@@ -273,6 +299,10 @@ class SALevelTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         B, N, m, C, total = ctx.shape
+        if ctx.chains is None:
+            raise RuntimeError("the fused training chain frees its saved activations in backward: a second backward "
+                               "through the same graph (retain_graph=True) is not supported; set "
+                               "_train_mlp.TRAIN_FUSED = False for that")
         gout = gout.contiguous()
         dev = gout.device
         fshape, fneeds = ctx.feat_meta
@@ -349,6 +379,10 @@ class FPTrain(torch.autograd.Function):
     def backward(ctx, gout):
         B, n, mk, C2, C1, idx, weight, need_u, need_k = ctx.meta
         ch = ctx.chain
+        if ch is None:
+            raise RuntimeError("the fused training chain frees its saved activations in backward: a second backward "
+                               "through the same graph (retain_graph=True) is not supported; set "
+                               "_train_mlp.TRAIN_FUSED = False for that")
         gout = gout.contiguous()
         dev = gout.device
         cout = ch.c[-1]
@@ -384,10 +418,15 @@ def sa_level_train(module, xyz, new_xyz, features, idxs):
     """PointnetSAModuleMSG.forward in training mode -> (B, C_total, npoint) (a transposed view of the point-major
     result), or None when a scale is not of the supported form."""
     from . import pointnet2_utils
+    if xyz.requires_grad or new_xyz.requires_grad:
+        return None          # the chain has no gradient w.r.t. the coordinates; the op-by-op composition does
     spec, layer_lists = [], []
+    c_feat = features.size(1) if features is not None else 0
     for grouper, mlp, idx in zip(module.groupers, module.mlps, idxs):
         layers = shared_mlp_layers(mlp)
         if layers is None or not isinstance(grouper, pointnet2_utils.QueryAndGroup) or idx is None:
+            return None
+        if idx.size(2) > MAX_NSAMPLE or max([c_feat + 3] + [conv.out_channels for conv, _ in layers]) > MAX_LD - 16:
             return None
         if features is None and not grouper.use_xyz:
             return None
@@ -404,6 +443,9 @@ def fp_train(module, unknow_feats, known_feats, idx, weight):
     """PointnetFPModule.forward in training mode -> (B, C_out, n) (transposed view), or None."""
     layers = shared_mlp_layers(module.mlp)
     if layers is None:
+        return None
+    c_in = known_feats.size(1) + (unknow_feats.size(1) if unknow_feats is not None else 0)
+    if max([c_in] + [conv.out_channels for conv, _ in layers]) > MAX_LD - 16:
         return None
     channel_major = not getattr(module, "_point_major_out", False)
     out = FPTrain.apply(unknow_feats, known_feats, idx.contiguous(), weight.contiguous(), layers, channel_major,

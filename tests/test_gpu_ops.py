@@ -959,6 +959,49 @@ def test_graphed_forward_replays_the_eager_forward(dev):
         assert torch.equal(g(pc), w)
     with pytest.raises(RuntimeError):
         g(pcs[0][:, :100])
+    # the graph bakes in the folded weights: a later load_state_dict (and a raw-pointer running-statistics update of a
+    # training step, which bumps the tensor versions since round 4) is noticed and the graph is captured again
+    sd = {k: (v * 1.25 if v.dtype.is_floating_point else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        want2 = net(pcs[1]).clone()
+    assert not torch.equal(want2, want[1])
+    assert torch.equal(g(pcs[1]), want2)
+
+
+def test_training_step_invalidates_the_folded_eval_weights(dev):
+    """A training-mode forward of the bf16 chain updates BatchNorm running statistics through raw pointers; the eval
+    path's folded-weight caches (keyed on tensor versions) must see it even when num_batches_tracked is absent."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _train_mlp
+    torch.manual_seed(1)
+    sa = pm.PointnetSAModuleMSG(npoint=64, radii=[0.05, 0.1], nsamples=[16, 32], mlps=[[6, 16, 32], [6, 32, 64]]).to(dev)
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.num_batches_tracked = None
+    xyz = T(clouds(31, 2, 500, 0.1), dev)
+    feats = torch.randn(2, 6, 500, device=dev)
+    sa.eval()
+    with torch.no_grad():
+        before = sa(xyz, feats)[1].clone()
+    sa.train()
+    _train_mlp.TRAIN_FUSED = True
+    try:
+        v0 = [m.running_mean._version for m in sa.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        sa(xyz, feats.clone().requires_grad_(True))[1].sum().backward()
+        v1 = [m.running_mean._version for m in sa.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    finally:
+        _train_mlp.TRAIN_FUSED = "auto"
+    assert all(b > a for a, b in zip(v0, v1))
+    sa.eval()
+    with torch.no_grad():
+        after = sa(xyz, feats)[1]
+        pm.FUSED_INFERENCE = False
+        try:
+            after_unfused = sa(xyz, feats)[1]
+        finally:
+            pm.FUSED_INFERENCE = True
+    assert not torch.equal(before, after)
+    assert (after - after_unfused).abs().max().item() < 1e-4 * max(after_unfused.abs().max().item(), 1.0)
 
 
 def test_geometry_ahead_handle_gives_the_same_forward(dev):
