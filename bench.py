@@ -51,6 +51,7 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0
 PEAK_FP32_VALU_TFLOPS = 157.3
 PEAK_FP32_MFMA_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32, exact fp32 (guide: matrix fp32 = vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (guide; the 2:1-sparsity headline figure is not used)
 # VALU issue bound of the pair-scanning ops ("report time and % of a VALU bound, not GB/s"):
 # one fp32 VALU instruction per lane and clock on each of 256 CUs x 4 SIMDs x 32 lanes at 2.4 GHz (= the 157.3
 # TFLOP/s peak counted as FMAs), and the fewest instructions the reference arithmetic allows per (query, point)
@@ -501,9 +502,35 @@ def extra_configs(net, dev, poll_every, with_cpu):
             _train_mlp.TRAIN_FUSED = "auto"
         entry[tag] = dict(ms_per_step=ms, frames_per_s=B * 1e3 / ms, loss_first=float(losses[0]), loss_last=float(losses[-1]),
                           peak_mem_gb=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+        if tag == "bf16_autocast":
+            alg = ts.algorithmic_work_per_step(model.backbone, B)
         del model, opt
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats(dev)
+    # roofline of the step's SA / FP SharedMLP chains (what csrc/mlp_train.hip owns; FPS, the heads, the loss and Adam
+    # are in the step time but not in the algorithmic work): both bounds, the binding one first
+    t = entry["bf16_autocast"]["ms_per_step"] * 1e-3
+    t_hbm, t_mfma = alg["bytes"] / (PEAK_HBM_GBS * 1e9), alg["flops"] / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    rl = dict(bound="hbm" if t_hbm >= t_mfma else "mfma", achieved=alg["bytes"] / t / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+              frac=alg["bytes"] / t / 1e9 / PEAK_HBM_GBS, traffic=None,
+              algorithmic_bytes_per_step=alg["bytes"], algorithmic_flops_per_step=alg["flops"],
+              mfma_view=dict(achieved=alg["flops"] / t / 1e12, peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                             frac=alg["flops"] / t / 1e12 / PEAK_BF16_MFMA_TFLOPS),
+              time_at_hbm_peak_ms=t_hbm * 1e3, time_at_mfma_peak_ms=t_mfma * 1e3,
+              note="denominator = the whole bf16_autocast step (incl. FPS, heads, loss, Adam); bytes = bf16 matrices "
+                   "the per-layer passes must stream (train_step.algorithmic_work_per_step); the narrow-K GEMMs make "
+                   "HBM, not MFMA, the binding roofline")
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_train_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("frames_per_step") == B:
+            rl["traffic"] = pmc["sa_fp_mlp_chain_bytes_per_step"]
+            rl["traffic_all_kernels"] = pmc["all_kernels_bytes_per_step"]
+            rl["traffic_source"] = "profiles/%s_train_pmc_traffic.json" % pmc.get("tag")
+            rl["traffic_measured_in_run"] = False
+    except (OSError, ValueError, KeyError):
+        pass
+    entry["roofline"] = rl
     out.append(entry)
     return out
 

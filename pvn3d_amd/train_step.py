@@ -116,3 +116,79 @@ def synthetic_batch(n_frames, n_pts, dev, seed_base=0, n_obj=None):
     lab = np.stack([f["mask"] for f in fr], 0).astype(np.float32)[..., None]
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return dict(pc=T(pc), kp_targ_ofst=T(kp_t), ctr_targ_ofst=T(ctr_t), labels=T(lab))
+
+
+def algorithmic_work_per_step(backbone, n_frames, n_pts=12288):
+    """Algorithmic FLOPs and bytes of ONE training step of the SA / FP SharedMLP chains (BASELINE config 5), i.e. of
+    the part of the step this package owns (csrc/mlp_train.hip); the heads, the loss and the optimizer are not in it.
+
+    FLOPs: per layer 2 * rows * cin * cout for the forward product, the same for the weight gradient, and the same for
+    the input gradient wherever one is needed (every layer but the first of SA level 0, whose input -- the cloud's own
+    features and coordinates -- takes no gradient).
+    Bytes: what the bf16 formulation has to stream per layer (true channel counts, no padding; bf16 = 2 B):
+      forward   GEMM reads X, writes Y (pre-BatchNorm: batch statistics need the whole matrix before any element can be
+                normalised); BatchNorm+ReLU reads Y, writes H -- the pooled last layer of an SA chain reads Y and writes
+                the pooled fp32 row + 1-byte arg-indices instead;
+      backward  statistics pass reads dH and Y (pooled: Y at the arg positions, 1/nsample of it); apply pass reads dH
+                and Y, writes dY (pooled: reads Y, writes dY); input gradient reads dY, writes dX; weight gradient
+                reads dY and H_prev;
+      layer 0   the gathered input X0 is written once (forward) and its gradient read once (backward), the fp32
+                source / gradient rows once each.
+    Weights and statistics are KBs and left out.  Returns dict(flops, bytes, per_level=[...]), rows = matrix rows."""
+    scale = n_pts / 12288.0
+    B = n_frames
+    flops = bytes_ = 0.0
+    levels = []
+
+    def chain(name, rows, dims, pooled_ns, input_grad, src_rows, src_ch):
+        nonlocal flops, bytes_
+        f = b = 0.0
+        L = len(dims) - 1
+        b += rows * dims[0] * 2 + src_rows * src_ch * 4               # X0 written, fp32 source rows read
+        for li in range(L):
+            cin, cout = dims[li], dims[li + 1]
+            last_pooled = pooled_ns and li == L - 1
+            f += 2.0 * rows * cin * cout * (2 + (1 if (li > 0 or input_grad) else 0))
+            b += rows * (cin + cout) * 2                               # forward GEMM
+            if last_pooled:
+                b += rows * cout * 2 + (rows // pooled_ns) * cout * 5  # Y read, pooled fp32 + arg written
+                b += (rows // pooled_ns) * cout * (2 + 4 + 1)          # bwd statistics: Y at arg, dout, arg
+                b += rows * cout * 2 * 2                               # bwd apply: Y read, dY written
+            else:
+                b += rows * cout * 2 * 2                               # BatchNorm + ReLU: Y read, H written
+                b += rows * cout * 2 * 2                               # bwd statistics: dH, Y
+                b += rows * cout * 2 * 3                               # bwd apply: dH, Y read, dY written
+            if li > 0 or input_grad:
+                b += rows * (cout + cin) * 2                           # input gradient: dY read, dX written
+            b += rows * (cout + cin) * 2                               # weight gradient: dY, H_prev read
+        if input_grad:
+            b += rows * dims[0] * 2 + src_rows * src_ch * 4           # dX0 read, fp32 gradient rows written
+        flops += f
+        bytes_ += b
+        levels.append(dict(name=name, rows=int(rows), dims=list(dims), flops=f, bytes=b))
+
+    n_in = n_pts
+    sa_width = []
+    for li, mod in enumerate(backbone.SA_modules):
+        m = int(mod.npoint * scale)
+        for si, (grouper, mlp) in enumerate(zip(mod.groupers, mod.mlps)):
+            convs = [c for c in mlp.modules() if isinstance(c, nn.Conv2d)]
+            dims = [convs[0].in_channels] + [c.out_channels for c in convs]
+            chain("SA%d.%d" % (li, si), B * m * grouper.nsample, dims, grouper.nsample, li > 0, B * n_in, dims[0] - 3)
+            if si == 0:
+                sa_width.append(0)
+                if li == 0:
+                    c_input = dims[0] - 3
+            sa_width[-1] += dims[-1]
+        n_in = m
+    n_unknown = [int(v * scale) for v in (12288, 2048, 1024, 512)]
+    n_known = [int(v * scale) for v in (2048, 1024, 512, 128)]
+    for fi, mod in enumerate(backbone.FP_modules):
+        convs = [c for c in mod.mlp.modules() if isinstance(c, nn.Conv2d)]
+        dims = [convs[0].in_channels] + [c.out_channels for c in convs]
+        # sources: the known points' features (interpolated, C2 channels) + the unknown points' own skip features (C1)
+        c1 = c_input if fi == 0 else sa_width[fi - 1]
+        c2 = dims[0] - c1
+        src_floats = B * (n_known[fi] * c2 + n_unknown[fi] * c1)
+        chain("FP%d" % fi, B * n_unknown[fi], dims, 0, True, src_floats, 1)
+    return dict(flops=flops, bytes=bytes_, per_level=levels)

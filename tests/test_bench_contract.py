@@ -89,3 +89,19 @@ def test_bench_self_launches_its_ranks_when_asked_for_more_than_one_gpu():
     r = subprocess.run([sys.executable, py, "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+
+
+def test_train_step_algorithmic_work():
+    """Config 5's accounting (train_step.algorithmic_work_per_step): forward + weight gradient + input gradient of every
+    SharedMLP layer = 3x the inference FLOPs minus the one input gradient nothing needs (SA level 0's first layers), and
+    a byte count dominated by the wide early levels; HBM is the binding roofline, not MFMA."""
+    from pvn3d_amd import train_step as ts
+    net = ts.PointVoteNet()
+    B = 24
+    w = ts.algorithmic_work_per_step(net.backbone, B)
+    sa, fp = bench.mlp_flops_per_frame(net.backbone, 1.0)
+    first = 2.0 * (2048 * 16 * 9 * 16 + 2048 * 32 * 9 * 32)            # SA0 layer 0, both scales, per frame
+    assert abs(w["flops"] - B * (3.0 * (sa + fp) - first)) <= 1e-9 * w["flops"]
+    assert len(w["per_level"]) == 12 and abs(sum(l["bytes"] for l in w["per_level"]) - w["bytes"]) < 1.0
+    t_hbm, t_mfma = w["bytes"] / (bench.PEAK_HBM_GBS * 1e9), w["flops"] / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
+    assert 25e9 < w["bytes"] < 40e9 and t_hbm > 5 * t_mfma
