@@ -205,6 +205,28 @@ int pvn3d_fp_interp_mlp(int b, int n, int m, int c2, int c1, const float* known_
                         const float* const* w_packed, const float* const* bias_padded, float* out,
                         int out_point_major, int ld_out, void* stream);
 
+/* The same two fused chains with the fp32 contraction carried by the bf16 matrix pipe (csrc/sa_mlp_split.hip): every
+ * fp32 operand is the exact sum of three bf16 pieces and a product is formed as the six partial products
+ * w_i.x_j (i + j <= 4) accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the three dropped terms are below 2^-24 of
+ * the product, fp32's own rounding step, so the results carry fp32 accuracy at 6/16 of the fp32-MFMA cost.
+ * Arguments as pvn3d_sa_mlp_maxpool (use_xyz = 1, features required) / pvn3d_fp_interp_mlp, except
+ *   w_split[l]  DEVICE int16[ceil(K/16)][ceil(M/32)][3][64][8]: entry (slab, mt, piece, lane, j) = piece `piece` (bf16
+ *               bits; hi = bf16(W'), mid = bf16(W' - hi), lo = bf16(W' - hi - mid), round to nearest) of
+ *               W'[mt*32 + (lane & 31)][16*slab + 8*(lane >> 5) + j], 0 outside M x K.
+ * Only the chain shapes the kernels are instantiated for are taken -- ask pvn3d_mlp_split_ok (1 = supported) with
+ * c_a = channels of the first row source (SA: c, FP: c2), c_b = FP skip channels c1 (SA: 0); row tables must be
+ * 16-byte aligned with ld % 4 == 0.  Unsupported shapes return hipErrorInvalidValue. */
+int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);
+int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                               const float* features_pm, int ld_feat, const int* idx, int n_layers,
+                               const int* dims_host, const void* const* w_split, const float* const* bias_padded,
+                               float* out_pm, int ld_out, int out_coff, void* stream);
+int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                              const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                              int n_layers, const int* dims_host, const void* const* w_split,
+                              const float* const* bias_padded, float* out, int out_point_major, int ld_out,
+                              void* stream);
+
 /* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */
 int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out, int ld_out,
                                void* stream);

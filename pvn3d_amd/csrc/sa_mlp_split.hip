@@ -1,0 +1,743 @@
+// sa_mlp_split.hip -- the fused "group -> SharedMLP -> max-pool" (set abstraction) and "three_interpolate -> concat ->
+// SharedMLP" (feature propagation) chains of csrc/sa_mlp.hip with the fp32 contraction carried by the bf16 matrix pipe.
+//
+// Same data flow and the same reference semantics as sa_mlp.hip (pvn3d/lib/pointnet2_utils/pointnet2_modules.py:57-69,
+// 183-206; pytorch_utils.py:25-50; eval BatchNorm folded on the host).  What changes is the arithmetic of the 1x1
+// convolutions.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  An fp32 number is the exact sum of three
+// bf16 numbers x = x1 + x2 + x3 (8 + 8 + 8 significant bits), a bf16 x bf16 product is exact in fp32, so
+//     w.x = sum_{i,j} w_i.x_j   accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+// The six terms with i + j <= 4 are kept; the three dropped ones are below 2^-24 of the product -- fp32's own rounding
+// step -- so the result carries fp32 accuracy (tools/mfma_split_bench.hip: max error 4.3e-7 of the output scale at
+// K = 512 against 2.7e-7 for the fp32 FMA chain, identical rms) at 6/16 of the fp32-MFMA cost.  It is NOT a reduced
+// precision path: no operand is rounded to bf16, every bit of both fp32 operands enters the product.
+//   * weights: split on the host (round to nearest per piece), packed per layer as
+//     [K/16 slabs][M/32 row tiles][3 pieces][64 lanes] x 16 bytes = the A fragment of one MFMA per load
+//     (lane l: row mt*32 + (l & 31), k = 16*slab + 8*(l >> 5) + 0..7);
+//   * activations: split by truncation where they are produced (x1 = x & 0xffff0000, x2 = (x - x1) & 0xffff0000,
+//     x3 = x - x1 - x2: exact, all three pieces share the sign) and kept in LDS as three bf16 planes P[piece][column][k]
+//     (row stride 2*Kcap + 16 bytes = 16 x odd: conflict-free 16-byte B-fragment reads).
+//
+// Workgroup = 4 MFMA waves + 4 loader waves (one of each per SIMD, 256 registers per wave), 64 columns ((centre,
+// sample) pairs or unknown points), persistent over column blocks.  A kernel is instantiated per chain signature
+// (row tiles per MFMA wave in layer 0 / 1 / 2): the layer sequence is straight-line code, every layer has exactly one
+// loop body, and nothing of one layer's address arithmetic or fragments stays alive across another's.  The layer-0 input is gathered, split and staged by the LOADER waves into a ring of four 32-channel
+// chunk buffers (loader wave j owns slot j and every fourth chunk); the MFMA waves only read LDS and stream weight
+// fragments, so their vmcnt queue never holds a gather (a weight load queued behind a gather completes after it, and
+// with bf16 MFMAs a chunk is multiplied in a third of the time a gather takes).  Loaders and MFMA waves meet through
+// LDS sequence words (ready / consumed per slot) and the MFMA waves synchronise among themselves through an LDS
+// counter -- s_barrier would stop the loaders, which run up to four chunks (into the next column block) ahead.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int S3_COLS = 64;
+constexpr int S3_KC = 32;                       // input channels per layer-0 chunk (two 16-k slabs)
+constexpr int S3_CS = 80;                       // bytes per column of a chunk buffer (64 + 16: 16 x odd)
+constexpr int S3_CPS = S3_COLS * S3_CS;         // bytes per piece plane of a chunk buffer
+constexpr int S3_CHUNK = 3 * S3_CPS;            // 15360 bytes
+constexpr int S3_RING = 4;                      // chunk buffers = loader waves
+constexpr int S3_NWC = 4;                       // MFMA (consumer) waves
+constexpr int S3_NWL = 4;                       // loader waves
+constexpr int S3_THREADS = 64 * (S3_NWC + S3_NWL);
+constexpr int S3_MAX_LAYERS = 4;
+constexpr int S3_EPAD = 68;                     // row stride (floats) of a wave's max-pool patch
+
+struct S3Args {
+  int n_layers;
+  int K[S3_MAX_LAYERS], M[S3_MAX_LAYERS];
+  const uint4* W[S3_MAX_LAYERS];                // packed split weights
+  const float* bias[S3_MAX_LAYERS];             // [ceil(M/32)*32] zero padded
+  int is_sa;
+  // set abstraction
+  const float* xyz;                             // (B, n, 3)
+  const float* new_xyz;                         // (B, m, 3)
+  int n, m, ns, tail_xyz;
+  // feature propagation
+  const float* weight;                          // (B, n_cols, 3)
+  const int* idx;                               // SA (B, m, ns); FP (B, n_cols, 3)
+  // layer-0 row sources (point-major tables)
+  const float* tabA; int rowsA, ldA, nA;        // SA: features, FP: known points; nA = 32-channel chunks
+  const float* tabB; int rowsB, ldB, nB;        // FP: the unknown points' own features (full chunks)
+  int tail_w;                                   // channels of the <= 8 wide tail chunk (SA: 3 xyz; FP: widthB - 32 nB)
+  int cols_total, bpf, n_blocks;                // columns per frame, column blocks per frame, blocks in all
+  int n_frames;
+  int rs, ps;                                   // P: bytes per column, bytes per piece plane
+  int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
+  int bias_off, bias_all;
+  float* out; int point_major, ld_out, coff;
+};
+
+// LDS control words (static): sequence numbers, all monotone
+struct S3Ctl {
+  unsigned rdy[S3_RING];      // chunk number + 1 that the slot holds (written by its loader wave)
+  unsigned fin[S3_RING];      // MFMA waves that have finished reading the slot, summed over its uses
+  unsigned bar;               // arrivals at the MFMA waves' barrier
+  unsigned blk;               // column blocks whose LDS the MFMA waves have released (ring overlaid on P only)
+};
+
+__device__ __forceinline__ unsigned lds_peek(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait_ge(const unsigned* p, unsigned v) {
+  // watchdog: a protocol error must end as a kernel fault, never as a hung GPU (2^24 polls of >= 64 cycles ~ 1 s; the
+  // longest legitimate wait is one layer of one column block, tens of microseconds)
+  unsigned spins = 0;
+  while ((int)(lds_peek(p) - v) < 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) __builtin_trap();
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_signal_add(unsigned* p, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // this wave's LDS traffic has completed
+  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// barrier of the MFMA waves only
+__device__ __forceinline__ void cbar(S3Ctl* ctl, unsigned& phase, int lane) {
+  lds_signal_add(&ctl->bar, lane);
+  phase += S3_NWC;
+  lds_wait_ge(&ctl->bar, phase);
+}
+
+// block q of the launch -> (frame, column block): frame f on XCD f mod 8 when the frame count allows (persistent
+// workgroup w visits q = w, w + gridDim, ...; gridDim is a multiple of 8, so a workgroup stays on "its" frames' XCD)
+__device__ __forceinline__ void s3_block_map(const S3Args& a, int q, int& bi, int& bx) {
+  if ((a.n_frames & 7) == 0) {
+    const int r = q >> 3;
+    bi = (q & 7) + 8 * (r / a.bpf);
+    bx = r % a.bpf;
+  } else {
+    bi = q / a.bpf;
+    bx = q % a.bpf;
+  }
+}
+
+// ---- exact 3-way split of four fp32 values (consecutive k) into three packed bf16x4 ---------------------------------
+__device__ __forceinline__ void split4(const float (&x)[4], uint2& h, uint2& m, uint2& l) {
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hb[i] = __float_as_uint(x[i]) & 0xffff0000u;
+    const float r1 = x[i] - __uint_as_float(hb[i]);
+    mb[i] = __float_as_uint(r1) & 0xffff0000u;
+    lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));      // <= 8 significant bits: its top half-word is exact
+  }
+  h.x = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u); h.y = __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u);
+  m.x = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u); m.y = __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u);
+  l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
+}
+
+// ---- loader waves -----------------------------------------------------------------------------------------------------
+// One loader wave stages one whole chunk (32 channels x 64 columns, or the <= 8-channel tail): lane -> row group
+// g = lane & 7 (channels 4g..4g+3), columns (lane >> 3) + 8 i, i < 8.
+template <bool IS_SA>
+__device__ __forceinline__ void loader_chunk(const S3Args& a, char* slot, int bi, int col0, int lc /*local chunk*/, int lane) {
+  const int g = lane & 7, cq = lane >> 3;
+  const int n_full = a.nA + a.nB;
+  if (lc < n_full) {
+    const bool fromA = lc < a.nA;
+    const float* tab = fromA ? a.tabA : a.tabB;
+    const int rows = fromA ? a.rowsA : a.rowsB, ld = fromA ? a.ldA : a.ldB;
+    const int cbase = (fromA ? lc : lc - a.nA) * S3_KC + 4 * g;
+    const float* t = tab + (size_t)bi * rows * ld + cbase;
+    float4 v[8];
+    if (IS_SA || !fromA) {
+      // one source row per column: SA neighbour index / FP the unknown point itself
+      int id[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
+        id[i] = IS_SA ? a.idx[(size_t)bi * a.cols_total + gc] : gc;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(t + (size_t)id[i] * ld);
+    } else {
+      // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order
+      int id[8][3];
+      float w[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
+        const size_t o = ((size_t)bi * a.cols_total + gc) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { id[i][k] = a.idx[o + k]; w[i][k] = a.weight[o + k]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 p0 = *reinterpret_cast<const float4*>(t + (size_t)id[i][0] * ld);
+        const float4 p1 = *reinterpret_cast<const float4*>(t + (size_t)id[i][1] * ld);
+        const float4 p2 = *reinterpret_cast<const float4*>(t + (size_t)id[i][2] * ld);
+        v[i].x = p0.x * w[i][0] + p1.x * w[i][1] + p2.x * w[i][2];
+        v[i].y = p0.y * w[i][0] + p1.y * w[i][1] + p2.y * w[i][2];
+        v[i].z = p0.z * w[i][0] + p1.z * w[i][1] + p2.z * w[i][2];
+        v[i].w = p0.w * w[i][0] + p1.w * w[i][1] + p2.w * w[i][2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cq + 8 * i;
+      const bool ok = col0 + c < a.cols_total;
+      const float x[4] = {ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f};
+      uint2 h, m, l;
+      split4(x, h, m, l);
+      char* d = slot + c * S3_CS + 8 * g;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + S3_CPS) = m;
+      *reinterpret_cast<uint2*>(d + 2 * S3_CPS) = l;
+    }
+  } else {
+    // tail chunk: one 16-k slab, channels [0, tail_w) real, the rest zero.  lane -> column lane, rows 0..15
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = 0.f;
+    const int gc = col0 + lane;
+    if (gc < a.cols_total) {
+      if (IS_SA) {
+        const int id = a.idx[(size_t)bi * a.cols_total + gc];
+        const float* p = a.xyz + ((size_t)bi * a.n + id) * 3;
+        const float* c = a.new_xyz + ((size_t)bi * a.m + gc / a.ns) * 3;
+        x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];      // grouped_xyz -= new_xyz
+      } else {
+        const float* p = a.tabB + ((size_t)bi * a.rowsB + gc) * a.ldB + a.nB * S3_KC;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < a.tail_w) x[k] = p[k];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float y[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+      uint2 h, m, l;
+      split4(y, h, m, l);
+      char* d = slot + lane * S3_CS + 8 * q;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + S3_CPS) = m;
+      *reinterpret_cast<uint2*>(d + 2 * S3_CPS) = l;
+    }
+  }
+}
+
+// ---- MFMA waves -------------------------------------------------------------------------------------------------------
+struct WSrc {               // this lane's view of a layer's packed weights
+  const uint4* p;           // + (tile0 * 3) * 64 + lane
+  size_t sstride;           // uint4 per slab = mt_total * 3 * 64
+  int last;                 // last slab
+};
+
+// B fragments of one slab: base = plane 0, this lane's column (+ column tile for CS), k offset of the slab
+template <bool CS>
+__device__ __forceinline__ void b_load(bf16x8 (&b)[CS ? 1 : 2][3], const char* base, int ps, int ct_bytes) {
+#pragma unroll
+  for (int c = 0; c < (CS ? 1 : 2); ++c)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      b[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (size_t)pc * ps + (size_t)c * ct_bytes));
+}
+
+// the six partial products of one slab, smallest terms first; consecutive MFMAs hit different accumulators
+template <int NTC, int NT, bool CS>
+__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NTC][3],
+                                        const bf16x8 (&b)[CS ? 1 : 2][3]) {
+#define S3_MM(PA, PB)                                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < (CS ? 1 : 2); ++c)             \
+      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t][PA]), b[c][PB], acc[t][c], 0, 0, 0)
+  S3_MM(0, 2); S3_MM(2, 0); S3_MM(1, 1);
+  S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
+#undef S3_MM
+}
+
+__device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb, int half) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(sb + 8 * g + 4 * half);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+}
+
+// One layer's MFMA loop shapes: NTC row tiles (tile0 + 4 t, clamped to the layer's last tile: a wave without a t-th
+// tile recomputes the last one and drops the result) x both column tiles.
+template <bool IS_SA, int N0, int N1, int N2>
+struct S3Consumer {
+  static constexpr int NMAX = N0 > N1 ? (N0 > N2 ? N0 : N2) : (N1 > N2 ? N1 : N2);
+  static constexpr int NL = N2 > 0 ? 3 : 2;
+  const S3Args& a;
+  char* P;
+  char* ring;
+  const float* s_bias;
+  S3Ctl* ctl;
+  int lane_, wave;
+  unsigned phase;          // barrier arrivals expected so far
+  unsigned chunk_no;       // chunks of this workgroup consumed so far (all blocks)
+
+  template <int NTC>
+  __device__ __forceinline__ WSrc wsrc(int l, int slabs, int lane) const {
+    const int mt_total = (a.M[l] + 31) >> 5;
+    WSrc w;
+    w.p = a.W[l] + lane;
+    w.sstride = (size_t)mt_total * 3 * 64;
+    w.last = slabs - 1;
+    return w;
+  }
+  template <int NTC>
+  __device__ __forceinline__ void tiles_of(int l, int (&tile)[NTC]) const {
+    const int mt_total = (a.M[l] + 31) >> 5;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) tile[t] = min(wave + S3_NWC * t, mt_total - 1);
+  }
+  template <int NTC>
+  __device__ __forceinline__ void a_load(uint4 (&r)[NTC][3], const WSrc& w, const int (&tile)[NTC], int slab) const {
+    const uint4* q = w.p + (size_t)min(slab, w.last) * w.sstride;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) r[t][pc] = q[((size_t)tile[t] * 3 + pc) * 64];
+  }
+  template <int NTC>
+  __device__ __forceinline__ void init_acc(f32x16 (&acc)[NMAX][2], const int (&tile)[NTC], int boff, int half) const {
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      acc_bias(acc[t][0], s_bias + boff + tile[t] * 32, half);
+      acc[t][1] = acc[t][0];
+    }
+  }
+
+  // layer 0: the input arrives chunk by chunk from the loader waves.  Slab j of the layer is multiplied from weight ring
+  // slot j & 1; the other slot is refilled at the start of the slab, so one slab of MFMAs covers the fetch.
+  template <int NTC>
+  __device__ __forceinline__ void layer0(f32x16 (&acc)[NMAX][2], int lane) {
+    const int half = lane >> 5, col = lane & 31;
+    const int n_full = a.nA + a.nB;
+    const bool tail = a.tail_w > 0;
+    const int slabs = 2 * n_full + (tail ? 1 : 0);
+    const WSrc w = wsrc<NTC>(0, slabs, lane);
+    int tile[NTC];
+    tiles_of<NTC>(0, tile);
+    init_acc<NTC>(acc, tile, 0, half);
+    uint4 ringA[2][NTC][3];
+    a_load<NTC>(ringA[0], w, tile, 0);
+    const int lane_off = col * S3_CS + half * 16;
+    int j = 0;
+    for (int c = 0; c < n_full; ++c, j += 2) {
+      const unsigned cn = chunk_no + c;
+      const int slot = cn & (S3_RING - 1);
+      lds_wait_ge(&ctl->rdy[slot], cn + 1);
+      const char* base = ring + (size_t)slot * S3_CHUNK + lane_off;
+      bf16x8 b0[2][3], b1[2][3];
+      a_load<NTC>(ringA[1], w, tile, j + 1);
+      b_load<false>(b0, base, S3_CPS, 32 * S3_CS);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
+      b_load<false>(b1, base + 32, S3_CPS, 32 * S3_CS);
+      a_load<NTC>(ringA[0], w, tile, j + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_slab<NTC, NMAX, false>(acc, ringA[1], b1);
+      lds_signal_add(&ctl->fin[slot], lane);
+    }
+    if (tail) {
+      const unsigned cn = chunk_no + n_full;
+      const int slot = cn & (S3_RING - 1);
+      lds_wait_ge(&ctl->rdy[slot], cn + 1);
+      bf16x8 b0[2][3];
+      b_load<false>(b0, ring + (size_t)slot * S3_CHUNK + lane_off, S3_CPS, 32 * S3_CS);
+      mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
+      lds_signal_add(&ctl->fin[slot], lane);
+    }
+    chunk_no += n_full + (tail ? 1 : 0);
+  }
+
+  // layers >= 1: the input is P
+  template <int NTC>
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], int l, int boff, int lane) {
+    const int half = lane >> 5, col = lane & 31;
+    const int slabs = (a.K[l] + 15) >> 4;
+    const WSrc w = wsrc<NTC>(l, slabs, lane);
+    int tile[NTC];
+    tiles_of<NTC>(l, tile);
+    init_acc<NTC>(acc, tile, boff, half);
+    const char* base = P + (size_t)col * a.rs + half * 16;
+    const int ctb = 32 * a.rs;
+    uint4 ringA[2][NTC][3];
+    bf16x8 b[2][2][3];
+    a_load<NTC>(ringA[0], w, tile, 0);
+    b_load<false>(b[0], base, a.ps, ctb);
+    int s = 0;
+    for (; s + 2 <= slabs; s += 2) {
+      a_load<NTC>(ringA[1], w, tile, s + 1);
+      b_load<false>(b[1], base + (size_t)(s + 1) * 32, a.ps, ctb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_slab<NTC, NMAX, false>(acc, ringA[0], b[0]);
+      a_load<NTC>(ringA[0], w, tile, s + 2);
+      b_load<false>(b[0], base + (size_t)min(s + 2, slabs - 1) * 32, a.ps, ctb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm_slab<NTC, NMAX, false>(acc, ringA[1], b[1]);
+    }
+    if (s < slabs) mm_slab<NTC, NMAX, false>(acc, ringA[0], b[0]);
+  }
+
+  // relu(tile) -> three bf16 planes of P: register group g of a tile holds rows mt*32 + 8g + 4*half + 0..3 of the lane's
+  // column = four consecutive k of the next layer = one 8-byte store per plane
+  __device__ __forceinline__ void store_tile(const f32x16& acc, int mt, int colx, int lane) {
+    const int half = lane >> 5;
+    char* d0 = P + (size_t)colx * a.rs + 64 * mt + 8 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float x[4] = {fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f), fmaxf(acc[4 * g + 2], 0.f),
+                          fmaxf(acc[4 * g + 3], 0.f)};
+      uint2 h, m, l;
+      split4(x, h, m, l);
+      char* d = d0 + 16 * g;
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + a.ps) = m;
+      *reinterpret_cast<uint2*>(d + 2 * (size_t)a.ps) = l;
+    }
+  }
+  template <int NTC>
+  __device__ __forceinline__ void store_layer(const f32x16 (&acc)[NMAX][2], int l, int lane) {
+    const int mt_total = (a.M[l] + 31) >> 5;
+    const int col = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      const int mt = wave + S3_NWC * t;
+      if (mt < mt_total) {
+        store_tile(acc[t][0], mt, col, lane);
+        store_tile(acc[t][1], mt, 32 + col, lane);
+      }
+    }
+  }
+
+  // a fresh opaque copy of the lane id per layer: every address of the layer derives from it, nothing can be hoisted
+  __device__ __forceinline__ int fresh_lane() const {
+    int l = lane_;
+    asm volatile("" : "+v"(l));
+    return l;
+  }
+
+  __device__ __forceinline__ void run_block(int bi, int col0) {
+    f32x16 acc[NMAX][2];
+    int boff = 0;
+    {
+      const int lane = fresh_lane();
+      layer0<N0>(acc, lane);
+      // every MFMA wave has finished reading its input (and the previous block's epilogue patches in P): P is free
+      cbar(ctl, phase, lane);
+      store_layer<N0>(acc, 0, lane);
+      cbar(ctl, phase, lane);
+      boff += ((a.M[0] + 31) >> 5) * 32;
+    }
+    if (NL == 3) {
+      const int lane = fresh_lane();
+      layerN<N1>(acc, 1, boff, lane);
+      cbar(ctl, phase, lane);
+      store_layer<N1>(acc, 1, lane);
+      cbar(ctl, phase, lane);
+      boff += ((a.M[1] + 31) >> 5) * 32;
+    }
+    constexpr int NLAST = NL == 3 ? N2 : N1;
+    {
+      const int lane = fresh_lane();
+      layerN<NLAST>(acc, NL - 1, boff, lane);
+      cbar(ctl, phase, lane);              // P is dead: the SA epilogue parks its patches there
+    }
+
+    // ---- epilogue on the last layer's accumulators (rows wave + 4 t, both column tiles)
+    const int lane = fresh_lane();
+    const int half = lane >> 5, col = lane & 31;
+    const int M = a.M[NL - 1];
+    const int mt_total = (M + 31) >> 5;
+    float* const out = a.out;
+    if (IS_SA) {
+      // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip)
+      float* sc = reinterpret_cast<float*>(P) + (size_t)wave * (32 * S3_EPAD);
+      const int ns = a.ns;
+      const int nout = ns >= 32 ? 1 : 32 / ns;
+      const int jbase = ns >= 64 ? col0 / ns : (col0 + 32 * half) / ns;
+#pragma unroll
+      for (int t = 0; t < NLAST; ++t) {
+        const int mt = wave + S3_NWC * t;
+        if (mt < mt_total) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[rr * S3_EPAD + col] = fmaxf(acc[t][0][r], 0.f);
+            sc[rr * S3_EPAD + 32 + col] = fmaxf(acc[t][1][r], 0.f);
+          }
+          __builtin_amdgcn_wave_barrier();
+          int v[32];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int4 q = *reinterpret_cast<const int4*>(sc + col * S3_EPAD + 32 * half + 4 * i);
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (ns >= 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = max(v[2 * i], v[2 * i + 1]);
+          }
+          if (ns >= 16) { v[0] = max(v[0], v[1]); v[1] = max(v[2], v[3]); }
+          if (ns >= 32) v[0] = max(v[0], v[1]);
+          if (ns >= 64) v[0] = max(v[0], __shfl_xor(v[0], 32, 64));
+          const int row = mt * 32 + col;
+          if (row < M && (ns < 64 || half == 0)) {
+            float* o = out + ((size_t)bi * a.m + jbase) * a.ld_out + a.coff + row;
+            if (nout <= 2) {
+              if (jbase < a.m) o[0] = __int_as_float(v[0]);
+              if (nout == 2 && jbase + 1 < a.m) o[a.ld_out] = __int_as_float(v[1]);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 32; ++q)
+                if (q < nout && jbase + q < a.m) o[(size_t)q * a.ld_out] = __int_as_float(v[q]);
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NLAST; ++t) {
+        const int mt = wave + S3_NWC * t;
+        if (mt < mt_total) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = mt * 32 + 8 * g + 4 * half;
+            const int g0 = col0 + col, g1 = col0 + 32 + col;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (row + k < M) {
+                const float v0 = fmaxf(acc[t][0][4 * g + k], 0.f), v1 = fmaxf(acc[t][1][4 * g + k], 0.f);
+                if (a.point_major) {
+                  if (g0 < a.cols_total) out[((size_t)bi * a.cols_total + g0) * a.ld_out + a.coff + row + k] = v0;
+                  if (g1 < a.cols_total) out[((size_t)bi * a.cols_total + g1) * a.ld_out + a.coff + row + k] = v1;
+                } else {
+                  if (g0 < a.cols_total) out[((size_t)bi * M + row + k) * a.cols_total + g0] = v0;
+                  if (g1 < a.cols_total) out[((size_t)bi * M + row + k) * a.cols_total + g1] = v1;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+};
+
+template <bool IS_SA, int N0, int N1, int N2>
+__global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
+  extern __shared__ char s_mem[];
+  __shared__ S3Ctl ctl;
+  char* P = s_mem;
+  char* ring = s_mem + a.ring_off;
+  float* s_bias = reinterpret_cast<float*>(s_mem + a.bias_off);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < (int)(sizeof(S3Ctl) / 4)) reinterpret_cast<unsigned*>(&ctl)[tid] = 0u;
+  {   // all biases of the chain -> LDS, once per (persistent) workgroup
+    int off = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+      const int mp = ((a.M[l] + 31) >> 5) << 5;
+      for (int i = tid; i < mp; i += S3_THREADS) s_bias[off + i] = a.bias[l][i];
+      off += mp;
+    }
+  }
+  __syncthreads();          // the only s_barrier: from here on the two roles only meet through LDS words
+
+  const int n_chunks = a.nA + a.nB + (a.tail_w > 0 ? 1 : 0);
+  if (wave >= S3_NWC) {
+    // ------------------------------------------------ loader wave j: slot j, chunks j, j + 4, ...
+    const int j = wave - S3_NWC;
+    char* slot = ring + (size_t)j * S3_CHUNK;
+    unsigned uses = 0;                   // how often the slot has been filled
+    unsigned base = 0;                   // chunk number of the current block's first chunk
+    unsigned blocks_done = 0;
+    for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x, base += n_chunks, ++blocks_done) {
+      int bi, bx;
+      s3_block_map(a, q, bi, bx);
+      // ring overlaid on P: this block's chunks may only be written once the MFMA waves have left the previous block
+      if (a.ring_off == 0 && blocks_done > 0) lds_wait_ge(&ctl.blk, blocks_done);
+      // first local chunk with (base + lc) % 4 == j
+      for (int lc = (int)((j - base) & (S3_RING - 1)); lc < n_chunks; lc += S3_RING) {
+        lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
+        loader_chunk<IS_SA>(a, slot, bi, bx * S3_COLS, lc, lane);
+        ++uses;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl.rdy[j], base + lc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return;
+  }
+  // ---------------------------------------------------- MFMA waves
+  S3Consumer<IS_SA, N0, N1, N2> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u};
+  for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
+    int bi, bx;
+    s3_block_map(a, q, bi, bx);
+    c.run_block(bi, bx * S3_COLS);
+    if (a.ring_off == 0) {
+      // the epilogue patches (P) are read by their own wave only; when every wave is through, the loaders may overwrite
+      cbar(&ctl, c.phase, lane);
+      if (wave == 0 && lane == 0) __hip_atomic_fetch_add(&ctl.blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+bool vec_ok(const float* p, int ld) { return p != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Chain signature = row tiles per MFMA wave in each layer; the instantiated ones are the shapes of PVN3D's backbone
+// that gain: SA level 2 (259 -> 128 -> 196 -> 256), FP level 0 (262 -> 128 -> 128), FP level 1 (608 -> 256 -> 256).
+// -1: no kernel for this chain (the caller keeps the fp32-MFMA kernels of sa_mlp.hip).
+int s3_signature(int is_sa, int n_layers, const int* dims) {
+  int n[3] = {0, 0, 0};
+  if (n_layers < 2 || n_layers > 3) return -1;
+  for (int l = 0; l < n_layers; ++l) n[l] = pvn3d_ceil_div(pvn3d_ceil_div(dims[l + 1], 32), S3_NWC);
+  const int sig = n[0] * 100 + n[1] * 10 + n[2];
+  if (is_sa) return sig == 122 ? sig : -1;
+  return (sig == 110 || sig == 220) ? sig : -1;
+}
+
+// LDS plan; false when the chain does not fit
+bool s3_plan(S3Args& a) {
+  int kcap = 32, bias_all = 0;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int mp = ((a.M[l] + 31) / 32) * 32;
+    if (l + 1 < a.n_layers) kcap = max(kcap, mp);
+    bias_all += mp;
+  }
+  a.rs = 2 * kcap + 16;                                    // 16 x odd (kcap is a multiple of 32)
+  a.ps = S3_COLS * a.rs;
+  size_t p_bytes = (size_t)3 * a.ps;
+  if (a.is_sa) p_bytes = max(p_bytes, (size_t)S3_NWC * 32 * S3_EPAD * 4);
+  const size_t ring_bytes = (size_t)S3_RING * S3_CHUNK;
+  const size_t bias_bytes = (size_t)bias_all * 4;
+  const size_t budget = 160 * 1024 - sizeof(S3Ctl) - 64;
+  if (p_bytes + ring_bytes + bias_bytes <= budget) {
+    a.ring_off = (int)p_bytes;
+    a.bias_off = (int)(p_bytes + ring_bytes);
+  } else if (max(p_bytes, ring_bytes) + bias_bytes <= budget) {
+    a.ring_off = 0;                                        // chunk ring overlaid on P
+    a.bias_off = (int)max(p_bytes, ring_bytes);
+  } else {
+    return false;
+  }
+  a.bias_all = bias_all;
+  return true;
+}
+
+int s3_launch(S3Args& a, int sig, hipStream_t st) {
+  if (!s3_plan(a)) return -1;
+  const size_t lds = (size_t)a.bias_off + (size_t)a.bias_all * 4;
+  a.bpf = pvn3d_ceil_div(a.cols_total, S3_COLS);
+  a.n_blocks = a.bpf * a.n_frames;
+  // persistent grid: one workgroup per CU (the LDS footprint allows no more), a multiple of 8 so that a workgroup's
+  // blocks stay on one XCD's frames
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int grid = min(a.n_blocks, cus);
+  if (grid >= 8) grid &= ~7;
+#define S3_GO(SA, A0, A1, A2)                                                                                 \
+  do {                                                                                                        \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2>));                \
+    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2>), dim3(grid), dim3(S3_THREADS), lds, st, a);      \
+  } while (0)
+  if (a.is_sa && sig == 122) S3_GO(true, 1, 2, 2);
+  else if (!a.is_sa && sig == 110) S3_GO(false, 1, 1, 0);
+  else if (!a.is_sa && sig == 220) S3_GO(false, 2, 2, 0);
+  else return -1;
+#undef S3_GO
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+bool s3_fill(S3Args* a, int n_layers, const int* dims, const void* const* w, const float* const* bias) {
+  if (n_layers < 1 || n_layers > S3_MAX_LAYERS) return false;
+  a->n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    a->K[l] = dims[l];
+    a->M[l] = dims[l + 1];
+    a->W[l] = reinterpret_cast<const uint4*>(w[l]);
+    a->bias[l] = bias[l];
+    if (dims[l] <= 0 || dims[l + 1] <= 0 || !w[l] || !bias[l]) return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+// 1: the split-bf16 family takes this shape; 0: use pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp (fp32 MFMA).
+// c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.
+extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host) {
+  if (!dims_host || n_layers < 2 || n_layers > 3) return 0;
+  if (c_a <= 0 || (c_a % S3_KC) != 0) return 0;                       // whole 32-channel row-gather chunks
+  if (is_sa) {
+    if (nsample <= 0 || (nsample & (nsample - 1)) || nsample > 64) return 0;
+  } else if ((c_b % S3_KC) > 8) {
+    return 0;                                                         // the tail chunk holds <= 8 channels
+  }
+  if (s3_signature(is_sa, n_layers, dims_host) < 0) return 0;
+  S3Args a = {};
+  a.n_layers = n_layers;
+  a.is_sa = is_sa;
+  for (int l = 0; l < n_layers; ++l) a.M[l] = dims_host[l + 1];
+  return s3_plan(a) ? 1 : 0;
+}
+
+extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz,
+                                          const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
+                                          int n_layers, const int* dims_host, const void* const* w_split,
+                                          const float* const* bias_padded, float* out_pm, int ld_out, int out_coff,
+                                          void* stream) {
+  if (b <= 0 || m <= 0) return 0;
+  if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
+    return (int)hipErrorInvalidValue;
+  if (!pvn3d_mlp_split_ok(1, c, 0, nsample, n_layers, dims_host) || dims_host[0] != c + 3 || !vec_ok(features_pm, ld_feat) ||
+      ld_feat < c || out_coff < 0 || ld_out < out_coff + dims_host[n_layers])
+    return (int)hipErrorInvalidValue;
+  S3Args a = {};
+  if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
+  a.is_sa = 1;
+  a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
+  a.idx = idx;
+  a.tabA = features_pm; a.rowsA = n; a.ldA = ld_feat; a.nA = c / S3_KC;
+  a.tail_w = 3;
+  a.cols_total = m * nsample;
+  a.n_frames = b;
+  a.out = out_pm; a.point_major = 1; a.ld_out = ld_out; a.coff = out_coff;
+  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host), (hipStream_t)stream);
+  return rc < 0 ? (int)hipErrorInvalidValue : rc;
+}
+
+extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                                         const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                                         int n_layers, const int* dims_host, const void* const* w_split,
+                                         const float* const* bias_padded, float* out, int out_point_major, int ld_out,
+                                         void* stream) {
+  if (b <= 0 || n <= 0) return 0;
+  if (!known_pm || !idx || !weight || !out || !dims_host || !w_split || !bias_padded || (c1 > 0 && !unknown_pm))
+    return (int)hipErrorInvalidValue;
+  if (!pvn3d_mlp_split_ok(0, c2, c1, 0, n_layers, dims_host) || dims_host[0] != c2 + c1 || !vec_ok(known_pm, ld_known) ||
+      ld_known < c2 || (c1 > 0 && ld_unknown < c1) || (c1 >= S3_KC && !vec_ok(unknown_pm, ld_unknown)) ||
+      (out_point_major && ld_out < dims_host[n_layers]))
+    return (int)hipErrorInvalidValue;
+  S3Args a = {};
+  if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
+  a.is_sa = 0;
+  a.idx = idx; a.weight = weight;
+  a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
+  a.tabB = unknown_pm; a.rowsB = n; a.ldB = ld_unknown; a.nB = c1 / S3_KC;
+  a.tail_w = c1 % S3_KC;
+  a.cols_total = n;
+  a.n_frames = b;
+  a.out = out; a.point_major = out_point_major ? 1 : 0; a.ld_out = ld_out; a.coff = 0;
+  const int rc = s3_launch(a, s3_signature(0, n_layers, dims_host), (hipStream_t)stream);
+  return rc < 0 ? (int)hipErrorInvalidValue : rc;
+}

@@ -14,6 +14,7 @@ grouped at the bottom.
 import torch
 
 from ..._lib import lib, check, on_device
+from . import _fused_mlp
 
 # Reproduce what the reference BINARY returns from three_interpolate_grad (it calls the forward
 # kernel with swapped sizes, pvn3d/_ext-src/src/interpolate.cpp:89-93).  Default: the
@@ -424,6 +425,14 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
         out_pm = torch.empty((B, m, (M + 3) // 4 * 4), dtype=torch.float32, device=xyz.device)
         out_coff = 0
     ld_out = out_pm.size(2)
+    if (use_xyz and feat is not None and _fused_mlp.MLP_ARITH == "bf16x3" and ld_feat % 4 == 0
+            and feat.data_ptr() % 16 == 0 and lib.pvn3d_mlp_split_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
+        with on_device(xyz.device):
+            check(lib.pvn3d_sa_mlp_maxpool_split(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),
+                                                 ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, packed.split(),
+                                                 packed.b_c, out_pm.data_ptr(), ld_out, out_coff, _stream(xyz)),
+                  "sa_mlp_maxpool_split")
+        return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
     with on_device(xyz.device):
         check(lib.pvn3d_sa_mlp_maxpool(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
                                        new_xyz.data_ptr(), feat.data_ptr() if feat is not None else None,
@@ -463,6 +472,16 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     else:
         ld_out = 0
         out = torch.empty((B, M, n), dtype=torch.float32, device=known_feats.device)
+    if (_fused_mlp.MLP_ARITH == "bf16x3" and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0
+            and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
+            and lib.pvn3d_mlp_split_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
+        with on_device(known_feats.device):
+            check(lib.pvn3d_fp_interp_mlp_split(B, n, m, C2, C1, kf.data_ptr(), ld_k,
+                                                uf.data_ptr() if uf is not None else None, ld_u, idx.data_ptr(),
+                                                weight.data_ptr(), packed.n_layers, packed.dims_c, packed.split(),
+                                                packed.b_c, out.data_ptr(), 1 if point_major_out else 0, ld_out,
+                                                _stream(known_feats)), "fp_interp_mlp_split")
+        return out[:, :, :M].transpose(1, 2) if point_major_out else out
     with on_device(known_feats.device):
         check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                       uf.data_ptr() if uf is not None else None, ld_u,

@@ -7,6 +7,7 @@ A layer is eligible when it is exactly [1x1 Conv2d] -> [BatchNorm2d in eval mode
 None and the caller keeps the unfused torch path.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -25,10 +26,18 @@ def invalidate_packed():
     _WEIGHTS_EPOCH[0] += 1
 
 
+# Arithmetic of the fused inference chains where a chain has both kernels (csrc/sa_mlp_split.hip decides per shape):
+#   "bf16x3": every fp32 operand as the exact sum of three bf16 pieces, six partial products per multiply accumulated in
+#             fp32 on the bf16 matrix pipe -- fp32 accuracy (the dropped terms are below fp32's own rounding step) at
+#             6/16 of the fp32-MFMA cost;
+#   "fp32":   v_mfma_f32_32x32x2_f32 everywhere (csrc/sa_mlp.hip).
+MLP_ARITH = os.environ.get("PVN3D_MLP_ARITH", "bf16x3")
+
+
 class PackedMLP(object):
     """Device buffers + the host pointer arrays pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp take."""
 
-    def __init__(self, dims, w_list, b_list):
+    def __init__(self, dims, w_list, b_list, folded=None):
         self.dims = list(dims)
         self.n_layers = len(w_list)
         self.w = w_list            # keep the tensors alive
@@ -36,6 +45,34 @@ class PackedMLP(object):
         self.dims_c = (ctypes.c_int * len(dims))(*dims)
         self.w_c = (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in w_list])
         self.b_c = (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in b_list])
+        self._folded = folded      # [(W' (M, K) fp32 in the kernels' layer-0 channel order)]: source of the split packing
+        self._split = None
+
+    def split(self):
+        """-> ctypes array of the split-bf16 weight buffers (csrc/sa_mlp_split.hip), built on first use."""
+        if self._split is None:
+            ws = [_pack_weight_split(W) for W in self._folded]
+            self._split = (ws, (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in ws]))
+        return self._split[1]
+
+
+def _pack_weight_split(W):
+    """W (M, K) float32 -> int16 [ceil(K/16) slabs][ceil(M/32) row tiles][3 pieces][64 lanes][8]: the three bf16 pieces
+    of W (each rounded to nearest: hi = bf16(W), mid = bf16(W - hi), lo = bf16(W - hi - mid); W - hi - mid - lo is at
+    most 2^-26 |W|), lane l of a fragment holding row mt*32 + (l & 31), k = 16*slab + 8*(l >> 5) + 0..7; zero outside
+    M x K (include/pvn3d_hip.h)."""
+    M, K = W.shape
+    MT, S = (M + 31) // 32, (K + 15) // 16
+    Wp = torch.zeros((MT * 32, S * 16), dtype=torch.float32, device=W.device)
+    Wp[:M, :K] = W
+    hi = Wp.to(torch.bfloat16)
+    r1 = Wp - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    pieces = torch.stack([hi, mid, lo], 0)                      # (3, MT*32, S*16)
+    # (piece, mt, r, s, half, j) -> (s, mt, piece, half, r, j)
+    out = pieces.view(3, MT, 32, S, 2, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
+    return out.view(torch.int16).view(S, MT, 3, 64, 8)
 
 
 def _pack_weight(W):
@@ -102,15 +139,16 @@ def pack_shared_mlp(mlp, max_width=512, n_xyz_first=0):
     if max(dims[1:]) > max_width or any(folded[i][0].shape[1] != dims[i] for i in range(len(folded))):
         mlp._pvn3d_packed = (sig, None)
         return None
-    w_list, b_list = [], []
+    w_list, b_list, w_folded = [], [], []
     for li, (W, b) in enumerate(folded):
         if li == 0 and n_xyz_first:
             W = torch.cat([W[:, n_xyz_first:], W[:, :n_xyz_first]], dim=1)
+        w_folded.append(W)
         w_list.append(_pack_weight(W))
         M = W.shape[0]
         bp = torch.zeros(((M + 31) // 32) * 32, dtype=torch.float32, device=W.device)
         bp[:M] = b
         b_list.append(bp)
-    packed = PackedMLP(dims, w_list, b_list)
+    packed = PackedMLP(dims, w_list, b_list, folded=w_folded)
     mlp._pvn3d_packed = (sig, packed)
     return packed

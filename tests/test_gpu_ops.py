@@ -1022,3 +1022,95 @@ def test_geometry_ahead_handle_gives_the_same_forward(dev):
         got0 = net(pcs[0], geometry=h0)
         got1 = net(pcs[1], geometry=h1)
     assert torch.equal(got0, want[0]) and torch.equal(got1, want[1])
+
+
+@pytest.mark.parametrize("c_in,mlp,ns,npoint,n,b", [
+    (64, [64, 128, 196, 256], 16, 70, 400, 2),        # ragged column count (70 * 16 = 17.5 blocks), 2 frames
+    (256, [256, 128, 196, 256], 32, 512, 1024, 8),    # SA level 2 of the backbone (lib/pvn3d.py:89-97), 8 frames (XCD map)
+    (96, [96, 100, 130, 200], 64, 9, 300, 3),         # nsample 64: one centre per block; widths not multiples of 32
+    (32, [32, 128, 256, 256], 8, 33, 200, 1),         # one 32-channel chunk + the xyz tail; nsample 8
+])
+def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns, npoint, n, b):
+    """csrc/sa_mlp_split.hip (fp32 operands as three bf16 pieces, six partial products on the bf16 matrix pipe, loader /
+    MFMA wave specialisation) against the fp32-MFMA chain of csrc/sa_mlp.hip on the same module, and both against a
+    float64 numpy evaluation: the split arithmetic carries fp32 accuracy (2e-5 of the output scale like the fp32 test
+    above; the two kernels agree to 2e-6)."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp
+    torch.manual_seed(7)
+    sa = pm.PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=0.08, nsample=ns).to(dev).eval()
+    _randomize_bn(sa)
+    xyz_np = clouds(41, b, n, 0.1)
+    feats_np = np.random.default_rng(8).normal(size=(b, c_in, n)).astype(np.float32)
+    # features as a transposed view of a point-major buffer (what Pointnet2MSG hands over between levels)
+    feats = T(np.ascontiguousarray(np.transpose(feats_np, (0, 2, 1))), dev).transpose(1, 2)
+    outs = {}
+    for arith in ("bf16x3", "fp32"):
+        _fused_mlp.MLP_ARITH = arith
+        try:
+            with torch.no_grad():
+                new_xyz, out = sa(T(xyz_np, dev), feats)
+        finally:
+            _fused_mlp.MLP_ARITH = "bf16x3"
+        outs[arith] = out.cpu().double().numpy()
+    packed = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
+    from pvn3d_amd._lib import lib
+    assert lib.pvn3d_mlp_split_ok(1, c_in, 0, ns, packed.n_layers, packed.dims_c) == 1      # the split kernel really ran
+    new_xyz_np = new_xyz.cpu().numpy()
+    idx = orc.ball_query(new_xyz_np, xyz_np, 0.08, ns)
+    b_ix = np.arange(b)[:, None, None]
+    gx = xyz_np[b_ix, idx].astype(np.float64) - new_xyz_np[:, :, None, :].astype(np.float64)
+    gf = np.transpose(feats_np, (0, 2, 1))[b_ix, idx].astype(np.float64)
+    h = np.concatenate([gx, gf], -1)
+    for layer in sa.mlps[0].children():
+        W = layer.conv.weight.detach().cpu().double().numpy()[:, :, 0, 0]
+        bn = layer.normlayer.bn
+        mu, var = bn.running_mean.cpu().double().numpy(), bn.running_var.cpu().double().numpy()
+        ga, be = bn.weight.detach().cpu().double().numpy(), bn.bias.detach().cpu().double().numpy()
+        h = np.maximum((h @ W.T - mu) / np.sqrt(var + bn.eps) * ga + be, 0.0)
+    want = np.transpose(h.max(axis=2), (0, 2, 1))
+    scale = max(1.0, np.abs(want).max())
+    e_split, e_fp32 = np.abs(outs["bf16x3"] - want).max() / scale, np.abs(outs["fp32"] - want).max() / scale
+    print("SA chain %s: max err / scale vs fp64: split %.2e, fp32 mfma %.2e" % (mlp, e_split, e_fp32))
+    assert e_split < 2e-5 and e_fp32 < 2e-5
+    assert np.abs(outs["bf16x3"] - outs["fp32"]).max() / scale < 2e-6
+
+
+@pytest.mark.parametrize("c2,c1,mlp,n,m,b,pm_out", [
+    (256, 6, [262, 128, 128], 1500, 300, 2, False),       # FP level 0 of the backbone: 6-channel tail, (B, C, n) output
+    (512, 96, [608, 256, 256], 700, 200, 8, True),        # FP level 1: three skip chunks, point-major output
+    (64, 40, [104, 100, 97], 257, 64, 3, True),           # one skip chunk + an 8-channel tail, ragged widths
+    (128, 0, [128, 200, 130], 130, 40, 1, False),         # no skip features
+])
+def test_split_bf16_fp_chain_matches_fp32_mfma(dev, c2, c1, mlp, n, m, b, pm_out):
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp
+    from pvn3d_amd._lib import lib
+    torch.manual_seed(9)
+    fp = pm.PointnetFPModule(mlp=list(mlp)).to(dev).eval()
+    _randomize_bn(fp)
+    fp._point_major_out = pm_out
+    unknown = T(clouds(51, b, n, 0.1), dev)
+    known = unknown[:, :m].contiguous()
+    kf = torch.randn(b, m, c2, device=dev).transpose(1, 2)                   # point-major producers
+    uf = torch.randn(b, n, c1 + 3, device=dev)[:, :, 3:].transpose(1, 2) if c1 else None      # a strided view like pc[..., 3:]
+    if c1 >= 32:
+        uf = torch.randn(b, n, c1, device=dev).transpose(1, 2)
+    outs = {}
+    for arith in ("bf16x3", "fp32"):
+        _fused_mlp.MLP_ARITH = arith
+        try:
+            with torch.no_grad():
+                outs[arith] = fp(unknown, known, uf, kf).clone()
+        finally:
+            _fused_mlp.MLP_ARITH = "bf16x3"
+    packed = _fused_mlp.pack_shared_mlp(fp.mlp)
+    assert lib.pvn3d_mlp_split_ok(0, c2, c1, 0, packed.n_layers, packed.dims_c) == 1
+    pm.FUSED_INFERENCE = False
+    try:
+        with torch.no_grad():
+            ref = fp(unknown, known, uf.contiguous() if uf is not None else None, kf.contiguous())
+    finally:
+        pm.FUSED_INFERENCE = True
+    scale = max(1.0, ref.abs().max().item())
+    assert outs["bf16x3"].shape == ref.shape == (b, mlp[-1], n)
+    assert (outs["bf16x3"] - outs["fp32"]).abs().max().item() / scale < 2e-6
+    assert (outs["bf16x3"] - ref).abs().max().item() / scale < 1e-4

@@ -231,3 +231,26 @@ def test_training_chain_only_takes_the_reference_shared_mlp_form():
     assert _train_mlp.shared_mlp_layers(odd) is None
     # the row-stride rule of the bf16 matrices: channels rounded up to 16
     assert [_train_mlp._ld(c) for c in (1, 9, 16, 17, 259, 515)] == [16, 16, 16, 32, 272, 528]
+
+
+def test_split_weight_packing_is_exact_and_in_fragment_order():
+    """_fused_mlp._pack_weight_split: the three bf16 pieces of a folded weight add back to it (to 2^-24 relative at worst --
+    three 8-bit pieces rounded to nearest), zero padding outside M x K, and entry (slab, mt, piece, lane, j) is row
+    mt*32 + (lane & 31), k = 16*slab + 8*(lane >> 5) + j -- the A fragment of v_mfma_f32_32x32x16_bf16."""
+    import torch
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+    torch.manual_seed(0)
+    W = torch.randn(70, 37) * torch.logspace(-3, 2, 37)[None]
+    P = _fused_mlp._pack_weight_split(W)
+    assert P.shape == (3, 3, 3, 64, 8) and P.dtype == torch.int16
+    pieces = P.view(torch.bfloat16).double()                                   # (S, MT, 3, 64, 8)
+    total = pieces.sum(2)                                                      # (S, MT, 64, 8)
+    full = torch.zeros(96, 48, dtype=torch.float64)
+    for s in range(3):
+        for mt in range(3):
+            for lane in range(64):
+                full[mt * 32 + (lane & 31), 16 * s + 8 * (lane >> 5):16 * s + 8 * (lane >> 5) + 8] = total[s, mt, lane]
+    assert float((full[:70, :37] - W.double()).abs().max() / W.abs().max()) < 2.0 ** -24
+    rel = ((full[:70, :37] - W.double()).abs() / W.double().abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 2.0 ** -23
+    assert float(full[70:].abs().max()) == 0.0 and float(full[:, 37:].abs().max()) == 0.0

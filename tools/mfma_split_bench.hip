@@ -86,22 +86,37 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(const void* __restrict__ W
     const size_t pstride = (size_t)4 * NT * 64, tstride = 4 * 64;
     const int pairs = K / 4;
     for (int rep = 0; rep < reps; ++rep) {
-      float2 a[2][NT];
-      for (int t = 0; t < NT; ++t) a[0][t] = W[t * tstride];
-      for (int p = 0; p < pairs; ++p) {
-        const int pn = min(p + 1, pairs - 1);
-        for (int t = 0; t < NT; ++t) a[(p + 1) & 1][t] = W[(size_t)pn * pstride + t * tstride];
-        const float* r0 = H + (size_t)p * 4 * 64 + half * 64;
-        const float b00 = r0[col], b01 = r0[col + 32], b10 = r0[128 + col], b11 = r0[128 + col + 32];
+      float2 ring[8][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][t].x, b00, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][t].x, b01, acc[t][1], 0, 0, 0);
-        }
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][t].y, b10, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][t].y, b11, acc[t][1], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) ring[u][t] = W[(size_t)u * pstride + t * tstride];
+      for (int p0 = 0; p0 < pairs; p0 += 8) {
+        const float* r0 = H + (size_t)p0 * 4 * 64 + half * 64;
+        float bb[2][4];
+        bb[0][0] = r0[col]; bb[0][1] = r0[col + 32]; bb[0][2] = r0[128 + col]; bb[0][3] = r0[128 + col + 32];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u + 1 < 8) {
+            const float* r1 = r0 + (u + 1) * 4 * 64;
+            bb[(u + 1) & 1][0] = r1[col]; bb[(u + 1) & 1][1] = r1[col + 32];
+            bb[(u + 1) & 1][2] = r1[128 + col]; bb[(u + 1) & 1][3] = r1[128 + col + 32];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][t].x, bb[u & 1][0], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][t].x, bb[u & 1][1], acc[t][1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][t].y, bb[u & 1][2], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][t].y, bb[u & 1][3], acc[t][1], 0, 0, 0);
+          }
+          const int pn = min(p0 + 8 + u, pairs - 1);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) ring[u][t] = W[(size_t)pn * pstride + t * tstride];
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -110,31 +125,58 @@ __global__ __launch_bounds__(256, 2) void loop_kernel(const void* __restrict__ W
     const int rs = 2 * K + 16;
     for (int i = tid; i < 3 * 64 * rs / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (i & 0xff);
     __syncthreads();
-    // A: [k16][row tile of the workgroup (4 * NT)][piece][64 lanes] x 16 bytes
+    // A: [k16][row tile of the workgroup (4 * NT)][piece][64 lanes] x 16 bytes; ring of D slabs, statically indexed
+    constexpr int D = 2;
     const uint4* W = reinterpret_cast<const uint4*>(Wv) + lane;
     const size_t kstride = (size_t)4 * NT * 3 * 64;
     const int slabs = K / 16;
+    const char* bbase = smem + (size_t)col * rs + half * 16;
     for (int rep = 0; rep < reps; ++rep) {
-      uint4 a[2][NT][3];
-      for (int t = 0; t < NT; ++t) for (int p = 0; p < 3; ++p) a[0][t][p] = W[((size_t)(wave + 4 * t) * 3 + p) * 64];
-      for (int s = 0; s < slabs; ++s) {
-        const int sn = min(s + 1, slabs - 1);
+      uint4 ring[D][NT][3];
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+#pragma unroll
         for (int t = 0; t < NT; ++t)
-          for (int p = 0; p < 3; ++p) a[(s + 1) & 1][t][p] = W[(size_t)sn * kstride + ((size_t)(wave + 4 * t) * 3 + p) * 64];
-        bf16x8 b[2][3];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+          for (int p = 0; p < 3; ++p) ring[u][t][p] = W[(size_t)u * kstride + ((size_t)(wave + 4 * t) * 3 + p) * 64];
+      bf16x8 b[2][2][3];
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
-            b[c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
-                smem + ((size_t)p * 64 + c * 32 + col) * rs + (size_t)s * 32 + half * 16));
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[0][c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bbase + ((size_t)p * 64 + c * 32) * rs));
+      // slab s is multiplied from ring[s & 1]; the refill of the OTHER slot (consumed by the previous slab) is issued at
+      // the start of the slab, so at the next slab's start it is the only load outstanding: vmcnt(0) is then exact, and
+      // the prefetch distance is one slab of MFMAs (the compiler puts vmcnt(0) at a loop head whatever is in flight)
+      for (int s0 = 0; s0 < slabs; s0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          const int s = s0 + u;
+          if (s > 0) {
+            const int sn = min(s + 1, slabs - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                ring[u ^ 1][t][p] = W[(size_t)sn * kstride + ((size_t)(wave + 4 * t) * 3 + p) * 64];
+          }
+          const int sb = min(s + 1, slabs - 1);
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              b[(u + 1) & 1][c][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                  bbase + ((size_t)p * 64 + c * 32) * rs + (size_t)sb * 32));
+          __builtin_amdgcn_sched_barrier(0);
 #define MM(PA, PB)                                                                                                       \
   _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                           \
-      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s & 1][t][PA]), b[c][PB], acc[t][c], 0, 0, 0)
-        if (MODE >= 9) { MM(2, 2); MM(1, 2); MM(2, 1); }
-        MM(0, 2); MM(2, 0); MM(1, 1);
-        MM(0, 1); MM(1, 0); MM(0, 0);
+      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[u][t][PA]), b[u & 1][c][PB], acc[t][c], 0, 0, 0)
+          if (MODE >= 9) { MM(2, 2); MM(1, 2); MM(2, 1); }
+          MM(0, 2); MM(2, 0); MM(1, 1);
+          MM(0, 1); MM(1, 0); MM(0, 0);
 #undef MM
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
