@@ -26,6 +26,8 @@
 // with bf16 MFMAs a chunk is multiplied in a third of the time a gather takes).  Loaders and MFMA waves meet through
 // LDS sequence words (ready / consumed per slot) and the MFMA waves synchronise among themselves through an LDS
 // counter -- s_barrier would stop the loaders, which run up to four chunks (into the next column block) ahead.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -68,7 +70,17 @@ struct S3Args {
   int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
   int bias_off, bias_all;
   float* out; int point_major, ld_out, coff;
+  int dbg;                                      // PVN3D_S3_DBG (tuning): 1 no gathers, 2 no index loads, 4 no layer-0 MFMAs, 8 no layer >= 1 MFMAs, 16 no split stores
 };
+
+// tuning probe (PVN3D_S3_DBG & 64): cycle stamps of workgroup 0 -- [0..63] MFMA wave 0 (8 stamps per column block),
+// [64..127] loader wave 0 (one stamp per chunk it staged, before / after)
+__device__ unsigned long long g_s3_prof[256];
+#define S3_STAMP(IDX)                                                                                   \
+  do {                                                                                                  \
+    if ((a.dbg & 64) && blockIdx.x == 0 && (IDX) < 128 && (threadIdx.x & 63) == 0)                       \
+      g_s3_prof[(IDX)] = __builtin_readcyclecounter();                                                  \
+  } while (0)
 
 // LDS control words (static): sequence numbers, all monotone
 struct S3Ctl {
@@ -150,10 +162,15 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, char* slot, int bi
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
-        id[i] = IS_SA ? a.idx[(size_t)bi * a.cols_total + gc] : gc;
+        id[i] = (IS_SA && !(a.dbg & 2)) ? a.idx[(size_t)bi * a.cols_total + gc] : gc % rows;
       }
+      if (a.dbg & 1) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(t + (size_t)id[i] * ld);
+        for (int i = 0; i < 8; ++i) v[i] = make_float4(0.25f * id[i], 1.f, 2.f, 3.f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(t + (size_t)id[i] * ld);
+      }
     } else {
       // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order
       int id[8][3];
@@ -271,6 +288,7 @@ struct S3Consumer {
   int lane_, wave;
   unsigned phase;          // barrier arrivals expected so far
   unsigned chunk_no;       // chunks of this workgroup consumed so far (all blocks)
+  int blk_no;              // column blocks done (probe only)
 
   template <int NTC>
   __device__ __forceinline__ WSrc wsrc(int l, int slabs, int lane) const {
@@ -290,6 +308,13 @@ struct S3Consumer {
   template <int NTC>
   __device__ __forceinline__ void a_load(uint4 (&r)[NTC][3], const WSrc& w, const int (&tile)[NTC], int slab) const {
     const uint4* q = w.p + (size_t)min(slab, w.last) * w.sstride;
+    if (a.dbg & 32) {        // tuning: no weight traffic
+#pragma unroll
+      for (int t = 0; t < NTC; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) r[t][pc] = make_uint4(0x3c003c00u + slab, 0x3c003c00u, 0x3c003c00u + pc, 0x3c003c00u);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
 #pragma unroll
@@ -304,8 +329,11 @@ struct S3Consumer {
     }
   }
 
-  // layer 0: the input arrives chunk by chunk from the loader waves.  Slab j of the layer is multiplied from weight ring
-  // slot j & 1; the other slot is refilled at the start of the slab, so one slab of MFMAs covers the fetch.
+  // Weight fragments: a ring of four slab slots per wave, slab s in slot s & 3; at the start of slab s the slot slab
+  // s - 1 has just left is refilled with slab s + 3.  Three slabs of MFMAs (1.1k - 2.3k cycles) cover the fetch: with
+  // every CU streaming weights the L2 round trip is ~2k cycles, and one slab of cover left the loops latency-bound
+  // (2.2 ms for SA level 2 whatever else was switched off).
+  // layer 0: the input arrives chunk by chunk (two slabs) from the loader waves.
   template <int NTC>
   __device__ __forceinline__ void layer0(f32x16 (&acc)[NMAX][2], int lane) {
     const int half = lane >> 5, col = lane & 31;
@@ -316,33 +344,45 @@ struct S3Consumer {
     int tile[NTC];
     tiles_of<NTC>(0, tile);
     init_acc<NTC>(acc, tile, 0, half);
-    uint4 ringA[2][NTC][3];
+    uint4 ringA[4][NTC][3];
     a_load<NTC>(ringA[0], w, tile, 0);
+    a_load<NTC>(ringA[1], w, tile, 1);
+    a_load<NTC>(ringA[2], w, tile, 2);
     const int lane_off = col * S3_CS + half * 16;
-    int j = 0;
-    for (int c = 0; c < n_full; ++c, j += 2) {
-      const unsigned cn = chunk_no + c;
-      const int slot = cn & (S3_RING - 1);
-      lds_wait_ge(&ctl->rdy[slot], cn + 1);
-      const char* base = ring + (size_t)slot * S3_CHUNK + lane_off;
-      bf16x8 b0[2][3], b1[2][3];
-      a_load<NTC>(ringA[1], w, tile, j + 1);
-      b_load<false>(b0, base, S3_CPS, 32 * S3_CS);
-      __builtin_amdgcn_sched_barrier(0);
-      mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
-      b_load<false>(b1, base + 32, S3_CPS, 32 * S3_CS);
-      a_load<NTC>(ringA[0], w, tile, j + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mm_slab<NTC, NMAX, false>(acc, ringA[1], b1);
-      lds_signal_add(&ctl->fin[slot], lane);
+    // one chunk = slabs j (slot U0) and j + 1 (slot U0 + 1)
+#define S3_CHUNK_STEP(C, U0)                                                                           \
+  do {                                                                                                 \
+    const unsigned cn_ = chunk_no + (C);                                                               \
+    const int slot_ = cn_ & (S3_RING - 1);                                                             \
+    lds_wait_ge(&ctl->rdy[slot_], cn_ + 1);                                                            \
+    const char* base_ = ring + (size_t)slot_ * S3_CHUNK + lane_off;                                    \
+    bf16x8 b0_[2][3], b1_[2][3];                                                                       \
+    a_load<NTC>(ringA[((U0) + 3) & 3], w, tile, 2 * (C) + 3);                                          \
+    b_load<false>(b0_, base_, S3_CPS, 32 * S3_CS);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (!(a.dbg & 4)) mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], b0_);                                \
+    b_load<false>(b1_, base_ + 32, S3_CPS, 32 * S3_CS);                                                \
+    a_load<NTC>(ringA[((U0) + 4) & 3], w, tile, 2 * (C) + 4);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (!(a.dbg & 4)) mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], b1_);                            \
+    lds_signal_add(&ctl->fin[slot_], lane);                                                            \
+  } while (0)
+    int c = 0;
+    for (; c + 2 <= n_full; c += 2) {
+      S3_CHUNK_STEP(c, 0);
+      S3_CHUNK_STEP(c + 1, 2);
     }
+    const bool odd = c < n_full;
+    if (odd) S3_CHUNK_STEP(c, 0);
+#undef S3_CHUNK_STEP
     if (tail) {
       const unsigned cn = chunk_no + n_full;
       const int slot = cn & (S3_RING - 1);
       lds_wait_ge(&ctl->rdy[slot], cn + 1);
       bf16x8 b0[2][3];
       b_load<false>(b0, ring + (size_t)slot * S3_CHUNK + lane_off, S3_CPS, 32 * S3_CS);
-      mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
+      if (odd) mm_slab<NTC, NMAX, false>(acc, ringA[2], b0);
+      else mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
       lds_signal_add(&ctl->fin[slot], lane);
     }
     chunk_no += n_full + (tail ? 1 : 0);
@@ -359,22 +399,31 @@ struct S3Consumer {
     init_acc<NTC>(acc, tile, boff, half);
     const char* base = P + (size_t)col * a.rs + half * 16;
     const int ctb = 32 * a.rs;
-    uint4 ringA[2][NTC][3];
+    uint4 ringA[4][NTC][3];
     bf16x8 b[2][2][3];
     a_load<NTC>(ringA[0], w, tile, 0);
+    a_load<NTC>(ringA[1], w, tile, 1);
+    a_load<NTC>(ringA[2], w, tile, 2);
     b_load<false>(b[0], base, a.ps, ctb);
+#define S3_SLAB_STEP(S, U)                                                                             \
+  do {                                                                                                 \
+    a_load<NTC>(ringA[((U) + 3) & 3], w, tile, (S) + 3);                                               \
+    b_load<false>(b[((U) + 1) & 1], base + (size_t)min((S) + 1, slabs - 1) * 32, a.ps, ctb);           \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if (!(a.dbg & 8)) mm_slab<NTC, NMAX, false>(acc, ringA[(U)], b[(U) & 1]);                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
     int s = 0;
-    for (; s + 2 <= slabs; s += 2) {
-      a_load<NTC>(ringA[1], w, tile, s + 1);
-      b_load<false>(b[1], base + (size_t)(s + 1) * 32, a.ps, ctb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm_slab<NTC, NMAX, false>(acc, ringA[0], b[0]);
-      a_load<NTC>(ringA[0], w, tile, s + 2);
-      b_load<false>(b[0], base + (size_t)min(s + 2, slabs - 1) * 32, a.ps, ctb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm_slab<NTC, NMAX, false>(acc, ringA[1], b[1]);
+    for (; s + 4 <= slabs; s += 4) {
+      S3_SLAB_STEP(s, 0);
+      S3_SLAB_STEP(s + 1, 1);
+      S3_SLAB_STEP(s + 2, 2);
+      S3_SLAB_STEP(s + 3, 3);
     }
-    if (s < slabs) mm_slab<NTC, NMAX, false>(acc, ringA[0], b[0]);
+    if (s < slabs) S3_SLAB_STEP(s, 0);
+    if (s + 1 < slabs) S3_SLAB_STEP(s + 1, 1);
+    if (s + 2 < slabs) S3_SLAB_STEP(s + 2, 2);
+#undef S3_SLAB_STEP
   }
 
   // relu(tile) -> three bf16 planes of P: register group g of a tile holds rows mt*32 + 8g + 4*half + 0..3 of the lane's
@@ -401,7 +450,7 @@ struct S3Consumer {
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
       const int mt = wave + S3_NWC * t;
-      if (mt < mt_total) {
+      if (mt < mt_total && !(a.dbg & 16)) {
         store_tile(acc[t][0], mt, col, lane);
         store_tile(acc[t][1], mt, 32 + col, lane);
       }
@@ -418,29 +467,38 @@ struct S3Consumer {
   __device__ __forceinline__ void run_block(int bi, int col0) {
     f32x16 acc[NMAX][2];
     int boff = 0;
+    const int pb = wave == 0 ? blk_no * 8 : 1 << 20;
+    S3_STAMP(pb + 0);
     {
       const int lane = fresh_lane();
       layer0<N0>(acc, lane);
+      S3_STAMP(pb + 1);
       // every MFMA wave has finished reading its input (and the previous block's epilogue patches in P): P is free
       cbar(ctl, phase, lane);
+      S3_STAMP(pb + 2);
       store_layer<N0>(acc, 0, lane);
       cbar(ctl, phase, lane);
+      S3_STAMP(pb + 3);
       boff += ((a.M[0] + 31) >> 5) * 32;
     }
     if (NL == 3) {
       const int lane = fresh_lane();
       layerN<N1>(acc, 1, boff, lane);
+      S3_STAMP(pb + 4);
       cbar(ctl, phase, lane);
       store_layer<N1>(acc, 1, lane);
       cbar(ctl, phase, lane);
+      S3_STAMP(pb + 5);
       boff += ((a.M[1] + 31) >> 5) * 32;
     }
     constexpr int NLAST = NL == 3 ? N2 : N1;
     {
       const int lane = fresh_lane();
       layerN<NLAST>(acc, NL - 1, boff, lane);
+      S3_STAMP(pb + 6);
       cbar(ctl, phase, lane);              // P is dead: the SA epilogue parks its patches there
     }
+    ++blk_no;
 
     // ---- epilogue on the last layer's accumulators (rows wave + 4 t, both column tiles)
     const int lane = fresh_lane();
@@ -527,13 +585,18 @@ struct S3Consumer {
         }
       }
     }
+    S3_STAMP(pb + 7);
   }
 };
 
 template <bool IS_SA, int N0, int N1, int N2>
 __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
-  extern __shared__ char s_mem[];
-  __shared__ S3Ctl ctl;
+  // 16-byte aligned dynamic LDS (every fragment read is a ds_read_b128: a base that is only 8-byte aligned -- what a
+  // static __shared__ object in front of it produces -- turns each of them into a slow misaligned access); the control
+  // words live in a 64-byte static block so that the dynamic segment starts on a multiple of 16
+  extern __shared__ __attribute__((aligned(16))) char s_mem[];
+  __shared__ __attribute__((aligned(64))) S3Ctl ctl_storage[2];      // 2 x 40 bytes -> padded to 128
+  S3Ctl& ctl = ctl_storage[0];
   char* P = s_mem;
   char* ring = s_mem + a.ring_off;
   float* s_bias = reinterpret_cast<float*>(s_mem + a.bias_off);
@@ -565,8 +628,12 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
       if (a.ring_off == 0 && blocks_done > 0) lds_wait_ge(&ctl.blk, blocks_done);
       // first local chunk with (base + lc) % 4 == j
       for (int lc = (int)((j - base) & (S3_RING - 1)); lc < n_chunks; lc += S3_RING) {
+        const int pl = j == 0 ? 64 + 3 * (int)uses : 1 << 20;
+        S3_STAMP(pl);
         lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
+        S3_STAMP(pl + 1);
         loader_chunk<IS_SA>(a, slot, bi, bx * S3_COLS, lc, lane);
+        S3_STAMP(pl + 2);
         ++uses;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(&ctl.rdy[j], base + lc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -575,7 +642,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u};
+  S3Consumer<IS_SA, N0, N1, N2> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -616,7 +683,7 @@ bool s3_plan(S3Args& a) {
   if (a.is_sa) p_bytes = max(p_bytes, (size_t)S3_NWC * 32 * S3_EPAD * 4);
   const size_t ring_bytes = (size_t)S3_RING * S3_CHUNK;
   const size_t bias_bytes = (size_t)bias_all * 4;
-  const size_t budget = 160 * 1024 - sizeof(S3Ctl) - 64;
+  const size_t budget = 160 * 1024 - 256;
   if (p_bytes + ring_bytes + bias_bytes <= budget) {
     a.ring_off = (int)p_bytes;
     a.bias_off = (int)(p_bytes + ring_bytes);
@@ -632,6 +699,10 @@ bool s3_plan(S3Args& a) {
 
 int s3_launch(S3Args& a, int sig, hipStream_t st) {
   if (!s3_plan(a)) return -1;
+  {
+    const char* e = getenv("PVN3D_S3_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const size_t lds = (size_t)a.bias_off + (size_t)a.bias_all * 4;
   a.bpf = pvn3d_ceil_div(a.cols_total, S3_COLS);
   a.n_blocks = a.bpf * a.n_frames;
@@ -672,6 +743,10 @@ bool s3_fill(S3Args* a, int n_layers, const int* dims, const void* const* w, con
 }
 
 }  // namespace
+
+extern "C" int pvn3d_debug_s3_prof_read(unsigned long long* host256) {
+  return (int)hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_s3_prof), sizeof(unsigned long long) * 256);
+}
 
 // 1: the split-bf16 family takes this shape; 0: use pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp (fp32 MFMA).
 // c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Phase timeline of workgroup 0 of the split-bf16 SA level-2 kernel (PVN3D_S3_DBG & 64 stamps, csrc/sa_mlp_split.hip)."""
+import ctypes
+import os
+import sys
+
+os.environ["PVN3D_S3_DBG"] = str(64 | int(os.environ.get("S3_EXTRA", "0")))
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm  # noqa: E402
+from pvn3d_amd import synth  # noqa: E402
+from pvn3d_amd._lib import lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = 64
+xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
+sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
+feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+with torch.no_grad():
+    geo = sa.sample_and_query(xyz)
+    for _ in range(3):
+        sa(xyz, feats, geometry=geo)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 256)()
+f = lib._lib.pvn3d_debug_s3_prof_read if hasattr(lib, "_lib") else ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "libpvn3d_hip.so")).pvn3d_debug_s3_prof_read
+f.argtypes = [ctypes.c_void_p]
+assert f(buf) == 0
+t = np.array(buf[:], dtype=np.int64)
+names = ["start", "layer0 done", "bar", "store0+bar", "layer1 done", "bar+store1+bar", "layer2 done", "epilogue done"]
+t0 = t[0]
+for blk in range(4):
+    row = t[blk * 8:blk * 8 + 8] - t0
+    print("block %d:" % blk, "  ".join("%s %d" % (n, v) for n, v in zip(names, row)))
+    print("        deltas:", np.diff(row))
+print("loader wave 0 (wait-start, wait-end, chunk-done) x chunks, relative:")
+l = t[64:64 + 30].reshape(-1, 3) - t0
+print(l)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Time the split-bf16 fused chains (csrc/sa_mlp_split.hip) of the backbone shapes against the fp32-MFMA kernels,
+64 frames; PVN3D_S3_DBG (see sa_mlp_split.hip) switches pieces off for tuning.  Usage: python tools/s3_time.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp  # noqa: E402
+from pvn3d_amd import synth  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def ms_of(fn, reps=5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B = 64
+    torch.manual_seed(0)
+    xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
+    cases = []
+    # SA level 2: 1024 -> 512 centres, C = 256, ns 16 / 32
+    for ns, radius in ((16, 0.05), (32, 0.1)):
+        sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=radius, nsample=ns).to(dev).eval()
+        feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+        with torch.no_grad():
+            geo = sa.sample_and_query(xyz)
+        cases.append(("SA2 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz, feats, geometry=geo),
+                      2.0 * (259 * 128 + 128 * 196 + 196 * 256) * 512 * ns * B))
+    # FP level 0: 12288 <- 2048, C2 = 256, C1 = 6; FP level 1: 2048 <- 1024, 512 + 96
+    for name, n, m, c2, c1, mlp in (("FP0", 12288, 2048, 256, 6, [262, 128, 128]), ("FP1", 2048, 1024, 512, 96, [608, 256, 256])):
+        fp = pm.PointnetFPModule(mlp=mlp).to(dev).eval()
+        fp._point_major_out = True
+        unk = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=n, n_obj=256)["pcld"] for i in range(B)])).to(dev)
+        kn = unk[:, :m].contiguous()
+        kf = torch.randn(B, m, c2, device=dev).transpose(1, 2)
+        uf = torch.randn(B, n, c1 + 3, device=dev)[:, :, 3:].transpose(1, 2) if c1 < 32 else torch.randn(B, n, c1, device=dev).transpose(1, 2)
+        with torch.no_grad():
+            nb = fp.neighbours(unk, kn)
+        cases.append((name, lambda fp=fp, unk=unk, kn=kn, uf=uf, kf=kf, nb=nb: fp(unk, kn, uf, kf, neighbours=nb),
+                      2.0 * sum(a * b for a, b in zip(mlp[:-1], mlp[1:])) * n * B))
+    for name, fn, flops in cases:
+        res = {}
+        for arith in ("fp32", "bf16x3"):
+            _fused_mlp.MLP_ARITH = arith
+            with torch.no_grad():
+                res[arith] = ms_of(fn)
+        print("%-9s fp32 mfma %7.3f ms (%6.1f TF/s)   split bf16 %7.3f ms (%6.1f TF/s fp32-equivalent)   dbg=%s" % (
+            name, res["fp32"], flops / res["fp32"] / 1e9, res["bf16x3"], flops / res["bf16x3"] / 1e9,
+            os.environ.get("PVN3D_S3_DBG", "0")))
+
+
+if __name__ == "__main__":
+    main()
