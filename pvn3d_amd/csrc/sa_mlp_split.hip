@@ -70,7 +70,7 @@ struct S3Args {
   int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
   int bias_off, bias_all;
   float* out; int point_major, ld_out, coff;
-  int dbg;                                      // PVN3D_S3_DBG (tuning): 1 no gathers, 2 no index loads, 4 no layer-0 MFMAs, 8 no layer >= 1 MFMAs, 16 no split stores
+  int dbg;                                      // PVN3D_S3_DBG (tuning): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
 };
 
 // tuning probe (PVN3D_S3_DBG & 64): cycle stamps of workgroup 0 -- [0..63] MFMA wave 0 (8 stamps per column block),
@@ -144,9 +144,35 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2& h, uint2& m, 
 
 // ---- loader waves -----------------------------------------------------------------------------------------------------
 // One loader wave stages one whole chunk (32 channels x 64 columns, or the <= 8-channel tail): lane -> row group
-// g = lane & 7 (channels 4g..4g+3), columns (lane >> 3) + 8 i, i < 8.
+// g = lane & 7 (channels 4g..4g+3), columns (lane >> 3) + 8 i, i < 8.  The per-column gather information (neighbour
+// indices, interpolation weights) is loaded ONCE per column block into registers (LoaderCols), so that a chunk costs one
+// global round trip, not two.
 template <bool IS_SA>
-__device__ __forceinline__ void loader_chunk(const S3Args& a, char* slot, int bi, int col0, int lc /*local chunk*/, int lane) {
+struct LoaderCols {
+  int id[8][IS_SA ? 1 : 3];
+  float w[8][IS_SA ? 1 : 3];
+};
+
+template <bool IS_SA>
+__device__ __forceinline__ void loader_cols(const S3Args& a, LoaderCols<IS_SA>& lcx, int bi, int col0, int lane) {
+  const int cq = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
+    if (IS_SA) {
+      lcx.id[i][0] = (a.dbg & 2) ? gc % a.rowsA : a.idx[(size_t)bi * a.cols_total + gc];
+      lcx.w[i][0] = 1.f;
+    } else {
+      const size_t o = ((size_t)bi * a.cols_total + gc) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lcx.id[i][k] = a.idx[o + k]; lcx.w[i][k] = a.weight[o + k]; }
+    }
+  }
+}
+
+template <bool IS_SA>
+__device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<IS_SA>& lcx, char* slot, int bi, int col0,
+                                             int lc /*local chunk*/, int lane) {
   const int g = lane & 7, cq = lane >> 3;
   const int n_full = a.nA + a.nB;
   if (lc < n_full) {
@@ -158,39 +184,37 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, char* slot, int bi
     float4 v[8];
     if (IS_SA || !fromA) {
       // one source row per column: SA neighbour index / FP the unknown point itself
-      int id[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
-        id[i] = (IS_SA && !(a.dbg & 2)) ? a.idx[(size_t)bi * a.cols_total + gc] : gc % rows;
-      }
       if (a.dbg & 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = make_float4(0.25f * id[i], 1.f, 2.f, 3.f);
+        for (int i = 0; i < 8; ++i) v[i] = make_float4(0.25f * lcx.id[i][0], 1.f, 2.f, 3.f);
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(t + (size_t)id[i] * ld);
+        for (int i = 0; i < 8; ++i) {
+          const int id = IS_SA ? lcx.id[i][0] : min(col0 + cq + 8 * i, a.cols_total - 1);
+          v[i] = *reinterpret_cast<const float4*>(t + (size_t)id * ld);
+        }
       }
     } else {
-      // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order
-      int id[8][3];
-      float w[8][3];
+      // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order; two halves of
+      // four columns (12 rows in flight each: 24 at once made the 4-wave kernels spill)
+      constexpr int K1 = IS_SA ? 0 : 1, K2 = IS_SA ? 0 : 2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
-        const size_t o = ((size_t)bi * a.cols_total + gc) * 3;
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 p[4][IS_SA ? 1 : 3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { id[i][k] = a.idx[o + k]; w[i][k] = a.weight[o + k]; }
-      }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 p0 = *reinterpret_cast<const float4*>(t + (size_t)id[i][0] * ld);
-        const float4 p1 = *reinterpret_cast<const float4*>(t + (size_t)id[i][1] * ld);
-        const float4 p2 = *reinterpret_cast<const float4*>(t + (size_t)id[i][2] * ld);
-        v[i].x = p0.x * w[i][0] + p1.x * w[i][1] + p2.x * w[i][2];
-        v[i].y = p0.y * w[i][0] + p1.y * w[i][1] + p2.y * w[i][2];
-        v[i].z = p0.z * w[i][0] + p1.z * w[i][1] + p2.z * w[i][2];
-        v[i].w = p0.w * w[i][0] + p1.w * w[i][1] + p2.w * w[i][2];
+          for (int k = 0; k < (IS_SA ? 1 : 3); ++k)
+            p[i][k] = *reinterpret_cast<const float4*>(t + (size_t)lcx.id[4 * hh + i][k] * ld);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float w0 = lcx.w[4 * hh + i][0], w1 = lcx.w[4 * hh + i][K1], w2 = lcx.w[4 * hh + i][K2];
+          v[4 * hh + i].x = p[i][0].x * w0 + p[i][K1].x * w1 + p[i][K2].x * w2;
+          v[4 * hh + i].y = p[i][0].y * w0 + p[i][K1].y * w1 + p[i][K2].y * w2;
+          v[4 * hh + i].z = p[i][0].z * w0 + p[i][K1].z * w1 + p[i][K2].z * w2;
+          v[4 * hh + i].w = p[i][0].w * w0 + p[i][K1].w * w1 + p[i][K2].w * w2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
@@ -238,9 +262,15 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, char* slot, int bi
 }
 
 // ---- MFMA waves -------------------------------------------------------------------------------------------------------
-struct WSrc {               // this lane's view of a layer's packed weights
-  const uint4* p;           // + (tile0 * 3) * 64 + lane
-  size_t sstride;           // uint4 per slab = mt_total * 3 * 64
+// A layer's packed weights as the MFMA loops address them: a wave-uniform (SGPR) base that advances by one slab, plus
+// one 32-bit per-lane byte offset per row tile; the three pieces of a tile sit 1 KiB apart (instruction offsets).
+// Nothing of an A-fragment address is computed on the VALU inside the loops -- on this chip a wave's VALU work does
+// not overlap its own MFMAs, so every vector instruction in a slab is time taken from the matrix pipe.
+template <int NTC>
+struct WSrc {
+  const char* sbase;        // layer's weights (uniform)
+  unsigned voff[NTC];       // (tile * 3 * 64 + lane) * 16
+  unsigned sstride;         // bytes per slab = mt_total * 3 * 64 * 16
   int last;                 // last slab
 };
 
@@ -291,48 +321,61 @@ struct S3Consumer {
   int blk_no;              // column blocks done (probe only)
 
   template <int NTC>
-  __device__ __forceinline__ WSrc wsrc(int l, int slabs, int lane) const {
+  __device__ __forceinline__ WSrc<NTC> wsrc(int l, int slabs, int lane) const {
     const int mt_total = (a.M[l] + 31) >> 5;
-    WSrc w;
-    w.p = a.W[l] + lane;
-    w.sstride = (size_t)mt_total * 3 * 64;
+    WSrc<NTC> w;
+    w.sbase = reinterpret_cast<const char*>(a.W[l]);
+    w.sstride = (unsigned)mt_total * 3u * 64u * 16u;
     w.last = slabs - 1;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) w.voff[t] = ((unsigned)min(wave + S3_NWC * t, mt_total - 1) * 192u + (unsigned)lane) * 16u;
     return w;
   }
   template <int NTC>
-  __device__ __forceinline__ void tiles_of(int l, int (&tile)[NTC]) const {
-    const int mt_total = (a.M[l] + 31) >> 5;
-#pragma unroll
-    for (int t = 0; t < NTC; ++t) tile[t] = min(wave + S3_NWC * t, mt_total - 1);
-  }
-  template <int NTC>
-  __device__ __forceinline__ void a_load(uint4 (&r)[NTC][3], const WSrc& w, const int (&tile)[NTC], int slab) const {
-    const uint4* q = w.p + (size_t)min(slab, w.last) * w.sstride;
-    if (a.dbg & 32) {        // tuning: no weight traffic
-#pragma unroll
-      for (int t = 0; t < NTC; ++t)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) r[t][pc] = make_uint4(0x3c003c00u + slab, 0x3c003c00u, 0x3c003c00u + pc, 0x3c003c00u);
-      return;
-    }
+  __device__ __forceinline__ void a_load(uint4 (&r)[NTC][3], const WSrc<NTC>& w, int slab) const {
+    const char* sb = w.sbase + (size_t)((unsigned)min(slab, w.last) * w.sstride);      // scalar
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) r[t][pc] = q[((size_t)tile[t] * 3 + pc) * 64];
+      for (int pc = 0; pc < 3; ++pc) r[t][pc] = *reinterpret_cast<const uint4*>(sb + w.voff[t] + pc * 1024);
+  }
+  // LDS byte addresses of this lane's B fragments: [column tile][piece]; a slab is + 32 bytes (an instruction offset)
+  struct BSrc {
+    const char* p[2][3];
+  };
+  __device__ __forceinline__ BSrc bsrc(const char* base, int ps, int ct_bytes) const {
+    BSrc b;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) b.p[c][pc] = base + (size_t)c * ct_bytes + (size_t)pc * ps;
+    return b;
+  }
+  template <int OFF>
+  __device__ __forceinline__ void b_ld(bf16x8 (&b)[2][3], const BSrc& src) const {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) b[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(src.p[c][pc] + OFF));
+  }
+  __device__ __forceinline__ void tiles_bias(int l, int (&tile)[NMAX], int n) const {
+    const int mt_total = (a.M[l] + 31) >> 5;
+#pragma unroll
+    for (int t = 0; t < NMAX; ++t) tile[t] = t < n ? min(wave + S3_NWC * t, mt_total - 1) : 0;
   }
   template <int NTC>
-  __device__ __forceinline__ void init_acc(f32x16 (&acc)[NMAX][2], const int (&tile)[NTC], int boff, int half) const {
+  __device__ __forceinline__ void init_acc(f32x16 (&acc)[NMAX][2], int l, int boff, int half) const {
+    const int mt_total = (a.M[l] + 31) >> 5;
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-      acc_bias(acc[t][0], s_bias + boff + tile[t] * 32, half);
+      acc_bias(acc[t][0], s_bias + boff + min(wave + S3_NWC * t, mt_total - 1) * 32, half);
       acc[t][1] = acc[t][0];
     }
   }
 
   // Weight fragments: a ring of four slab slots per wave, slab s in slot s & 3; at the start of slab s the slot slab
-  // s - 1 has just left is refilled with slab s + 3.  Three slabs of MFMAs (1.1k - 2.3k cycles) cover the fetch: with
-  // every CU streaming weights the L2 round trip is ~2k cycles, and one slab of cover left the loops latency-bound
-  // (2.2 ms for SA level 2 whatever else was switched off).
+  // s - 1 has just left is refilled with slab s + 3: three slabs of MFMAs cover the L2 round trip (~2k cycles with
+  // every CU streaming weights).
   // layer 0: the input arrives chunk by chunk (two slabs) from the loader waves.
   template <int NTC>
   __device__ __forceinline__ void layer0(f32x16 (&acc)[NMAX][2], int lane) {
@@ -340,31 +383,32 @@ struct S3Consumer {
     const int n_full = a.nA + a.nB;
     const bool tail = a.tail_w > 0;
     const int slabs = 2 * n_full + (tail ? 1 : 0);
-    const WSrc w = wsrc<NTC>(0, slabs, lane);
-    int tile[NTC];
-    tiles_of<NTC>(0, tile);
-    init_acc<NTC>(acc, tile, 0, half);
+    const WSrc<NTC> w = wsrc<NTC>(0, slabs, lane);
+    init_acc<NTC>(acc, 0, 0, half);
     uint4 ringA[4][NTC][3];
-    a_load<NTC>(ringA[0], w, tile, 0);
-    a_load<NTC>(ringA[1], w, tile, 1);
-    a_load<NTC>(ringA[2], w, tile, 2);
-    const int lane_off = col * S3_CS + half * 16;
-    // one chunk = slabs j (slot U0) and j + 1 (slot U0 + 1)
+    a_load<NTC>(ringA[0], w, 0);
+    a_load<NTC>(ringA[1], w, 1);
+    a_load<NTC>(ringA[2], w, 2);
+    // this lane's fragment addresses in ring slot 0; slot k is + k * S3_CHUNK
+    const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
+    // one chunk = slabs j (weight slot U0) and j + 1 (slot U0 + 1)
 #define S3_CHUNK_STEP(C, U0)                                                                           \
   do {                                                                                                 \
     const unsigned cn_ = chunk_no + (C);                                                               \
     const int slot_ = cn_ & (S3_RING - 1);                                                             \
     lds_wait_ge(&ctl->rdy[slot_], cn_ + 1);                                                            \
-    const char* base_ = ring + (size_t)slot_ * S3_CHUNK + lane_off;                                    \
+    BSrc bs_;                                                                                          \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)  \
+        bs_.p[c_][p_] = bs0.p[c_][p_] + slot_ * S3_CHUNK;                                              \
     bf16x8 b0_[2][3], b1_[2][3];                                                                       \
-    a_load<NTC>(ringA[((U0) + 3) & 3], w, tile, 2 * (C) + 3);                                          \
-    b_load<false>(b0_, base_, S3_CPS, 32 * S3_CS);                                                     \
+    a_load<NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
+    b_ld<0>(b0_, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (!(a.dbg & 4)) mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], b0_);                                \
-    b_load<false>(b1_, base_ + 32, S3_CPS, 32 * S3_CS);                                                \
-    a_load<NTC>(ringA[((U0) + 4) & 3], w, tile, 2 * (C) + 4);                                          \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], b0_);                                                  \
+    b_ld<32>(b1_, bs_);                                                                                \
+    a_load<NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (!(a.dbg & 4)) mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], b1_);                            \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], b1_);                                              \
     lds_signal_add(&ctl->fin[slot_], lane);                                                            \
   } while (0)
     int c = 0;
@@ -379,8 +423,13 @@ struct S3Consumer {
       const unsigned cn = chunk_no + n_full;
       const int slot = cn & (S3_RING - 1);
       lds_wait_ge(&ctl->rdy[slot], cn + 1);
+      BSrc bs;
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * S3_CHUNK;
       bf16x8 b0[2][3];
-      b_load<false>(b0, ring + (size_t)slot * S3_CHUNK + lane_off, S3_CPS, 32 * S3_CS);
+      b_ld<0>(b0, bs);
       if (odd) mm_slab<NTC, NMAX, false>(acc, ringA[2], b0);
       else mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
       lds_signal_add(&ctl->fin[slot], lane);
@@ -393,36 +442,40 @@ struct S3Consumer {
   __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], int l, int boff, int lane) {
     const int half = lane >> 5, col = lane & 31;
     const int slabs = (a.K[l] + 15) >> 4;
-    const WSrc w = wsrc<NTC>(l, slabs, lane);
-    int tile[NTC];
-    tiles_of<NTC>(l, tile);
-    init_acc<NTC>(acc, tile, boff, half);
-    const char* base = P + (size_t)col * a.rs + half * 16;
-    const int ctb = 32 * a.rs;
+    const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane);
+    init_acc<NTC>(acc, l, boff, half);
+    BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);
     uint4 ringA[4][NTC][3];
     bf16x8 b[2][2][3];
-    a_load<NTC>(ringA[0], w, tile, 0);
-    a_load<NTC>(ringA[1], w, tile, 1);
-    a_load<NTC>(ringA[2], w, tile, 2);
-    b_load<false>(b[0], base, a.ps, ctb);
-#define S3_SLAB_STEP(S, U)                                                                             \
+    a_load<NTC>(ringA[0], w, 0);
+    a_load<NTC>(ringA[1], w, 1);
+    a_load<NTC>(ringA[2], w, 2);
+    b_ld<0>(b[0], bs);
+    // slab S (weight slot U): fragments of slab S + 1 are requested at the offset OFFN from the current bases
+#define S3_SLAB_STEP(S, U, OFFN)                                                                       \
   do {                                                                                                 \
-    a_load<NTC>(ringA[((U) + 3) & 3], w, tile, (S) + 3);                                               \
-    b_load<false>(b[((U) + 1) & 1], base + (size_t)min((S) + 1, slabs - 1) * 32, a.ps, ctb);           \
+    a_load<NTC>(ringA[((U) + 3) & 3], w, (S) + 3);                                                     \
+    b_ld<(OFFN)>(b[((U) + 1) & 1], bs);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    if (!(a.dbg & 8)) mm_slab<NTC, NMAX, false>(acc, ringA[(U)], b[(U) & 1]);                          \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U)], b[(U) & 1]);                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
+    // (the layer's slab count is padded: P holds zero rows up to a multiple of 32 k, and the fragment reads of the
+    // slab after the last stay inside the column's row -- rs = 2 * kcap + 16 bytes)
     int s = 0;
     for (; s + 4 <= slabs; s += 4) {
-      S3_SLAB_STEP(s, 0);
-      S3_SLAB_STEP(s + 1, 1);
-      S3_SLAB_STEP(s + 2, 2);
-      S3_SLAB_STEP(s + 3, 3);
+      S3_SLAB_STEP(s, 0, 32);
+      S3_SLAB_STEP(s + 1, 1, 64);
+      S3_SLAB_STEP(s + 2, 2, 96);
+      S3_SLAB_STEP(s + 3, 3, 128);
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] += 128;
     }
-    if (s < slabs) S3_SLAB_STEP(s, 0);
-    if (s + 1 < slabs) S3_SLAB_STEP(s + 1, 1);
-    if (s + 2 < slabs) S3_SLAB_STEP(s + 2, 2);
+    if (s < slabs) S3_SLAB_STEP(s, 0, 32);
+    if (s + 1 < slabs) S3_SLAB_STEP(s + 1, 1, 64);
+    if (s + 2 < slabs) S3_SLAB_STEP(s + 2, 2, 96);
 #undef S3_SLAB_STEP
   }
 
@@ -450,7 +503,7 @@ struct S3Consumer {
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
       const int mt = wave + S3_NWC * t;
-      if (mt < mt_total && !(a.dbg & 16)) {
+      if (mt < mt_total) {
         store_tile(acc[t][0], mt, col, lane);
         store_tile(acc[t][1], mt, 32 + col, lane);
       }
@@ -624,6 +677,8 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x, base += n_chunks, ++blocks_done) {
       int bi, bx;
       s3_block_map(a, q, bi, bx);
+      LoaderCols<IS_SA> lcx;
+      loader_cols<IS_SA>(a, lcx, bi, bx * S3_COLS, lane);      // (in flight while the wave waits for its slot)
       // ring overlaid on P: this block's chunks may only be written once the MFMA waves have left the previous block
       if (a.ring_off == 0 && blocks_done > 0) lds_wait_ge(&ctl.blk, blocks_done);
       // first local chunk with (base + lc) % 4 == j
@@ -632,7 +687,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
         S3_STAMP(pl);
         lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
         S3_STAMP(pl + 1);
-        loader_chunk<IS_SA>(a, slot, bi, bx * S3_COLS, lc, lane);
+        loader_chunk<IS_SA>(a, lcx, slot, bi, bx * S3_COLS, lc, lane);
         S3_STAMP(pl + 2);
         ++uses;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

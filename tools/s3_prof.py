@@ -16,12 +16,26 @@ from pvn3d_amd._lib import lib  # noqa: E402
 dev = torch.device("cuda:0")
 B = 64
 xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
-sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
-feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
-with torch.no_grad():
-    geo = sa.sample_and_query(xyz)
-    for _ in range(3):
-        sa(xyz, feats, geometry=geo)
+case = sys.argv[1] if len(sys.argv) > 1 else "sa2"
+if case == "sa2":
+    sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
+    feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+    with torch.no_grad():
+        geo = sa.sample_and_query(xyz)
+        for _ in range(3):
+            sa(xyz, feats, geometry=geo)
+else:
+    n, m, c2, c1, mlp = (12288, 2048, 256, 6, [262, 128, 128]) if case == "fp0" else (2048, 1024, 512, 96, [608, 256, 256])
+    fp = pm.PointnetFPModule(mlp=mlp).to(dev).eval()
+    fp._point_major_out = case != "fp0"
+    unk = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=n, n_obj=256)["pcld"] for i in range(B)])).to(dev)
+    kn = unk[:, :m].contiguous()
+    kf = torch.randn(B, m, c2, device=dev).transpose(1, 2)
+    uf = torch.randn(B, n, c1 + 3, device=dev)[:, :, 3:].transpose(1, 2) if c1 < 32 else torch.randn(B, n, c1, device=dev).transpose(1, 2)
+    with torch.no_grad():
+        nb = fp.neighbours(unk, kn)
+        for _ in range(3):
+            fp(unk, kn, uf, kf, neighbours=nb)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 256)()
 f = lib._lib.pvn3d_debug_s3_prof_read if hasattr(lib, "_lib") else ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "libpvn3d_hip.so")).pvn3d_debug_s3_prof_read
