@@ -306,7 +306,10 @@ __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ 
 
 // One layer's MFMA loop shapes: NTC row tiles (tile0 + 4 t, clamped to the layer's last tile: a wave without a t-th
 // tile recomputes the last one and drops the result) x both column tiles.
-template <bool IS_SA, int N0, int N1, int N2>
+// PASSES: the last layer's row tiles are worked off in PASSES rounds of 4 * NLAST tiles (512-wide last layers: the
+// accumulators of all 16 tiles would not fit); its input P is only read, so the rounds need no barrier between them,
+// and their max-pool runs on DPP lane shifts instead of LDS patches (P is still being read by the other waves).
+template <bool IS_SA, int N0, int N1, int N2, int PASSES>
 struct S3Consumer {
   static constexpr int NMAX = N0 > N1 ? (N0 > N2 ? N0 : N2) : (N1 > N2 ? N1 : N2);
   static constexpr int NL = N2 > 0 ? 3 : 2;
@@ -321,14 +324,15 @@ struct S3Consumer {
   int blk_no;              // column blocks done (probe only)
 
   template <int NTC>
-  __device__ __forceinline__ WSrc<NTC> wsrc(int l, int slabs, int lane) const {
+  __device__ __forceinline__ WSrc<NTC> wsrc(int l, int slabs, int lane, int tile_base = 0) const {
     const int mt_total = (a.M[l] + 31) >> 5;
     WSrc<NTC> w;
     w.sbase = reinterpret_cast<const char*>(a.W[l]);
     w.sstride = (unsigned)mt_total * 3u * 64u * 16u;
     w.last = slabs - 1;
 #pragma unroll
-    for (int t = 0; t < NTC; ++t) w.voff[t] = ((unsigned)min(wave + S3_NWC * t, mt_total - 1) * 192u + (unsigned)lane) * 16u;
+    for (int t = 0; t < NTC; ++t)
+      w.voff[t] = ((unsigned)min(tile_base + wave + S3_NWC * t, mt_total - 1) * 192u + (unsigned)lane) * 16u;
     return w;
   }
   template <int NTC>
@@ -364,11 +368,11 @@ struct S3Consumer {
     for (int t = 0; t < NMAX; ++t) tile[t] = t < n ? min(wave + S3_NWC * t, mt_total - 1) : 0;
   }
   template <int NTC>
-  __device__ __forceinline__ void init_acc(f32x16 (&acc)[NMAX][2], int l, int boff, int half) const {
+  __device__ __forceinline__ void init_acc(f32x16 (&acc)[NMAX][2], int l, int boff, int half, int tile_base = 0) const {
     const int mt_total = (a.M[l] + 31) >> 5;
 #pragma unroll
     for (int t = 0; t < NTC; ++t) {
-      acc_bias(acc[t][0], s_bias + boff + min(wave + S3_NWC * t, mt_total - 1) * 32, half);
+      acc_bias(acc[t][0], s_bias + boff + min(tile_base + wave + S3_NWC * t, mt_total - 1) * 32, half);
       acc[t][1] = acc[t][0];
     }
   }
@@ -379,6 +383,7 @@ struct S3Consumer {
   // layer 0: the input arrives chunk by chunk (two slabs) from the loader waves.
   template <int NTC>
   __device__ __forceinline__ void layer0(f32x16 (&acc)[NMAX][2], int lane) {
+    static_assert(NTC <= 2, "layer 0 runs the four-slot weight ring");
     const int half = lane >> 5, col = lane & 31;
     const int n_full = a.nA + a.nB;
     const bool tail = a.tail_w > 0;
@@ -437,27 +442,28 @@ struct S3Consumer {
     chunk_no += n_full + (tail ? 1 : 0);
   }
 
-  // layers >= 1: the input is P
+  // layers >= 1: the input is P.  Three row tiles per wave (NTC = 3: 96 accumulator registers) run a two-slot weight
+  // ring -- one slab of 36 MFMAs (1.1k cycles) of cover -- the others the four-slot ring.
   template <int NTC>
-  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], int l, int boff, int lane) {
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], int l, int boff, int lane, int tile_base = 0) {
     const int half = lane >> 5, col = lane & 31;
     const int slabs = (a.K[l] + 15) >> 4;
-    const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane);
-    init_acc<NTC>(acc, l, boff, half);
+    const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
+    init_acc<NTC>(acc, l, boff, half, tile_base);
     BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);
-    uint4 ringA[4][NTC][3];
+    constexpr int RD = NTC >= 3 ? 2 : 4;
+    uint4 ringA[RD][NTC][3];
     bf16x8 b[2][2][3];
-    a_load<NTC>(ringA[0], w, 0);
-    a_load<NTC>(ringA[1], w, 1);
-    a_load<NTC>(ringA[2], w, 2);
+#pragma unroll
+    for (int u = 0; u < RD - 1; ++u) a_load<NTC>(ringA[u], w, u);
     b_ld<0>(b[0], bs);
     // slab S (weight slot U): fragments of slab S + 1 are requested at the offset OFFN from the current bases
 #define S3_SLAB_STEP(S, U, OFFN)                                                                       \
   do {                                                                                                 \
-    a_load<NTC>(ringA[((U) + 3) & 3], w, (S) + 3);                                                     \
+    a_load<NTC>(ringA[((U) + RD - 1) % RD], w, (S) + RD - 1);                                          \
     b_ld<(OFFN)>(b[((U) + 1) & 1], bs);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U)], b[(U) & 1]);                                            \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U) % RD], b[(U) & 1]);                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
     // (the layer's slab count is padded: P holds zero rows up to a multiple of 32 k, and the fragment reads of the
@@ -545,6 +551,65 @@ struct S3Consumer {
       boff += ((a.M[1] + 31) >> 5) * 32;
     }
     constexpr int NLAST = NL == 3 ? N2 : N1;
+    const int M = a.M[NL - 1];
+    const int mt_total = (M + 31) >> 5;
+    float* const out = a.out;
+    if (PASSES > 1) {
+      // ---- last layer in rounds of 4 * NLAST row tiles; max-pool on DPP, no LDS (set abstraction only)
+#pragma unroll 1
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int lane = fresh_lane();
+        const int half = lane >> 5, col = lane & 31;
+        const int tile_base = pass * S3_NWC * NLAST;
+        layerN<NLAST>(acc, NL - 1, boff, lane, tile_base);
+        const int ns = a.ns;                                  // 16, 32 or 64
+        const bool writer = ns == 16 ? (lane & 15) == 15 : (lane & 31) == 31;
+#pragma unroll
+        for (int t = 0; t < NLAST; ++t) {
+          const int mt = tile_base + wave + S3_NWC * t;
+          if (mt < mt_total) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              if (ns == 64 && ct == 1) break;
+              float v[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                float x = fmaxf(acc[t][ct][r], 0.f);
+                if (ns == 64) x = fmaxf(x, fmaxf(acc[t][1][r], 0.f));
+                // max over the 16 lanes of a DPP row: rotate by 1, 2, 4, 8
+                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)));
+                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)));
+                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)));
+                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)));
+                if (ns >= 32)     // rows 1 and 3 take lane 15 of rows 0 and 2 (row_bcast15)
+                  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x142, 0xa,
+                                                                          0xf, false)));
+                v[r] = x;
+              }
+              // lane 15 (ns 16: and 31) of each 32-lane half holds the result of its centre: rows 8g + 4*half + 0..3
+              const int centre = ns == 64 ? col0 / 64 : (col0 + 32 * ct + (ns == 16 ? (col & 16) : 0)) / ns;
+              if (writer && centre < a.m) {
+                float* o = out + ((size_t)bi * a.m + centre) * a.ld_out + a.coff + mt * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const int row = mt * 32 + 8 * g + 4 * half;
+                  if (row + 3 < M) {
+                    *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                  } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                      if (row + k < M) o[8 * g + k] = v[4 * g + k];
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      ++blk_no;
+      S3_STAMP(pb + 7);
+      return;
+    }
     {
       const int lane = fresh_lane();
       layerN<NLAST>(acc, NL - 1, boff, lane);
@@ -556,9 +621,6 @@ struct S3Consumer {
     // ---- epilogue on the last layer's accumulators (rows wave + 4 t, both column tiles)
     const int lane = fresh_lane();
     const int half = lane >> 5, col = lane & 31;
-    const int M = a.M[NL - 1];
-    const int mt_total = (M + 31) >> 5;
-    float* const out = a.out;
     if (IS_SA) {
       // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip)
       float* sc = reinterpret_cast<float*>(P) + (size_t)wave * (32 * S3_EPAD);
@@ -642,7 +704,7 @@ struct S3Consumer {
   }
 };
 
-template <bool IS_SA, int N0, int N1, int N2>
+template <bool IS_SA, int N0, int N1, int N2, int PASSES>
 __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   // 16-byte aligned dynamic LDS (every fragment read is a ds_read_b128: a base that is only 8-byte aligned -- what a
   // static __shared__ object in front of it produces -- turns each of them into a slow misaligned access); the control
@@ -697,7 +759,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u, 0};
+  S3Consumer<IS_SA, N0, N1, N2, PASSES> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -712,15 +774,20 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
 
 bool vec_ok(const float* p, int ld) { return p != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Chain signature = row tiles per MFMA wave in each layer; the instantiated ones are the shapes of PVN3D's backbone
-// that gain: SA level 2 (259 -> 128 -> 196 -> 256), FP level 0 (262 -> 128 -> 128), FP level 1 (608 -> 256 -> 256).
+// Chain signature = row tiles per MFMA wave in each layer (x rounds of the last layer); the instantiated ones are the
+// shapes of PVN3D's backbone that gain: SA level 2 (259 -> 128 -> 196 -> 256), SA level 3 (515 -> 256 -> 256 | 384 ->
+// 512: the 16 tiles of the last layer in two rounds), FP level 0 (262 -> 128 -> 128), FP level 1 (608 -> 256 -> 256).
 // -1: no kernel for this chain (the caller keeps the fp32-MFMA kernels of sa_mlp.hip).
-int s3_signature(int is_sa, int n_layers, const int* dims) {
+int s3_signature(int is_sa, int n_layers, const int* dims, int nsample) {
   int n[3] = {0, 0, 0};
   if (n_layers < 2 || n_layers > 3) return -1;
   for (int l = 0; l < n_layers; ++l) n[l] = pvn3d_ceil_div(pvn3d_ceil_div(dims[l + 1], 32), S3_NWC);
   const int sig = n[0] * 100 + n[1] * 10 + n[2];
-  if (is_sa) return sig == 122 ? sig : -1;
+  if (is_sa) {
+    if (sig == 122) return sig;
+    if ((sig == 224 || sig == 234) && nsample >= 16) return sig;      // DPP pooling: whole 16-lane rows per centre
+    return -1;
+  }
   return (sig == 110 || sig == 220) ? sig : -1;
 }
 
@@ -770,14 +837,16 @@ int s3_launch(S3Args& a, int sig, hipStream_t st) {
   }
   int grid = min(a.n_blocks, cus);
   if (grid >= 8) grid &= ~7;
-#define S3_GO(SA, A0, A1, A2)                                                                                 \
-  do {                                                                                                        \
-    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2>));                \
-    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2>), dim3(grid), dim3(S3_THREADS), lds, st, a);      \
+#define S3_GO(SA, A0, A1, A2, PS)                                                                                 \
+  do {                                                                                                            \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2, PS>));                \
+    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2, PS>), dim3(grid), dim3(S3_THREADS), lds, st, a);      \
   } while (0)
-  if (a.is_sa && sig == 122) S3_GO(true, 1, 2, 2);
-  else if (!a.is_sa && sig == 110) S3_GO(false, 1, 1, 0);
-  else if (!a.is_sa && sig == 220) S3_GO(false, 2, 2, 0);
+  if (a.is_sa && sig == 122) S3_GO(true, 1, 2, 2, 1);
+  else if (a.is_sa && sig == 224) S3_GO(true, 2, 2, 2, 2);
+  else if (a.is_sa && sig == 234) S3_GO(true, 2, 3, 2, 2);
+  else if (!a.is_sa && sig == 110) S3_GO(false, 1, 1, 0, 1);
+  else if (!a.is_sa && sig == 220) S3_GO(false, 2, 2, 0, 1);
   else return -1;
 #undef S3_GO
   PVN3D_LAUNCH_CHECK();
@@ -813,7 +882,7 @@ extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int 
   } else if ((c_b % S3_KC) > 8) {
     return 0;                                                         // the tail chunk holds <= 8 channels
   }
-  if (s3_signature(is_sa, n_layers, dims_host) < 0) return 0;
+  if (s3_signature(is_sa, n_layers, dims_host, nsample) < 0) return 0;
   S3Args a = {};
   a.n_layers = n_layers;
   a.is_sa = is_sa;
@@ -842,7 +911,7 @@ extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsampl
   a.cols_total = m * nsample;
   a.n_frames = b;
   a.out = out_pm; a.point_major = 1; a.ld_out = ld_out; a.coff = out_coff;
-  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host), (hipStream_t)stream);
+  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host, nsample), (hipStream_t)stream);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
 
@@ -868,6 +937,6 @@ extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, co
   a.cols_total = n;
   a.n_frames = b;
   a.out = out; a.point_major = out_point_major ? 1 : 0; a.ld_out = ld_out; a.coff = 0;
-  const int rc = s3_launch(a, s3_signature(0, n_layers, dims_host), (hipStream_t)stream);
+  const int rc = s3_launch(a, s3_signature(0, n_layers, dims_host, 0), (hipStream_t)stream);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }

@@ -1029,6 +1029,11 @@ def test_geometry_ahead_handle_gives_the_same_forward(dev):
     (256, [256, 128, 196, 256], 32, 512, 1024, 8),    # SA level 2 of the backbone (lib/pvn3d.py:89-97), 8 frames (XCD map)
     (96, [96, 100, 130, 200], 64, 9, 300, 3),         # nsample 64: one centre per block; widths not multiples of 32
     (32, [32, 128, 256, 256], 8, 33, 200, 1),         # one 32-channel chunk + the xyz tail; nsample 8
+    (512, [512, 256, 256, 512], 16, 128, 512, 8),     # SA level 3, first scale: last layer in two rounds, DPP max-pool
+    (512, [512, 256, 384, 512], 32, 128, 512, 8),     # SA level 3, second scale: three row tiles per wave in layer 1
+    (64, [64, 250, 380, 500], 32, 33, 200, 3),        # the same kernels on ragged widths / column counts
+    (32, [32, 200, 250, 400], 64, 9, 300, 2),         # nsample 64 through the DPP pool
+    (96, [96, 256, 256, 390], 16, 50, 333, 1),
 ])
 def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns, npoint, n, b):
     """csrc/sa_mlp_split.hip (fp32 operands as three bf16 pieces, six partial products on the bf16 matrix pipe, loader /

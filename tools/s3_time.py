@@ -39,6 +39,15 @@ def main():
             geo = sa.sample_and_query(xyz)
         cases.append(("SA2 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz, feats, geometry=geo),
                       2.0 * (259 * 128 + 128 * 196 + 196 * 256) * 512 * ns * B))
+    # SA level 3: 512 -> 128 centres, C = 512
+    xyz3 = xyz[:, :512].contiguous()
+    for ns, radius, mlp in ((16, 0.1, [512, 256, 256, 512]), (32, 0.2, [512, 256, 384, 512])):
+        sa = pm.PointnetSAModule(mlp=list(mlp), npoint=128, radius=radius, nsample=ns).to(dev).eval()
+        feats = torch.randn(B, 512, 512, device=dev).transpose(1, 2)
+        with torch.no_grad():
+            geo = sa.sample_and_query(xyz3)
+        cases.append(("SA3 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz3, feats, geometry=geo),
+                      2.0 * (515 * mlp[1] + mlp[1] * mlp[2] + mlp[2] * mlp[3]) * 128 * ns * B))
     # FP level 0: 12288 <- 2048, C2 = 256, C1 = 6; FP level 1: 2048 <- 1024, 512 + 96
     for name, n, m, c2, c1, mlp in (("FP0", 12288, 2048, 256, 6, [262, 128, 128]), ("FP1", 2048, 1024, 512, 96, [608, 256, 256])):
         fp = pm.PointnetFPModule(mlp=mlp).to(dev).eval()
