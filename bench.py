@@ -242,6 +242,37 @@ def mlp_flops_per_frame(net, scale):
     return sa, fp
 
 
+def mlp_chain_table(net, scale):
+    """One row per fused chain of the forward: stage, widths, algorithmic flops per frame and the matrix pipe it runs on
+    (asked of the library: pvn3d_mlp_split_ok is the dispatch test of lib/pointnet2_utils/_ext.py)."""
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+    import ctypes
+    rows = []
+
+    def add(stage, name, dims, cols, is_sa, c_a, c_b, ns):
+        arr = (ctypes.c_int * len(dims))(*dims)
+        split = _fused_mlp.MLP_ARITH == "bf16x3" and bool(lib.pvn3d_mlp_split_ok(1 if is_sa else 0, c_a, c_b, ns, len(dims) - 1, arr))
+        fl = 2.0 * sum(a * b for a, b in zip(dims[:-1], dims[1:])) * cols
+        rows.append(dict(stage=stage, chain=name, dims=list(dims), flops_per_frame=fl,
+                         arithmetic="bf16x3 split on v_mfma_f32_32x32x16_bf16" if split else "fp32 on v_mfma_f32_32x32x2_f32",
+                         peak_tflops=PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS))
+
+    for li, mod in enumerate(net.SA_modules):
+        m = int(mod.npoint * scale)
+        for si, (grouper, mlp) in enumerate(zip(mod.groupers, mod.mlps)):
+            convs = [c for c in mlp.modules() if isinstance(c, torch.nn.Conv2d)]
+            dims = [convs[0].in_channels] + [c.out_channels for c in convs]
+            add("sa_mlp", "SA%d.%d" % (li, si), dims, m * grouper.nsample, True, dims[0] - 3, 0, grouper.nsample)
+    n_unknown = [int(v * scale) for v in (12288, 2048, 1024, 512)]
+    skip = [6, 96, 256, 512]
+    for fi, mod in enumerate(net.FP_modules):
+        convs = [c for c in mod.mlp.modules() if isinstance(c, torch.nn.Conv2d)]
+        dims = [convs[0].in_channels] + [c.out_channels for c in convs]
+        add("fp_mlp", "FP%d" % fi, dims, n_unknown[fi], False, dims[0] - skip[fi], skip[fi], 0)
+    return rows
+
+
 def run_postproc(inp, timer, poll_every):
     """(B) vote -> MeanShift x (K+1) -> Kabsch for the whole batch."""
     from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
@@ -733,18 +764,32 @@ def main():
                 rooflines[name] = entry
         if net is not None:
             sa_fl, fp_fl = mlp_flops_per_frame(net, scale)
+            # Per chain: which matrix pipe it runs on.  fp32 chains: v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s.  Split
+            # chains (csrc/sa_mlp_split.hip): every fp32 multiply is six bf16 x bf16 partial products on
+            # v_mfma_f32_32x32x16_bf16 (fp32 accuracy), so of the ALGORITHMIC fp32 flops the bf16 pipe
+            # can deliver at most 2500 / 6 = 416.7 TFLOP/s.  A stage mixes both: its `peak` is the rate at which the
+            # stage's chains would finish with every pipe at its dense peak (sum of flops / sum of ideal times), its
+            # `frac` = ideal time / measured time -- never a ratio against a peak the launch does not run on.
+            chains = mlp_chain_table(net, scale)
             for name, fl in (("sa_mlp", sa_fl), ("fp_mlp", fp_fl)):
                 if per_step.get(name, 0) > 0:
+                    mine = [c for c in chains if c["stage"] == name]
+                    t_ideal = sum(c["flops_per_frame"] * F / (c["peak_tflops"] * 1e12) for c in mine)
                     tfl = fl * F / (per_step[name] * 1e-3) / 1e12
-                    rooflines[name] = dict(bound="mfma", achieved=tfl, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                                           frac=tfl / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                                           ms_per_step=per_step[name], algorithmic_flops_per_frame=fl)
+                    peak = fl * F / t_ideal / 1e12
+                    rooflines[name] = dict(bound="mfma", achieved=tfl, peak=peak, unit="TFLOP/s (fp32-equivalent)",
+                                           frac=tfl / peak, traffic=None, ms_per_step=per_step[name],
+                                           algorithmic_flops_per_frame=fl, ms_at_peak=t_ideal * 1e3,
+                                           frac_of_fp32_mfma_peak=tfl / PEAK_FP32_MFMA_TFLOPS, chains=mine)
             if per_step.get("sa_mlp", 0) > 0 and per_step.get("fp_mlp", 0) > 0:
                 tms = per_step["sa_mlp"] + per_step["fp_mlp"]
                 tfl = (sa_fl + fp_fl) * F / (tms * 1e-3) / 1e12
-                rooflines["sa_mlp+fp_mlp"] = dict(bound="mfma", achieved=tfl, peak=PEAK_FP32_MFMA_TFLOPS,
-                                                  unit="TFLOP/s", frac=tfl / PEAK_FP32_MFMA_TFLOPS, traffic=None,
-                                                  ms_per_step=tms, algorithmic_flops_per_frame=sa_fl + fp_fl)
+                t_ideal = sum(c["flops_per_frame"] * F / (c["peak_tflops"] * 1e12) for c in chains)
+                peak = (sa_fl + fp_fl) * F / t_ideal / 1e12
+                rooflines["sa_mlp+fp_mlp"] = dict(bound="mfma", achieved=tfl, peak=peak, unit="TFLOP/s (fp32-equivalent)",
+                                                  frac=tfl / peak, traffic=None, ms_per_step=tms, ms_at_peak=t_ideal * 1e3,
+                                                  algorithmic_flops_per_frame=sa_fl + fp_fl,
+                                                  frac_of_fp32_mfma_peak=tfl / PEAK_FP32_MFMA_TFLOPS)
         if "ball_query" in op_step and "group" in op_step:
             per_step_bg = op_step
             tms = per_step_bg["ball_query"] + per_step_bg["group"]
@@ -786,8 +831,10 @@ def main():
                       "three_interpolate; synthetic features, no MLP GEMMs)")
         else:
             island = ("Pointnet2MSG forward (4 SA-MSG + 4 FP levels, random-init weights, eval): FPS, gather, "
-                      "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP "
-                      "on fp32 MFMA")
+                      "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP; "
+                      "fp32 operands and results throughout, the contraction on fp32 MFMA or -- SA levels 2-3, FP levels "
+                      "0-1 -- as six exact bf16 x bf16 partial products per multiply on bf16 MFMA (fp32 accuracy: every bit of "
+                      "both operands enters the product; tests pin both to 2e-5 of an fp64 evaluation)")
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

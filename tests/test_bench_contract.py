@@ -105,3 +105,18 @@ def test_train_step_algorithmic_work():
     assert len(w["per_level"]) == 12 and abs(sum(l["bytes"] for l in w["per_level"]) - w["bytes"]) < 1.0
     t_hbm, t_mfma = w["bytes"] / (bench.PEAK_HBM_GBS * 1e9), w["flops"] / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
     assert 25e9 < w["bytes"] < 40e9 and t_hbm > 5 * t_mfma
+
+
+def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
+    """bench.mlp_chain_table asks the library's own dispatch test (pvn3d_mlp_split_ok, host-only): SA levels 2-3 and FP
+    levels 0-1 of the backbone run the split-bf16 kernels (peak 2500 / 6 TFLOP/s of algorithmic fp32 flops), the narrow SA
+    levels 0-1 and the 512-wide FP levels 2-3 the fp32-MFMA kernels (157.3)."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    rows = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0)
+    split = {r["chain"] for r in rows if r["arithmetic"].startswith("bf16x3")}
+    assert split == {"SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1"}
+    assert len(rows) == 12
+    for r in rows:
+        assert abs(r["peak_tflops"] - (2500.0 / 6.0 if r["chain"] in split else 157.3)) < 1e-9
+    sa, fp = bench.mlp_flops_per_frame(Pointnet2MSG(input_channels=6), 1.0)
+    assert abs(sum(r["flops_per_frame"] for r in rows) - (sa + fp)) < 1.0

@@ -59,10 +59,17 @@ def main():
         fl = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * cols * FRAMES
         gui = c["GRBM_GUI_ACTIVE"] / N_XCD
         clk = gui / (us * 1e3)
-        rows.append(dict(chain=name, kernel=kern, duration_us=us, effective_clock_ghz=clk,
+        # split-bf16 chains (csrc/sa_mlp_split.hip) execute six bf16 partial products per fp32 multiply on
+        # v_mfma_f32_32x32x16_bf16 (1024 flop/clk/SIMD); the fp32 chains v_mfma_f32_32x32x2_f32 (64 flop/clk/SIMD).
+        # `tflops` stays the algorithmic (fp32-equivalent) rate; `tflops_peak_at_clock` is what the pipe the launch runs
+        # on could deliver of THAT quantity at the measured clock (bf16 peak / 6 for the split chains).
+        split = "s3_kernel" in kern
+        per_clk = 1024.0 / 6.0 if split else 64.0
+        rows.append(dict(chain=name, kernel=kern, arithmetic="bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split
+                         else "fp32 MFMA", duration_us=us, effective_clock_ghz=clk,
                          mfma_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui),
                          mfma_busy_vs_sq_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * c["SQ_BUSY_CYCLES"]),
-                         tflops=fl / (us * 1e-6) / 1e12, tflops_peak_at_clock=64 * 1024 * clk * 1e9 / 1e12,
+                         tflops=fl / (us * 1e-6) / 1e12, tflops_peak_at_clock=per_clk * 1024 * clk * 1e9 / 1e12,
                          wave_cycles_share=dict(wait_any=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                                                 wait_inst_any=c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                                                 active_inst_any=c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]),
@@ -74,6 +81,9 @@ def main():
                           effective_clock_ghz=tot_act / (tot_us * 1e3)))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "%s_mfma_busy.json" % tag), "w") as f:
+        json.dump(res, f, indent=1)
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "%s_mfma_busy.json" % tag), "w") as f:
         json.dump(res, f, indent=1)
     for r in rows:
         print("%-9s %-42s %8.1f us  clk %.2f GHz  MFMA-busy %.3f (%.3f)  %6.1f TF/s of %5.1f at clock" %

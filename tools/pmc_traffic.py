@@ -14,7 +14,8 @@ import subprocess
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-STAGE_OF = [("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
+STAGE_OF = [("mlp_chain_s3_kernel<true", "sa_mlp"), ("mlp_chain_s3_kernel<false", "fp_mlp"),
+            ("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
             ("mlp_chain_mid_kernel<true", "sa_mlp"), ("mlp_chain_cols_kernel<true", "sa_mlp"),
             ("mlp_chain_kernel<false", "fp_mlp"), ("mlp_chain_wide_kernel<false", "fp_mlp"),
             ("mlp_chain_mid_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
