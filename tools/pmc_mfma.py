@@ -51,7 +51,7 @@ def main():
     for r in csv.DictReader(open(glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0])):
         if "mlp_chain" in r["Kernel_Name"]:
             dur[int(r["Dispatch_Id"])] = ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
-                                          r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", ""))
+                                          r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0])
     ids = sorted(ctr)[-12:]           # the last fused forward of the run
     rows, tot_fl, tot_us, tot_busy, tot_act = [], 0.0, 0.0, 0.0, 0.0
     for (name, dims, cols), d in zip(CHAINS, ids):
