@@ -396,24 +396,45 @@ struct S3Consumer {
     a_load<NTC>(ringA[2], w, 2);
     // this lane's fragment addresses in ring slot 0; slot k is + k * S3_CHUNK
     const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
-    // one chunk = slabs j (weight slot U0) and j + 1 (slot U0 + 1)
+    const int n_chunks = n_full + (tail ? 1 : 0);
+    // Software pipeline over the chunks: the fragments of a chunk's first slab are requested during the previous
+    // chunk (after its first slab's MFMAs have been issued, so the ready poll and the LDS round trip run under MFMAs
+    // that are already in the pipe); a chunk step therefore starts with b0 in registers.
+    bf16x8 bA[2][3], bB[2][3];            // first-slab fragments of the current / next chunk, second-slab fragments
+    {
+      const int slot = chunk_no & (S3_RING - 1);
+      lds_wait_ge(&ctl->rdy[slot], chunk_no + 1);
+      BSrc bs;
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * S3_CHUNK;
+      b_ld<0>(bA, bs);
+    }
+    // one full chunk C = slabs 2C (weight slot U0) and 2C + 1 (slot U0 + 1); NEXT: there is a chunk C + 1 in this block
 #define S3_CHUNK_STEP(C, U0)                                                                           \
   do {                                                                                                 \
     const unsigned cn_ = chunk_no + (C);                                                               \
     const int slot_ = cn_ & (S3_RING - 1);                                                             \
-    lds_wait_ge(&ctl->rdy[slot_], cn_ + 1);                                                            \
     BSrc bs_;                                                                                          \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)  \
         bs_.p[c_][p_] = bs0.p[c_][p_] + slot_ * S3_CHUNK;                                              \
-    bf16x8 b0_[2][3], b1_[2][3];                                                                       \
     a_load<NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
-    b_ld<0>(b0_, bs_);                                                                                 \
+    b_ld<32>(bB, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], b0_);                                                  \
-    b_ld<32>(b1_, bs_);                                                                                \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], bA);                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
     a_load<NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
+    if ((C) + 1 < n_chunks) {                                                                          \
+      const int slotn_ = (cn_ + 1) & (S3_RING - 1);                                                    \
+      lds_wait_ge(&ctl->rdy[slotn_], cn_ + 2);                                                         \
+      BSrc bn_;                                                                                        \
+      _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) \
+          bn_.p[c_][p_] = bs0.p[c_][p_] + slotn_ * S3_CHUNK;                                           \
+      b_ld<0>(bA, bn_);                                                                                \
+    }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], b1_);                                              \
+    mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], bB);                                               \
     lds_signal_add(&ctl->fin[slot_], lane);                                                            \
   } while (0)
     int c = 0;
@@ -425,18 +446,11 @@ struct S3Consumer {
     if (odd) S3_CHUNK_STEP(c, 0);
 #undef S3_CHUNK_STEP
     if (tail) {
+      // the tail chunk's single slab: its fragments are already in bA
       const unsigned cn = chunk_no + n_full;
       const int slot = cn & (S3_RING - 1);
-      lds_wait_ge(&ctl->rdy[slot], cn + 1);
-      BSrc bs;
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * S3_CHUNK;
-      bf16x8 b0[2][3];
-      b_ld<0>(b0, bs);
-      if (odd) mm_slab<NTC, NMAX, false>(acc, ringA[2], b0);
-      else mm_slab<NTC, NMAX, false>(acc, ringA[0], b0);
+      if (odd) mm_slab<NTC, NMAX, false>(acc, ringA[2], bA);
+      else mm_slab<NTC, NMAX, false>(acc, ringA[0], bA);
       lds_signal_add(&ctl->fin[slot], lane);
     }
     chunk_no += n_full + (tail ? 1 : 0);
@@ -516,6 +530,59 @@ struct S3Consumer {
     }
   }
 
+  // max over the nsample (16, 32 or 64) columns of each centre for one row tile, on DPP lane shifts (no LDS), and the
+  // store of the pooled rows: lane 15 (nsample 16) / 31 of each 32-lane half ends up with the result of its centre for
+  // the rows 8g + 4*half + 0..3 of the tile -- four 16-byte stores.  The reduction is written as v_max_f32_dpp, one
+  // instruction per (register, step), step-major over the 16 registers: consecutive instructions are independent, and a
+  // register written in one step is read 15 instructions later (a DPP read needs 2 wait states after a VALU write; the
+  // builtin form cost a v_mov + canonicalising v_max + s_nop per step and 15k cycles per two tiles).
+  template <int NS>
+  __device__ __forceinline__ void pool_dpp_t(const f32x16 (&acc)[2], int mt, int bi, int col0, int lane) {
+    const int half = lane >> 5, col = lane & 31;
+    const int M = a.M[NL - 1];
+    const bool writer = NS == 16 ? (lane & 15) == 15 : (lane & 31) == 31;
+#pragma unroll
+    for (int ct = 0; ct < (NS == 64 ? 1 : 2); ++ct) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v[r] = fmaxf(acc[ct][r], 0.f);
+        if (NS == 64) v[r] = fmaxf(v[r], fmaxf(acc[1][r], 0.f));
+      }
+      asm volatile("s_nop 1" ::: "memory");
+#define S3_DPP_STEP(CTRL)                                                                                    \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                             \
+      asm volatile("v_max_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf" : "+v"(v[r]))
+      S3_DPP_STEP("row_ror:1 row_mask:0xf");
+      S3_DPP_STEP("row_ror:2 row_mask:0xf");
+      S3_DPP_STEP("row_ror:4 row_mask:0xf");
+      S3_DPP_STEP("row_ror:8 row_mask:0xf");
+      if (NS >= 32) S3_DPP_STEP("row_bcast:15 row_mask:0xa");      // rows 1, 3 take lane 15 of rows 0, 2
+#undef S3_DPP_STEP
+      asm volatile("s_nop 1" ::: "memory");
+      const int centre = NS == 64 ? col0 / 64 : (col0 + 32 * ct + (NS == 16 ? (col & 16) : 0)) / NS;
+      if (writer && centre < a.m) {
+        float* o = a.out + ((size_t)bi * a.m + centre) * a.ld_out + a.coff + mt * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = mt * 32 + 8 * g + 4 * half;
+          if (row + 3 < M) {
+            *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (row + k < M) o[8 * g + k] = v[4 * g + k];
+          }
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void pool_dpp(const f32x16 (&acc)[2], int mt, int bi, int col0, int lane) {
+    if (a.ns == 16) pool_dpp_t<16>(acc, mt, bi, col0, lane);
+    else if (a.ns == 32) pool_dpp_t<32>(acc, mt, bi, col0, lane);
+    else pool_dpp_t<64>(acc, mt, bi, col0, lane);
+  }
+
   // a fresh opaque copy of the lane id per layer: every address of the layer derives from it, nothing can be hoisted
   __device__ __forceinline__ int fresh_lane() const {
     int l = lane_;
@@ -559,51 +626,12 @@ struct S3Consumer {
 #pragma unroll 1
       for (int pass = 0; pass < PASSES; ++pass) {
         const int lane = fresh_lane();
-        const int half = lane >> 5, col = lane & 31;
         const int tile_base = pass * S3_NWC * NLAST;
         layerN<NLAST>(acc, NL - 1, boff, lane, tile_base);
-        const int ns = a.ns;                                  // 16, 32 or 64
-        const bool writer = ns == 16 ? (lane & 15) == 15 : (lane & 31) == 31;
 #pragma unroll
         for (int t = 0; t < NLAST; ++t) {
           const int mt = tile_base + wave + S3_NWC * t;
-          if (mt < mt_total) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-              if (ns == 64 && ct == 1) break;
-              float v[16];
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                float x = fmaxf(acc[t][ct][r], 0.f);
-                if (ns == 64) x = fmaxf(x, fmaxf(acc[t][1][r], 0.f));
-                // max over the 16 lanes of a DPP row: rotate by 1, 2, 4, 8
-                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)));
-                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)));
-                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)));
-                x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)));
-                if (ns >= 32)     // rows 1 and 3 take lane 15 of rows 0 and 2 (row_bcast15)
-                  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x142, 0xa,
-                                                                          0xf, false)));
-                v[r] = x;
-              }
-              // lane 15 (ns 16: and 31) of each 32-lane half holds the result of its centre: rows 8g + 4*half + 0..3
-              const int centre = ns == 64 ? col0 / 64 : (col0 + 32 * ct + (ns == 16 ? (col & 16) : 0)) / ns;
-              if (writer && centre < a.m) {
-                float* o = out + ((size_t)bi * a.m + centre) * a.ld_out + a.coff + mt * 32 + 4 * half;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const int row = mt * 32 + 8 * g + 4 * half;
-                  if (row + 3 < M) {
-                    *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-                  } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                      if (row + k < M) o[8 * g + k] = v[4 * g + k];
-                  }
-                }
-              }
-            }
-          }
+          if (mt < mt_total) pool_dpp(acc[t], mt, bi, col0, lane);
         }
       }
       ++blk_no;
@@ -622,7 +650,8 @@ struct S3Consumer {
     const int lane = fresh_lane();
     const int half = lane >> 5, col = lane & 31;
     if (IS_SA) {
-      // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip)
+      // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip;
+      // measured against the DPP form of the multi-round kernels: 4.0k vs 7.6k cycles for two tiles)
       float* sc = reinterpret_cast<float*>(P) + (size_t)wave * (32 * S3_EPAD);
       const int ns = a.ns;
       const int nout = ns >= 32 ? 1 : 32 / ns;
