@@ -424,11 +424,21 @@ def extra_configs(net, dev, poll_every, with_cpu):
         ms_g = _median_ms(lambda: g(inp["pc"]), 20)
         ms_gab = _median_ms(lambda: (g(inp["pc"]), post(inp)), 20)
         ms_fps = _median_ms(lambda: _e.furthest_point_sampling(inp["pcld"], 2048), 20)
+    # vote -> cluster -> pose of the frame as one HIP-graph replay too (bounded MeanShift iterations, no host poll)
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as _ev
+    ctr1 = inp["ctr_of"].unsqueeze(1) if inp["ctr_of"].dim() == 3 else inp["ctr_of"]
+    gp = _ev.GraphedFramePoses("lm", inp["pcld"], inp["mask"], ctr1, inp["pred_kp_of"], n_cls=2, obj_id=1,
+                               use_ctr_clus_flter=False)
+    ms_bg = _median_ms(lambda: gp(inp["pcld"], inp["mask"], ctr1, inp["pred_kp_of"]), 20)
+    ms_gg = None
+    if net is not None:
+        ms_gg = _median_ms(lambda: (g(inp["pc"]), gp(inp["pcld"], inp["mask"], ctr1, inp["pred_kp_of"])), 20)
         del g
     res = post(inp)
     out.append(dict(name="b1_latency", workload="config 2 (LineMOD eval path), ONE frame per call: N=12288, n_obj=3072, K=8",
                     ms_per_frame=dict(pointnet2_msg=ms_a, vote_cluster_pose=ms_b, both_serial=ms_ab,
-                                      pointnet2_msg_graph=ms_g, both_serial_graph=ms_gab, fps_level0=ms_fps),
+                                      pointnet2_msg_graph=ms_g, both_serial_graph=ms_gab, fps_level0=ms_fps,
+                                      vote_cluster_pose_graph=ms_bg, both_serial_both_graphs=ms_gg),
                     frames_per_s=1e3 / ms_ab, meanshift_iters_max=int(res["iters"].max().item()),
                     pose_err_vs_ground_truth=pose_err(res, inp["frames"])))
 
@@ -456,9 +466,14 @@ def extra_configs(net, dev, poll_every, with_cpu):
         for cid, (R, t) in f["poses"].items():
             err = max(err, float(np.abs(poses[i, cid - 1][:, :3] - R).max()), float(np.abs(poses[i, cid - 1][:, 3] - t).max()))
     ms1 = _median_ms(lambda: ev.cal_batch_poses(yp[:1], ym[:1], yc[:1], yk[:1], True, 22, True, poll_every=poll_every), 10)
+    # the same single-frame call as one HIP-graph replay (bounded MeanShift iterations, no host poll; frames that do not
+    # finish within the bound are repeated through the polled call -- none here)
+    gy = ev.GraphedFramePoses("ycb", yp[:1], ym[:1], yc[:1], yk[:1], n_cls=22)
+    ms1g = _median_ms(lambda: gy(yp[:1], ym[:1], yc[:1], yk[:1]), 10)
     out.append(dict(name="ycb_multi_instance", workload="config 3: N=12288, 21 classes, 5 objects of 1228 points, use_ctr_clus_flter=True; "
                                                          "16 frames per call",
                     ms_per_frame=ms / 16, frames_per_s=16e3 / ms, ms_single_frame_call=ms1,
+                    ms_single_frame_call_graph=ms1g, graph_fallbacks=gy.fallbacks,
                     meanshift_iters_max=int(ry["iters"].max().item()), pose_err_vs_ground_truth=err))
 
     # (iv) config 1: one 2048-point cloud, 1 object, all points on it; CPU path in full

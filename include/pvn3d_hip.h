@@ -246,8 +246,11 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
  * scratch.  poll_host: optional PINNED host int[2] used to stop enqueuing once every fit
  * has converged (the call then blocks on events every `poll_every` iterations, like the
  * reference's per-iteration host test, meanshift_pytorch.py:42); with poll_host == NULL the
- * call is fully asynchronous and enqueues all max_iter+1 iterations (finished fits exit at
- * block start).
+ * call is fully asynchronous: poll_every <= 0 enqueues all max_iter+1 iterations (finished fits exit
+ * at block start); poll_every = E > 0 enqueues at most E iterations -- a launch sequence of fixed
+ * length, capturable in a HIP graph -- and a fit that would still run after them reports
+ * iters[s] = -(iterations run): its centre is not final and the caller has to repeat the call
+ * with a poll buffer (typical vote sets converge in 4-6 iterations).
  * flags: PVN3D_MS_ALIGNED32 -- the caller guarantees seg_off[s] % 32 == 0 and that rows
  * [seg_off[s], seg_off[s] + roundup32(seg_cnt[s])) belong to segment s (pvn3d_vote_compact's
  * layout does; informational).  The iteration kernel keeps two seeds per lane (packed fp32 math)

@@ -919,6 +919,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
     const int* __restrict__ seg_cnt, const float4* __restrict__ c0,
     const float4* __restrict__ c1, const unsigned long long* __restrict__ best,
     const int* __restrict__ iters_ws, const float4* __restrict__ win_pos, const int* __restrict__ win_it,
+    const unsigned* __restrict__ maxshift, int max_iter, float thresh, int limit,
     float d2_max, float inv_kappa, float* __restrict__ ctr, uint8_t* __restrict__ labels,
     int* __restrict__ iters) {
   const int seg = blockIdx.y;
@@ -950,7 +951,10 @@ __global__ __launch_bounds__(MS_THREADS) void ms_final_kernel(
     ctr[seg * 3 + 0] = m.x * inv_kappa + org.x;
     ctr[seg * 3 + 1] = m.y * inv_kappa + org.y;
     ctr[seg * 3 + 2] = m.z * inv_kappa + org.z;
-    if (iters) iters[seg] = it;
+    // enqueue limit (no host poll): a fit that would still run reports -(iterations run); its centre is not final
+    const bool unfinished = it >= limit && it <= max_iter && !win_it[seg] &&
+                            __uint_as_float(maxshift[(size_t)seg * (max_iter + 2) + it]) >= thresh;
+    if (iters) iters[seg] = unfinished ? -it : it;
   }
 }
 
@@ -1072,7 +1076,10 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   }
   int rc = 0;
   int next_poll = poll_every;
-  for (int t = 1; t <= max_iter + 1; ++t) {
+  // no poll buffer + poll_every = E > 0: enqueue at most E iterations and report unfinished fits through `iters`
+  // (negative) -- a launch sequence of fixed length without a host round trip, i.e. capturable in a HIP graph
+  const int iter_limit = (!poll && poll_every > 0 && poll_every < max_iter + 1) ? poll_every : max_iter + 1;
+  for (int t = 1; t <= iter_limit; ++t) {
     const float4* cin = S.cbuf[(t - 1) & 1];
     float4* cout = S.cbuf[t & 1];
 #define MS_ITER(PK_, SP_)                                                                                    \
@@ -1133,8 +1140,8 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   if (rc) return rc;
   PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(ms_final_kernel, grid_1, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                     S.cbuf[0], S.cbuf[1], S.best, S.iters, S.win_pos, S.win_it, d2_max,
-                     inv_kappa, ctr, labels, iters);
+                     S.cbuf[0], S.cbuf[1], S.best, S.iters, S.win_pos, S.win_it, S.maxshift, max_iter, thresh,
+                     iter_limit, d2_max, inv_kappa, ctr, labels, iters);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

@@ -46,12 +46,14 @@ DEFAULT_KERNEL = None
 
 
 def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300, labels=None,
-                        poll_every=8, aligned32=False, kernel=None):
+                        poll_every=8, aligned32=False, kernel=None, enqueue_limit=None):
     """Batched MeanShiftTorch.fit.
 
     pts4 (total,4) float32 cuda; seg_off/seg_cnt (n_seg) int32 cuda; max_cnt: host bound on
     seg_cnt.  Returns ctr (n_seg,3) float32, labels (total) uint8, iters (n_seg) int32.
     poll_every = 0 -> fully asynchronous (enqueues max_iter+1 iterations).
+    enqueue_limit = E -> no host poll and at most E iterations enqueued (a fixed launch sequence: capturable in a HIP
+    graph); fits that would still run come back with a NEGATIVE iteration count and a centre that is not final.
     aligned32: every seg_off is a multiple of 32 and each segment owns roundup32(cnt) rows.
     kernel: None (library default) or a '+'-joined choice of "scalar" | "packed", "whole" | "split" and
     "noearly" (no early-out of converged seeds) -- pins the iteration kernel variant (all give identical results);
@@ -84,7 +86,9 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
         return ctr, labels, iters
     ws_bytes = int(lib.pvn3d_meanshift_workspace_bytes(n_seg, total, int(max_iter)))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    poll = _poll_buf() if poll_every > 0 else None
+    poll = _poll_buf() if poll_every > 0 and enqueue_limit is None else None
+    if enqueue_limit is not None:
+        poll_every = int(enqueue_limit)
     with on_device(dev):
         check(lib.pvn3d_meanshift_fit_batch(
             pts4.data_ptr(), seg_off.data_ptr(), seg_cnt.data_ptr(), n_seg, total, int(max_cnt),
@@ -131,6 +135,19 @@ def best_fit_transform_batch(A, B, valid=None):
     return T
 
 
+_const_cache = {}
+
+
+def _device_const(key, dev, make):
+    """Small constant tensors (mesh keypoints, thresholds, index ramps) uploaded once per device: a host-to-device copy
+    per call would also make the single-frame path uncapturable."""
+    k = (key, str(dev))
+    t = _const_cache.get(k)
+    if t is None:
+        t = _const_cache[k] = make().to(dev)
+    return t
+
+
 def _prep(pcld, mask, ctr_of, pred_kp_of):
     pcld = pcld.contiguous().float()
     mask = mask.contiguous().to(torch.int32)
@@ -140,12 +157,14 @@ def _prep(pcld, mask, ctr_of, pred_kp_of):
 
 
 def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1, use_ctr=True,
-                             use_ctr_clus_flter=False, radius=0.08, max_iter=300, poll_every=8):
+                             use_ctr_clus_flter=False, radius=0.08, max_iter=300, poll_every=8, async_limit=None):
     """Batched cal_frame_poses_lm (pvn3d/lib/utils/pvn3d_eval_utils.py:156-201).
 
     pcld (F,N,3); mask (F,N) integer; ctr_of (F,1,N,3); pred_kp_of (F,K,N,3);
     mesh_kps (K+use_ctr,3) object-frame keypoints (+centre last).
     Returns dict(poses (F,3,4) f64 cuda, cls_kps (F,K+1,3), iters (F,K+1), counts (F,K+1)).
+    async_limit = E: no host poll, at most E iterations per fit batch enqueued; `iters` < 0 marks fits that did not
+    finish (their poses are not final) -- the launch sequence is then fixed and capturable (GraphedFramePoses).
     """
     pcld, mask, ctr_of, pred_kp_of = _prep(pcld, mask, ctr_of, pred_kp_of)
     dev = pcld.device
@@ -157,7 +176,7 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         votes, seg_off, seg_cnt = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame,
                                                inst_cls, 0, K + 1)
         ctr, _, iters = meanshift_fit_batch(votes, seg_off, seg_cnt, N, radius, max_iter,
-                                            poll_every=poll_every, aligned32=(N % 32 == 0))
+                                            poll_every=poll_every, aligned32=(N % 32 == 0), enqueue_limit=async_limit)
     else:
         out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
         votes, seg_off, seg_cnt = out
@@ -165,21 +184,25 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         sc = seg_cnt.view(F, K + 1)
         c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(),
                                                     sc[:, K].contiguous(), N, radius, max_iter,
-                                                    poll_every=poll_every, aligned32=(N % 32 == 0))
+                                                    poll_every=poll_every, aligned32=(N % 32 == 0),
+                                                    enqueue_limit=async_limit)
         # keypoint votes filtered by the centre fit's inlier labels (rows of segment K)
         sel = labels[K * N:]
         vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
                      sel_inst_stride=(K + 1) * N, out=out)
         c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
                                              sc[:, :K].contiguous().view(-1), N, radius, max_iter,
-                                             poll_every=poll_every, aligned32=(N % 32 == 0))
+                                             poll_every=poll_every, aligned32=(N % 32 == 0),
+                                             enqueue_limit=async_limit)
         ctr = torch.cat([c_kp.view(F, K, 3), c_ctr.view(F, 1, 3)], 1).view(-1, 3)
         iters = torch.cat([it_kp.view(F, K), it_ctr.view(F, 1)], 1).view(-1)
     cls_kps = ctr.view(F, K + 1, 3)
     counts = seg_cnt.view(F, K + 1)
     valid = (mask == int(cls_id)).any(dim=1).to(torch.int32)
     npts = K + 1 if use_ctr else K
-    A = mesh_kps.to(device=dev, dtype=torch.float32)[:npts].unsqueeze(0).expand(F, npts, 3).contiguous()
+    mesh_dev = mesh_kps if mesh_kps.device == dev else _device_const(
+        ("mesh1", mesh_kps.detach().to(torch.float32).numpy().tobytes()), dev, lambda: mesh_kps.to(torch.float32))
+    A = mesh_dev.to(torch.float32)[:npts].unsqueeze(0).expand(F, npts, 3).contiguous()
     B = cls_kps[:, :npts].contiguous()
     poses = best_fit_transform_batch(A, B, valid)
     return dict(poses=poses, cls_kps=cls_kps, iters=iters.view(F, K + 1), counts=counts)
@@ -205,7 +228,7 @@ def relabel_by_centre(pcld, ctr_of0, mask, ctrs, present, thr_lst):
 
 def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls, radius_lst,
                             use_ctr=True, use_ctr_clus_flter=True, radius=0.08, max_iter=300,
-                            poll_every=8):
+                            poll_every=8, async_limit=None):
     """Batched cal_frame_poses (pvn3d/lib/utils/pvn3d_eval_utils.py:37-110) for every class id
     1..n_cls-1 of every frame; absent classes are empty segments.
 
@@ -228,10 +251,12 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     # A single frame (the reference's test_mini_batch_size = 1) instantiates all C class slots instead (40 MB of
     # votes): no host round trip at all, the absent classes are empty segments.
     if F == 1:
-        pairs = torch.stack([torch.zeros(C, dtype=torch.long), torch.arange(C, dtype=torch.long)], 1)
+        pf = torch.zeros(C, dtype=torch.long, device=dev)
+        pc = torch.arange(C, dtype=torch.long, device=dev)
+        n_inst = C
     else:
         pairs = torch.nonzero(present.cpu())                                    # (n_inst, 2) on the host
-    n_inst = int(pairs.size(0))
+        n_inst = int(pairs.size(0))
     poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
     poses_full[:, :, 0, 0] = 1.0
     poses_full[:, :, 1, 1] = 1.0
@@ -241,8 +266,9 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     if n_inst == 0:
         return dict(poses=poses_full, present=present0, present_new=present, cls_kps=kps_full, iters=iters_full,
                     new_mask=mask)
-    pf = pairs[:, 0].to(device=dev, dtype=torch.long)
-    pc = pairs[:, 1].to(device=dev, dtype=torch.long)
+    if F != 1:
+        pf = pairs[:, 0].to(device=dev, dtype=torch.long)
+        pc = pairs[:, 1].to(device=dev, dtype=torch.long)
     inst_frame = pf.to(torch.int32)
     inst_cls = (pc + 1).to(torch.int32)
     out = None
@@ -251,10 +277,11 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
         votes, seg_off, seg_cnt = out
         so = seg_off.view(n_inst, K + 1)
         sc = seg_cnt.view(n_inst, K + 1)
-        c0, _, _ = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
-                                       radius, max_iter, poll_every=poll_every,
-                                       aligned32=(N % 32 == 0))
-        thr = torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)).to(dev)
+        c0, _, it0 = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
+                                         radius, max_iter, poll_every=poll_every,
+                                         aligned32=(N % 32 == 0), enqueue_limit=async_limit)
+        thr = _device_const(("ycb_thr", tuple(np.asarray(radius_lst, np.float64).tolist())), dev,
+                            lambda: torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)))
         ctrs = torch.zeros((F, C, 3), dtype=torch.float32, device=dev)
         ctrs[pf, pc] = c0
         mask, present = relabel_by_centre(pcld, ctr_of[:, 0], mask, ctrs, present, thr)
@@ -265,17 +292,22 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     sc = seg_cnt.view(n_inst, K + 1)
     c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(),
                                                 N, radius, max_iter, poll_every=poll_every,
-                                                aligned32=(N % 32 == 0))
+                                                aligned32=(N % 32 == 0), enqueue_limit=async_limit)
     sel = labels[K * N:] if use_ctr_clus_flter else None
     vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
                  sel_inst_stride=(K + 1) * N, out=out)
     c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
                                          sc[:, :K].contiguous().view(-1), N, radius, max_iter,
-                                         poll_every=poll_every, aligned32=(N % 32 == 0))
+                                         poll_every=poll_every, aligned32=(N % 32 == 0), enqueue_limit=async_limit)
     cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
     iters = torch.cat([it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)], 1)
+    if use_ctr_clus_flter:
+        # an unfinished filter-pass fit (async_limit only) taints everything after it: carry its sign
+        iters = torch.where((it0 < 0).view(n_inst, 1).expand_as(iters), -iters.abs(), iters)
     npts = K + 1 if use_ctr else K
-    A = mesh_kps_all.to(device=dev, dtype=torch.float32)[pc, :npts].contiguous()
+    mesh_dev = mesh_kps_all if mesh_kps_all.device == dev else _device_const(
+        ("mesh_all", mesh_kps_all.detach().to(torch.float32).numpy().tobytes()), dev, lambda: mesh_kps_all.to(torch.float32))
+    A = mesh_dev.to(torch.float32)[pc, :npts].contiguous()
     B = cls_kps[:, :npts].contiguous()
     valid = present[pf, pc].to(torch.int32).contiguous()
     poses = best_fit_transform_batch(A, B, valid)

@@ -35,13 +35,13 @@ def _mesh_kps(cls, ds_type, use_ctr):
 
 
 def cal_batch_poses_lm(pclds, masks, ctr_ofs, pred_kp_ofs, use_ctr, n_cls, use_ctr_clus_flter,
-                       obj_id, poll_every=8):
+                       obj_id, poll_every=8, async_limit=None):
     """Batched cal_frame_poses_lm: pclds (F,N,3), masks (F,N), ctr_ofs (F,1,N,3),
     pred_kp_ofs (F,K,N,3).  Returns the engine dict (poses (F,3,4) float64 on the device, ...)."""
     mesh = _mesh_kps(obj_id, "linemod", True)
     return _eng.frames_pose_single_class(pclds, masks, ctr_ofs, pred_kp_ofs, mesh, cls_id=1,
                                          use_ctr=use_ctr, use_ctr_clus_flter=use_ctr_clus_flter,
-                                         radius=RADIUS, poll_every=poll_every)
+                                         radius=RADIUS, poll_every=poll_every, async_limit=async_limit)
 
 
 def cal_frame_poses_lm(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus_flter, obj_id):
@@ -62,12 +62,65 @@ def _ycb_mesh_all(n_cls, use_ctr=True):
 
 
 def cal_batch_poses(pclds, masks, ctr_ofs, pred_kp_ofs, use_ctr, n_cls, use_ctr_clus_flter,
-                    poll_every=8):
+                    poll_every=8, async_limit=None):
     """Batched cal_frame_poses over F frames and class ids 1..n_cls-1 (engine dict)."""
     return _eng.frames_pose_multi_class(pclds, masks, ctr_ofs, pred_kp_ofs, _ycb_mesh_all(n_cls),
                                         n_cls, _bs_utils.ycb_r_lst, use_ctr=use_ctr,
                                         use_ctr_clus_flter=use_ctr_clus_flter, radius=RADIUS,
-                                        poll_every=poll_every)
+                                        poll_every=poll_every, async_limit=async_limit)
+
+
+class GraphedFramePoses(object):
+    """HIP-graph replay of the vote -> cluster -> pose call for frames of ONE static shape -- the reference evaluates one
+    frame per call (test_mini_batch_size = 1, pvn3d/common.py:41), where the ~100 launches and three host polls of the
+    call, not the GPU, set its latency.
+
+        g = GraphedFramePoses("ycb", pcld, mask, ctr_of, pred_kp_of, n_cls=22)        # batched tensors (F, N, ...)
+        res = g(pcld, mask, ctr_of, pred_kp_of)                                      # the engine dict, like cal_batch_poses
+
+    The captured sequence enqueues at most `async_limit` MeanShift iterations per fit batch and no host poll; fits that
+    have not finished by then mark themselves (iters < 0).  `__call__` reads that flag together with the results and,
+    if any fit is unfinished (heavy-tailed votes), repeats the frame through the ordinary polled call -- same results
+    either way.  kind: "lm" (cal_batch_poses_lm, needs obj_id) or "ycb" (cal_batch_poses)."""
+
+    def __init__(self, kind, pclds, masks, ctr_ofs, pred_kp_ofs, n_cls, use_ctr=True, use_ctr_clus_flter=None, obj_id=None,
+                 async_limit=12, warmup=2):
+        assert kind in ("lm", "ycb") and pclds.is_cuda
+        self.kind, self.n_cls, self.use_ctr, self.obj_id = kind, n_cls, use_ctr, obj_id
+        self.flt = (kind == "ycb") if use_ctr_clus_flter is None else use_ctr_clus_flter
+        self.async_limit = async_limit
+        self.static = [t.clone() for t in (pclds, masks, ctr_ofs, pred_kp_ofs)]
+        self.fallbacks = 0
+        cur = torch.cuda.current_stream(pclds.device)
+        side = torch.cuda.Stream(device=pclds.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                       # allocator pools, cached constants, LDS opt-ins
+                self._run(async_limit)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(pclds.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.res = self._run(async_limit)
+            self.unfinished = (self.res["iters"] < 0).any()
+
+    def _run(self, limit, poll_every=8):
+        p, m, c, k = self.static
+        if self.kind == "lm":
+            return cal_batch_poses_lm(p, m, c, k, self.use_ctr, self.n_cls, self.flt, self.obj_id, poll_every=poll_every,
+                                      async_limit=limit)
+        return cal_batch_poses(p, m, c, k, self.use_ctr, self.n_cls, self.flt, poll_every=poll_every, async_limit=limit)
+
+    def __call__(self, pclds, masks, ctr_ofs, pred_kp_ofs):
+        for dst, src in zip(self.static, (pclds, masks, ctr_ofs, pred_kp_ofs)):
+            if dst.shape != src.shape:
+                raise RuntimeError("GraphedFramePoses was captured for shape %s" % (tuple(dst.shape),))
+            dst.copy_(src)
+        self.graph.replay()
+        if bool(self.unfinished.item()):                  # the one host read of the call (results are read next anyway)
+            self.fallbacks += 1
+            return self._run(None)
+        return self.res
 
 
 def cal_frame_poses(pcld, mask, ctr_of, pred_kp_of, use_ctr, n_cls, use_ctr_clus_flter):

@@ -449,3 +449,39 @@ def test_full_size_ycb_frames_vs_oracle(dev, orc):
             assert np.abs(poses[fi, cid - 1] - w).max() < TOL, (fi, cid)
             R, t = f["poses"][int(cid)]
             assert np.abs(poses[fi, cid - 1][:, :3] - R).max() < 3e-2 and np.abs(poses[fi, cid - 1][:, 3] - t).max() < 3e-3
+
+
+def test_graphed_single_frame_poses_equal_the_polled_call(dev):
+    """GraphedFramePoses: the single-frame vote -> cluster -> pose call as one HIP-graph replay (bounded MeanShift
+    iterations, no host poll) returns exactly what the ordinary polled call returns -- LineMOD and YCB (centre-cluster
+    filter on), a second frame through the same graph, and a heavy-tailed frame that does not finish within the bound and
+    is repeated through the polled path."""
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+
+    def lm(frame, **kw):
+        f = synth.synth_frame(frame=frame, n_pts=12288, n_obj=3072, **kw)
+        return [T(f["pcld"], dev)[None], T(f["mask"], dev)[None], T(f["ctr_of"], dev)[None], T(f["pred_kp_of"], dev)[None]]
+
+    a, b, heavy = lm(40), lm(41), lm(42, sig_out=0.30)
+    g = ev.GraphedFramePoses("lm", *a, n_cls=2, obj_id=1, use_ctr_clus_flter=False)
+    for inp in (a, b, a):
+        want = ev.cal_batch_poses_lm(*inp, True, 2, False, 1)
+        got = g(*inp)
+        assert torch.equal(got["poses"], want["poses"]) and torch.equal(got["cls_kps"], want["cls_kps"])
+    assert g.fallbacks == 0
+    want = ev.cal_batch_poses_lm(*heavy, True, 2, False, 1)
+    assert int(want["iters"].max()) > 12                      # this frame needs more than the graph's bound
+    got = g(*heavy)
+    assert g.fallbacks == 1
+    assert torch.equal(got["poses"], want["poses"])
+
+    y = [synth.synth_frame_ycb(frame=50 + i, n_pts=12288) for i in range(2)]
+    Y = lambda f: [T(f["pcld"], dev)[None], T(f["mask"], dev).to(torch.int32)[None], T(f["ctr_of"], dev)[None],
+                   T(f["pred_kp_of"], dev)[None]]
+    gy = ev.GraphedFramePoses("ycb", *Y(y[0]), n_cls=22)
+    for f in (y[0], y[1], y[0]):
+        want = ev.cal_batch_poses(*Y(f), True, 22, True)
+        got = gy(*Y(f))
+        assert torch.equal(got["poses"], want["poses"]) and torch.equal(got["present"], want["present"])
+        assert torch.equal(got["new_mask"], want["new_mask"])
+    assert gy.fallbacks == 0
