@@ -79,3 +79,16 @@ __device__ __forceinline__ int pvn3d_mbcnt(unsigned long long mask) {
 }
 
 __device__ __forceinline__ int pvn3d_lane() { return threadIdx.x & (PVN3D_WAVE - 1); }
+
+// Word fill as a kernel of this library.  Used instead of hipMemsetAsync wherever the call sequence may be captured into
+// a HIP graph (Pointnet2MSG.graphed, GraphedFramePoses): the runtime's memset node was observed to land out of order
+// with the kernels around it on replay; a kernel node is an ordinary link of the captured chain.
+static __global__ __launch_bounds__(256) void pvn3d_fill_u32_kernel(unsigned* __restrict__ p, unsigned v, size_t n) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) p[i] = v;
+}
+static inline void pvn3d_fill_u32(void* p, unsigned v, size_t n_words, hipStream_t st) {
+  if (n_words == 0) return;
+  const size_t blocks = (n_words + 255) / 256;
+  hipLaunchKernelGGL(pvn3d_fill_u32_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st,
+                     (unsigned*)p, v, n_words);
+}

@@ -1011,7 +1011,11 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   const size_t small_bytes =
       ((char*)workspace + pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter)) -
       (char*)S.maxshift;
-  PVN3D_RETURN_IF_ERR(hipMemsetAsync(S.maxshift, 0, small_bytes, st));
+  // zero the per-call state with a kernel of this library, not hipMemsetAsync: inside a captured HIP graph
+  // (GraphedFramePoses) the runtime's memset node was observed to land out of order with the kernels around it
+  // (random memory faults from a zeroed-too-late n_core / counts), a kernel node is an ordinary link of the chain
+  pvn3d_fill_u32(S.maxshift, 0u, small_bytes / 4, st);
+  PVN3D_LAUNCH_CHECK();
 
   const float thresh = (float)((double)bandwidth * 1e-3);  // meanshift_pytorch.py:21
   const float kappa = sqrtf(0.5f * 1.44269504088896341f) / bandwidth;

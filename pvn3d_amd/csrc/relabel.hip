@@ -66,7 +66,8 @@ extern "C" int pvn3d_relabel_by_centre(int n_frames, int n_pts, int n_cls_m1, co
       !new_mask || !present_new)
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  PVN3D_RETURN_IF_ERR(hipMemsetAsync(present_new, 0, sizeof(int) * (size_t)n_frames * n_cls_m1, st));
+  pvn3d_fill_u32(present_new, 0u, (size_t)n_frames * n_cls_m1, st);
+  PVN3D_LAUNCH_CHECK();
   hipLaunchKernelGGL(relabel_kernel, dim3(pvn3d_ceil_div(n_pts, 256), n_frames), dim3(256), 0, st, n_pts,
                      n_cls_m1, pcld, ctr_of, mask, ctrs, present, thr, new_mask, present_new);
   PVN3D_LAUNCH_CHECK();

@@ -567,7 +567,8 @@ extern "C" int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_l
   for (int l = 0; l < n_levels; ++l) lv.tmax = lv.m[l] > lv.tmax ? lv.m[l] : lv.tmax;
   if ((size_t)lv.tmax * sizeof(float4) > 128 * 1024) return (int)hipErrorInvalidValue;
   // 0x7f7f7f7f = "no round has to be run"
-  PVN3D_RETURN_IF_ERR(hipMemsetAsync(flags, 0x7f, (size_t)b * FPS_NEST_LEVELS * sizeof(int), st));
+  pvn3d_fill_u32(flags, 0x7f7f7f7fu, (size_t)b * FPS_NEST_LEVELS, st);
+  PVN3D_LAUNCH_CHECK();
   PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(fps_nest_verify_kernel));
   hipLaunchKernelGGL(fps_nest_verify_kernel, dim3(pvn3d_ceil_div(n0, 64), b), dim3(1024),
                      (size_t)lv.tmax * sizeof(float4), st, n0, lv, ordered_xyz, dmax, flags);

@@ -84,7 +84,7 @@ class GraphedFramePoses(object):
     either way.  kind: "lm" (cal_batch_poses_lm, needs obj_id) or "ycb" (cal_batch_poses)."""
 
     def __init__(self, kind, pclds, masks, ctr_ofs, pred_kp_ofs, n_cls, use_ctr=True, use_ctr_clus_flter=None, obj_id=None,
-                 async_limit=12, warmup=2):
+                 async_limit=8, warmup=2):
         assert kind in ("lm", "ycb") and pclds.is_cuda
         self.kind, self.n_cls, self.use_ctr, self.obj_id = kind, n_cls, use_ctr, obj_id
         self.flt = (kind == "ycb") if use_ctr_clus_flter is None else use_ctr_clus_flter

@@ -454,8 +454,8 @@ def test_full_size_ycb_frames_vs_oracle(dev, orc):
 def test_graphed_single_frame_poses_equal_the_polled_call(dev):
     """GraphedFramePoses: the single-frame vote -> cluster -> pose call as one HIP-graph replay (bounded MeanShift
     iterations, no host poll) returns exactly what the ordinary polled call returns -- LineMOD and YCB (centre-cluster
-    filter on), a second frame through the same graph, and a heavy-tailed frame that does not finish within the bound and
-    is repeated through the polled path."""
+    filter on), a second frame through the same graph, and a bound the fits do not finish within (the frame is then
+    repeated through the polled path)."""
     from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
 
     def lm(frame, **kw):
@@ -469,10 +469,15 @@ def test_graphed_single_frame_poses_equal_the_polled_call(dev):
         got = g(*inp)
         assert torch.equal(got["poses"], want["poses"]) and torch.equal(got["cls_kps"], want["cls_kps"])
     assert g.fallbacks == 0
+    # a bound the fits do not finish within (they need 4-6 iterations, heavy-tailed votes included thanks to the winner
+    # stop): every fit marks itself unfinished, the frame is repeated through the polled call, same result
     want = ev.cal_batch_poses_lm(*heavy, True, 2, False, 1)
-    assert int(want["iters"].max()) > 12                      # this frame needs more than the graph's bound
+    assert 3 < int(want["iters"].max()) <= 8
     got = g(*heavy)
-    assert g.fallbacks == 1
+    assert g.fallbacks == 0 and torch.equal(got["poses"], want["poses"])
+    g3 = ev.GraphedFramePoses("lm", *a, n_cls=2, obj_id=1, use_ctr_clus_flter=False, async_limit=3)
+    got = g3(*heavy)
+    assert g3.fallbacks == 1
     assert torch.equal(got["poses"], want["poses"])
 
     y = [synth.synth_frame_ycb(frame=50 + i, n_pts=12288) for i in range(2)]
