@@ -309,7 +309,10 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
   __shared__ int s_stage[4][NB][BQG_STAGE + 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bi = blockIdx.y;
+  // every workgroup of a cloud on one XCD: `sorted` / `cell_start` of the cloud are then fetched from HBM once, not
+  // once per XCD (PMC: 3.3x the algorithmic traffic with the plain mapping)
+  int bi, bx;
+  pvn3d_xcd_frame_map(bi, bx);
   unsigned* const bma = s_bm + (size_t)wave * NB * WORDS;
   unsigned* const bmb = bma + (NB - 1) * WORDS;
   bq_u16* const prea = reinterpret_cast<bq_u16*>(s_bm + (size_t)4 * NB * WORDS) + (size_t)wave * NB * WORDS;
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(
   const int stride = 4 * gridDim.x;
   float ncx, ncy, ncz;
   int nbeg, ncnt;
-  fetch_cells(blockIdx.x * 4 + wave, ncx, ncy, ncz, nbeg, ncnt);
-  for (int j = blockIdx.x * 4 + wave; j < m; j += stride) {
+  fetch_cells(bx * 4 + wave, ncx, ncy, ncz, nbeg, ncnt);
+  for (int j = bx * 4 + wave; j < m; j += stride) {
     const float cx = ncx, cy = ncy, cz = ncz;
     const int beg = nbeg, cnt = ncnt;
     fetch_cells(j + stride, ncx, ncy, ncz, nbeg, ncnt);

@@ -80,6 +80,21 @@ __device__ __forceinline__ int pvn3d_mbcnt(unsigned long long mask) {
 
 __device__ __forceinline__ int pvn3d_lane() { return threadIdx.x & (PVN3D_WAVE - 1); }
 
+// XCD-aware (frame, tile) of a workgroup in a (tiles, frames) grid.  Workgroups are dealt round-robin to the 8 XCDs in
+// linear-id order, each XCD with its own 4 MB L2: with the plain (x = tile, y = frame) reading every XCD touches every
+// frame's tables (and fetches its own copy of them from HBM); here XCD x works through frames x, x + 8, x + 16, ...
+__device__ __forceinline__ void pvn3d_xcd_frame_map(int& frame, int& tile) {
+  const int nb = gridDim.x, nf = gridDim.y;
+  tile = blockIdx.x;
+  frame = blockIdx.y;
+  if ((nf & 7) == 0) {
+    const unsigned lin = blockIdx.x + (unsigned)nb * blockIdx.y;
+    const unsigned q = lin >> 3;
+    frame = (int)(lin & 7) + 8 * (int)(q / nb);
+    tile = (int)(q % nb);
+  }
+}
+
 // Word fill as a kernel of this library.  Used instead of hipMemsetAsync wherever the call sequence may be captured into
 // a HIP graph (Pointnet2MSG.graphed, GraphedFramePoses): the runtime's memset node was observed to land out of order
 // with the kernels around it on replay; a kernel node is an ordinary link of the captured chain.

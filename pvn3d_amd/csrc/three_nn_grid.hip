@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(int n, int m, const 
   extern __shared__ float4 s_dyn[];
   float4* s_pts = s_dyn;                                          // [m]
   int* s_start = reinterpret_cast<int*>(s_dyn + m);               // [NG_T + 1]
-  const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  int bi, bx;
+  pvn3d_xcd_frame_map(bi, bx);          // a cloud's workgroups on one XCD: its bucket table is fetched from HBM once
   cell_start += (size_t)bi * (NG_T + 1);
   sorted += (size_t)bi * m;
   unknown += (size_t)bi * n * 3;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void three_nn_grid_kernel(int n, int m, const 
   __syncthreads();
 #pragma unroll 1
   for (int q = 0; q < QPT; ++q) {
-    const int j = (blockIdx.x * QPT + q) * 256 + tid;
+    const int j = (bx * QPT + q) * 256 + tid;
     const bool live = j < n;          // dead lanes still help in the cooperative fallback below
     float ux = 0.f, uy = 0.f, uz = 0.f;
     if (live) { ux = unknown[j * 3 + 0]; uy = unknown[j * 3 + 1]; uz = unknown[j * 3 + 2]; }
