@@ -109,6 +109,11 @@ int pvn3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
 int pvn3d_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
                    int* idx, void* stream);
 
+/* Inverse-distance interpolation weights of PointnetFPModule.forward (pointnet2_modules.py:184-186) from three_nn's
+ * dist2 (rows, 3): dist = sqrt(dist2); r = 1 / (dist + 1e-8); weight = r / (r0 + r1 + r2), fp32 in the reference's
+ * operation order (one launch instead of five elementwise kernels). */
+int pvn3d_three_nn_weights(long long rows, const float* dist2, float* weight, void* stream);
+
 /* Same output as pvn3d_three_nn, bit for bit, through a uniform grid over the known points
  * (csrc/three_nn_grid.hip): 64 <= m <= 2048; workspace >= pvn3d_three_nn_grid_workspace_bytes(b, m)
  * bytes of device memory (bucket table + bucket-ordered copy of `known`).  ~30x fewer distance

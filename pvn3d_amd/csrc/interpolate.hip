@@ -425,3 +425,30 @@ extern "C" int pvn3d_three_interpolate_grad(int b, int c, int n, int m, const fl
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
+
+// Inverse-distance weights of PointnetFPModule.forward (pointnet2_modules.py:184-186) from three_nn's squared distances,
+// in the reference's fp32 operation order: dist = sqrt(dist2); dist_recip = 1.0 / (dist + 1e-8);
+// norm = sum(dist_recip, dim=2); weight = dist_recip / norm.  One launch instead of five elementwise torch kernels.
+namespace {
+__global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, const float* __restrict__ dist2,
+                                                               float* __restrict__ weight) {
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= rows) return;
+  const float r0 = 1.0f / (sqrtf(dist2[i * 3 + 0]) + 1e-8f);
+  const float r1 = 1.0f / (sqrtf(dist2[i * 3 + 1]) + 1e-8f);
+  const float r2 = 1.0f / (sqrtf(dist2[i * 3 + 2]) + 1e-8f);
+  const float norm = (r0 + r1) + r2;
+  weight[i * 3 + 0] = r0 / norm;
+  weight[i * 3 + 1] = r1 / norm;
+  weight[i * 3 + 2] = r2 / norm;
+}
+}  // namespace
+
+extern "C" int pvn3d_three_nn_weights(long long rows, const float* dist2, float* weight, void* stream) {
+  if (rows <= 0) return 0;
+  if (!dist2 || !weight || rows > 0x7fffffffLL * 256) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(three_nn_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                     dist2, weight);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}

@@ -285,8 +285,8 @@ __device__ __forceinline__ void b_load(bf16x8 (&b)[CS ? 1 : 2][3], const char* b
 }
 
 // the six partial products of one slab, smallest terms first; consecutive MFMAs hit different accumulators
-template <int NTC, int NT, bool CS>
-__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NTC][3],
+template <int NTC, int NT, bool CS, int NR>
+__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][3],
                                         const bf16x8 (&b)[CS ? 1 : 2][3]) {
 #define S3_MM(PA, PB)                                                                                                  \
   _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < (CS ? 1 : 2); ++c)             \
@@ -335,8 +335,8 @@ struct S3Consumer {
       w.voff[t] = ((unsigned)min(tile_base + wave + S3_NWC * t, mt_total - 1) * 192u + (unsigned)lane) * 16u;
     return w;
   }
-  template <int NTC>
-  __device__ __forceinline__ void a_load(uint4 (&r)[NTC][3], const WSrc<NTC>& w, int slab) const {
+  template <int NTC, int NR>
+  __device__ __forceinline__ void a_load(uint4 (&r)[NR][3], const WSrc<NTC>& w, int slab) const {
     const char* sb = w.sbase + (size_t)((unsigned)min(slab, w.last) * w.sstride);      // scalar
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
@@ -391,9 +391,9 @@ struct S3Consumer {
     const WSrc<NTC> w = wsrc<NTC>(0, slabs, lane);
     init_acc<NTC>(acc, 0, 0, half);
     uint4 ringA[4][NTC][3];
-    a_load<NTC>(ringA[0], w, 0);
-    a_load<NTC>(ringA[1], w, 1);
-    a_load<NTC>(ringA[2], w, 2);
+    a_load<NTC, NTC>(ringA[0], w, 0);
+    a_load<NTC, NTC>(ringA[1], w, 1);
+    a_load<NTC, NTC>(ringA[2], w, 2);
     // this lane's fragment addresses in ring slot 0; slot k is + k * S3_CHUNK
     const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
     const int n_chunks = n_full + (tail ? 1 : 0);
@@ -419,12 +419,12 @@ struct S3Consumer {
     BSrc bs_;                                                                                          \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)  \
         bs_.p[c_][p_] = bs0.p[c_][p_] + slot_ * S3_CHUNK;                                              \
-    a_load<NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
+    a_load<NTC, NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
     b_ld<32>(bB, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], bA);                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    a_load<NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
+    a_load<NTC, NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
     if ((C) + 1 < n_chunks) {                                                                          \
       const int slotn_ = (cn_ + 1) & (S3_RING - 1);                                                    \
       lds_wait_ge(&ctl->rdy[slotn_], cn_ + 2);                                                         \
@@ -457,27 +457,36 @@ struct S3Consumer {
   }
 
   // layers >= 1: the input is P.  Three row tiles per wave (NTC = 3: 96 accumulator registers) run a two-slot weight
-  // ring -- one slab of 36 MFMAs (1.1k cycles) of cover -- the others the four-slot ring.
+  // ring -- one slab of 36 MFMAs (1.1k cycles) of cover -- the others the four-slot ring.  The first RD - 1 slabs of a
+  // layer's weights are requested by preloadA BEFORE the barrier + activation store + barrier that precede the layer
+  // (the ring registers are free then): the ~2k-cycle L2 round trip runs under the store phase instead of heading the
+  // layer (short layers -- 8 slabs -- spent a quarter of their time there).
   template <int NTC>
-  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], int l, int boff, int lane, int tile_base = 0) {
+  __device__ __forceinline__ void preloadA(uint4 (&R)[4][NMAX][3], int l, int lane, int tile_base = 0) const {
+    constexpr int RD = NTC >= 3 ? 2 : 4;
+    const int slabs = (a.K[l] + 15) >> 4;
+    const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
+#pragma unroll
+    for (int u = 0; u < RD - 1; ++u) a_load<NTC, NMAX>(R[u], w, u);
+  }
+  template <int NTC>
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], uint4 (&R)[4][NMAX][3], int l, int boff, int lane,
+                                         int tile_base = 0) {
     const int half = lane >> 5, col = lane & 31;
     const int slabs = (a.K[l] + 15) >> 4;
     const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
     init_acc<NTC>(acc, l, boff, half, tile_base);
     BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);
     constexpr int RD = NTC >= 3 ? 2 : 4;
-    uint4 ringA[RD][NTC][3];
     bf16x8 b[2][2][3];
-#pragma unroll
-    for (int u = 0; u < RD - 1; ++u) a_load<NTC>(ringA[u], w, u);
     b_ld<0>(b[0], bs);
     // slab S (weight slot U): fragments of slab S + 1 are requested at the offset OFFN from the current bases
 #define S3_SLAB_STEP(S, U, OFFN)                                                                       \
   do {                                                                                                 \
-    a_load<NTC>(ringA[((U) + RD - 1) % RD], w, (S) + RD - 1);                                          \
+    a_load<NTC, NMAX>(R[((U) + RD - 1) % RD], w, (S) + RD - 1);                                        \
     b_ld<(OFFN)>(b[((U) + 1) & 1], bs);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U) % RD], b[(U) & 1]);                                       \
+    mm_slab<NTC, NMAX, false>(acc, R[(U) % RD], b[(U) & 1]);                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
     // (the layer's slab count is padded: P holds zero rows up to a multiple of 32 k, and the fragment reads of the
@@ -592,12 +601,14 @@ struct S3Consumer {
 
   __device__ __forceinline__ void run_block(int bi, int col0) {
     f32x16 acc[NMAX][2];
+    uint4 R[4][NMAX][3];           // weight-fragment ring of the layers >= 1 (layer 0 has its own)
     int boff = 0;
     const int pb = wave == 0 ? blk_no * 8 : 1 << 20;
     S3_STAMP(pb + 0);
     {
       const int lane = fresh_lane();
       layer0<N0>(acc, lane);
+      preloadA<N1>(R, 1, lane);
       S3_STAMP(pb + 1);
       // every MFMA wave has finished reading its input (and the previous block's epilogue patches in P): P is free
       cbar(ctl, phase, lane);
@@ -609,7 +620,9 @@ struct S3Consumer {
     }
     if (NL == 3) {
       const int lane = fresh_lane();
-      layerN<N1>(acc, 1, boff, lane);
+      layerN<N1>(acc, R, 1, boff, lane);
+      constexpr int NP2 = (N2 > 0) ? N2 : 1;
+      preloadA<NP2>(R, 2, lane);
       S3_STAMP(pb + 4);
       cbar(ctl, phase, lane);
       store_layer<N1>(acc, 1, lane);
@@ -627,7 +640,8 @@ struct S3Consumer {
       for (int pass = 0; pass < PASSES; ++pass) {
         const int lane = fresh_lane();
         const int tile_base = pass * S3_NWC * NLAST;
-        layerN<NLAST>(acc, NL - 1, boff, lane, tile_base);
+        layerN<NLAST>(acc, R, NL - 1, boff, lane, tile_base);
+        if (pass + 1 < PASSES) preloadA<NLAST>(R, NL - 1, lane, tile_base + S3_NWC * NLAST);   // under the pool below
 #pragma unroll
         for (int t = 0; t < NLAST; ++t) {
           const int mt = tile_base + wave + S3_NWC * t;
@@ -640,7 +654,7 @@ struct S3Consumer {
     }
     {
       const int lane = fresh_lane();
-      layerN<NLAST>(acc, NL - 1, boff, lane);
+      layerN<NLAST>(acc, R, NL - 1, boff, lane);
       S3_STAMP(pb + 6);
       cbar(ctl, phase, lane);              // P is dead: the SA epilogue parks its patches there
     }

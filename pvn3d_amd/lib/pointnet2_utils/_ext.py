@@ -265,6 +265,17 @@ def three_nn(unknowns, knows):
     return [dist2, idx]
 
 
+def three_nn_weights(dist2):
+    """dist2 (B,n,3) of three_nn -> the inverse-distance weights of PointnetFPModule.forward
+    (pointnet2_modules.py:184-186), same fp32 operation order, one launch."""
+    _chk(dist2, "dist2", torch.float32)
+    w = torch.empty_like(dist2)
+    with on_device(dist2.device):
+        check(lib.pvn3d_three_nn_weights(dist2.numel() // 3, dist2.data_ptr(), w.data_ptr(), _stream(dist2)),
+              "three_nn_weights")
+    return w
+
+
 def three_interpolate(points, idx, weight):
     """points (B,C,m), idx/weight (B,n,3) -> (B,C,n).  interpolate.cpp:42-68"""
     _chk(points, "points", torch.float32)

@@ -243,6 +243,10 @@ class PointnetFPModule(nn.Module):
     def neighbours(unknown, known):
         """three_nn + inverse-distance weights (reference :183-186); depends on xyz only."""
         with _stage("three_nn"):
+            if unknown.is_cuda and not torch.is_grad_enabled():
+                # inference: the same fp32 formula as one kernel on three_nn's squared distances
+                dist2, idx = _ext.three_nn(unknown, known)
+                return idx, _ext.three_nn_weights(dist2)
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)

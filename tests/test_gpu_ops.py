@@ -1119,3 +1119,17 @@ def test_split_bf16_fp_chain_matches_fp32_mfma(dev, c2, c1, mlp, n, m, b, pm_out
     assert outs["bf16x3"].shape == ref.shape == (b, mlp[-1], n)
     assert (outs["bf16x3"] - outs["fp32"]).abs().max().item() / scale < 2e-6
     assert (outs["bf16x3"] - ref).abs().max().item() / scale < 1e-4
+
+
+def test_three_nn_weights_kernel_matches_the_torch_formula(dev, ext):
+    """pvn3d_three_nn_weights: the inverse-distance weights of PointnetFPModule.forward (pointnet2_modules.py:184-186)
+    as one kernel, against the same fp32 formula written with torch ops."""
+    g = np.random.default_rng(5)
+    d2 = T((g.random((3, 1000, 3)) ** 2 * 0.01).astype(np.float32), dev)
+    d2[0, 0, 0] = 0.0                      # an unknown point that coincides with a known one
+    got = ext.three_nn_weights(d2)
+    dist = torch.sqrt(d2)
+    rec = 1.0 / (dist + 1e-8)
+    want = rec / torch.sum(rec, dim=2, keepdim=True)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-9)
+    assert abs(float(got[0, 0].sum()) - 1.0) < 1e-6 and float(got[0, 0, 0]) > 0.999
