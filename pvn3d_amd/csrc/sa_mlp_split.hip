@@ -195,26 +195,21 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<I
         }
       }
     } else {
-      // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order; two halves of
-      // four columns (12 rows in flight each: 24 at once made the 4-wave kernels spill)
+      // three_interpolate (pointnet2_utils.py:136-170): p0*w0 + p1*w1 + p2*w2, unfused, in this order.  All 24 row
+      // segments of the chunk are requested before the first is used: one round trip per chunk
       constexpr int K1 = IS_SA ? 0 : 1, K2 = IS_SA ? 0 : 2;
+      float4 p[8][IS_SA ? 1 : 3];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float4 p[4][IS_SA ? 1 : 3];
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < (IS_SA ? 1 : 3); ++k) p[i][k] = *reinterpret_cast<const float4*>(t + (size_t)lcx.id[i][k] * ld);
 #pragma unroll
-          for (int k = 0; k < (IS_SA ? 1 : 3); ++k)
-            p[i][k] = *reinterpret_cast<const float4*>(t + (size_t)lcx.id[4 * hh + i][k] * ld);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float w0 = lcx.w[4 * hh + i][0], w1 = lcx.w[4 * hh + i][K1], w2 = lcx.w[4 * hh + i][K2];
-          v[4 * hh + i].x = p[i][0].x * w0 + p[i][K1].x * w1 + p[i][K2].x * w2;
-          v[4 * hh + i].y = p[i][0].y * w0 + p[i][K1].y * w1 + p[i][K2].y * w2;
-          v[4 * hh + i].z = p[i][0].z * w0 + p[i][K1].z * w1 + p[i][K2].z * w2;
-          v[4 * hh + i].w = p[i][0].w * w0 + p[i][K1].w * w1 + p[i][K2].w * w2;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i) {
+        const float w0 = lcx.w[i][0], w1 = lcx.w[i][K1], w2 = lcx.w[i][K2];
+        v[i].x = p[i][0].x * w0 + p[i][K1].x * w1 + p[i][K2].x * w2;
+        v[i].y = p[i][0].y * w0 + p[i][K1].y * w1 + p[i][K2].y * w2;
+        v[i].z = p[i][0].z * w0 + p[i][K1].z * w1 + p[i][K2].z * w2;
+        v[i].w = p[i][0].w * w0 + p[i][K1].w * w1 + p[i][K2].w * w2;
       }
     }
 #pragma unroll
