@@ -224,29 +224,52 @@ struct MsAcc {
 };
 
 template <bool PK, bool FAST>
+__device__ __forceinline__ void ms_pair(MsAcc& A, const float4 a, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
+  if (PK) {
+    // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : (one subtract +) three FMAs
+    const ms_f2 e0 = FAST ? ms_splat(a.w) : ms_splat(a.w) - pcm;
+    const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), e0)));
+    const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    A.w += w;
+    A.x = ms_fma2(w, ms_splat(a.x), A.x);
+    A.y = ms_fma2(w, ms_splat(a.y), A.y);
+    A.z = ms_fma2(w, ms_splat(a.z), A.z);
+  } else {
+    const float e0 = FAST ? a.w : a.w - pcm.x;
+    const float e = fmaf(p2z.x, a.z, fmaf(p2y.x, a.y, fmaf(p2x.x, a.x, e0)));
+    const float w = __builtin_amdgcn_exp2f(e);
+    A.w.x += w;
+    A.x.x = fmaf(w, a.x, A.x.x);
+    A.y.x = fmaf(w, a.y, A.y.x);
+    A.z.x = fmaf(w, a.z, A.z.x);
+  }
+}
+
+// [q_begin, q_end) is a whole number of 4-point groups (the callers pad the chunk to a multiple of four).  The next
+// group is read from LDS before the current one is evaluated: when a launch has one wave per SIMD (a single frame's
+// fits, the tail of a heavy batch) nothing else hides the read's ~100 cycles, a third of a group's time.
+template <bool PK, bool FAST>
 __device__ __forceinline__ void ms_accumulate(MsAcc& A, const float4* __restrict__ sp, int q_begin, int q_end,
                                               ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
-#pragma unroll 4
-  for (int q = q_begin; q < q_end; ++q) {
-    const float4 a = sp[q];
-    if (PK) {
-      // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : (one subtract +) three FMAs
-      const ms_f2 e0 = FAST ? ms_splat(a.w) : ms_splat(a.w) - pcm;
-      const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), e0)));
-      const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-      A.w += w;
-      A.x = ms_fma2(w, ms_splat(a.x), A.x);
-      A.y = ms_fma2(w, ms_splat(a.y), A.y);
-      A.z = ms_fma2(w, ms_splat(a.z), A.z);
-    } else {
-      const float e0 = FAST ? a.w : a.w - pcm.x;
-      const float e = fmaf(p2z.x, a.z, fmaf(p2y.x, a.y, fmaf(p2x.x, a.x, e0)));
-      const float w = __builtin_amdgcn_exp2f(e);
-      A.w.x += w;
-      A.x.x = fmaf(w, a.x, A.x.x);
-      A.y.x = fmaf(w, a.y, A.y.x);
-      A.z.x = fmaf(w, a.z, A.z.x);
-    }
+  if (q_begin >= q_end) return;
+  float4 a0 = sp[q_begin], a1 = sp[q_begin + 1], a2 = sp[q_begin + 2], a3 = sp[q_begin + 3];
+  float4 b0, b1, b2, b3;
+  for (int q = q_begin; q < q_end; q += 8) {      // two register sets in turn: no copies
+    const int qb = min(q + 4, q_end - 4);         // the last group re-reads itself (unused)
+    b0 = sp[qb]; b1 = sp[qb + 1]; b2 = sp[qb + 2]; b3 = sp[qb + 3];
+    __builtin_amdgcn_sched_barrier(0);            // or the scheduler sinks the reads to the end of the block again
+    ms_pair<PK, FAST>(A, a0, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, a1, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, a2, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, a3, p2x, p2y, p2z, pcm);
+    if (q + 4 >= q_end) break;
+    const int qa = min(q + 8, q_end - 4);
+    a0 = sp[qa]; a1 = sp[qa + 1]; a2 = sp[qa + 2]; a3 = sp[qa + 3];
+    __builtin_amdgcn_sched_barrier(0);
+    ms_pair<PK, FAST>(A, b0, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, b1, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, b2, p2x, p2y, p2z, pcm);
+    ms_pair<PK, FAST>(A, b3, p2x, p2y, p2z, pcm);
   }
 }
 
@@ -823,13 +846,20 @@ __global__ __launch_bounds__(1024) void ms_classify_kernel(
 
 // ROWS_NC = false: rows = every point, columns = the non-core list; writes counts[i].
 // ROWS_NC = true : rows = the non-core list, columns = the core list; adds to counts[i].
-// grid (n_seg, ceil(max_cnt/256)), block 256
-template <bool ROWS_NC>
+// SPLIT = false: a workgroup owns 256 rows, every lane walks all columns.  grid (n_seg, ceil(max_cnt/256)).
+// SPLIT = true : a workgroup owns 64 rows and its four waves walk one quarter of every staged column chunk each,
+//                then add their partial counts through LDS (integers: any order is exact).  grid (n_seg,
+//                ceil(max_cnt/64)).  Used for the ROWS_NC launch: it has few rows (the non-core points) and many
+//                columns, so its duration was one lane's walk over all core points -- 217 us per 576-fit batch,
+//                33 us per single-frame batch, for 1 us of work per SIMD.
+template <bool ROWS_NC, bool SPLIT>
 __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
     const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
     float d2_max, int* __restrict__ counts) {
+  constexpr int LANES = SPLIT ? 64 : MS_THREADS;
   __shared__ float4 s_pts[MS_CHUNK];
+  __shared__ int s_cnt[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
   // grid (n_seg, tiles): the segment is the FAST grid dimension.  Most tiles of the non-core
   // launch are empty (few non-core rows); with the tile as the fast dimension the surviving
   // workgroups (tile 0/1 of every segment, linear ids 12*seg + {0,1}) all land on the same four
@@ -839,11 +869,12 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
   const int ncore = n_core[seg], nnc = n - ncore;
   const int n_rows = ROWS_NC ? nnc : n;
   const int n_cols = ROWS_NC ? ncore : nnc;
-  const int tile0 = blockIdx.y * MS_THREADS;
+  const int tile0 = blockIdx.y * LANES;
   if (tile0 >= n_rows) return;
   const int base = seg_off[seg];
   const int tid = threadIdx.x;
-  const int r = tile0 + tid;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = tile0 + (SPLIT ? (tid & 63) : tid);
   int i = -1;
   float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r < n_rows) {
@@ -857,12 +888,19 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
     __syncthreads();
     for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + cols[j0 + q]];
     __syncthreads();
-    for (int q = 0; q < cnt; ++q) {
+    const int qb = SPLIT ? wave * MS_QUARTER : 0, qe = SPLIT ? min(qb + MS_QUARTER, cnt) : cnt;
+    for (int q = qb; q < qe; ++q) {
       const float4 a = s_pts[q];
       const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
       count += (d2 <= d2_max) ? 1 : 0;
     }
+  }
+  if (SPLIT) {
+    if (wave > 0) s_cnt[wave - 1][tid & 63] = count;
+    __syncthreads();
+    if (wave > 0) return;
+    count += s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid];
   }
   if (i < 0) return;
   if (ROWS_NC) counts[base + i] += count;   // one thread per row, after the first launch: no race
@@ -1058,9 +1096,10 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
                        S.core_idx, S.nc_idx, S.n_core);
     const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
-    hipLaunchKernelGGL(ms_count_pruned_kernel<false>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+    const dim3 grid_ts(n_seg, pvn3d_ceil_div(max_cnt_host, 64));
+    hipLaunchKernelGGL((ms_count_pruned_kernel<false, false>), grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
                        S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL(ms_count_pruned_kernel<true>, grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+    hipLaunchKernelGGL((ms_count_pruned_kernel<true, true>), grid_ts, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
                        S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
     hipLaunchKernelGGL(ms_count_addcore_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, S.core_idx,
                        S.n_core, S.counts);

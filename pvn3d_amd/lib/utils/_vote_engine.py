@@ -110,8 +110,8 @@ def vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, v_first, 
     n_seg = n_inst * (n_kps + 1)
     if out is None:
         votes = torch.empty((n_seg * n_pts, 4), dtype=torch.float32, device=dev)
-        seg_off = torch.zeros((n_seg,), dtype=torch.int32, device=dev)
-        seg_cnt = torch.zeros((n_seg,), dtype=torch.int32, device=dev)
+        seg = torch.zeros((2, n_seg), dtype=torch.int32, device=dev)      # one fill; rows = offsets, counts
+        seg_off, seg_cnt = seg[0], seg[1]
     else:
         votes, seg_off, seg_cnt = out
     with on_device(dev):
@@ -162,16 +162,17 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
 
     pcld (F,N,3); mask (F,N) integer; ctr_of (F,1,N,3); pred_kp_of (F,K,N,3);
     mesh_kps (K+use_ctr,3) object-frame keypoints (+centre last).
-    Returns dict(poses (F,3,4) f64 cuda, cls_kps (F,K+1,3), iters (F,K+1), counts (F,K+1)).
+    Returns dict(poses (F,3,4) f64 cuda, cls_kps (F,K+1,3), iters (F,K+1), counts (F,K+1), unfinished_min 0-dim).
     async_limit = E: no host poll, at most E iterations per fit batch enqueued; `iters` < 0 marks fits that did not
-    finish (their poses are not final) -- the launch sequence is then fixed and capturable (GraphedFramePoses).
+    finish (their poses are not final; `unfinished_min` = iters.min() < 0 then) -- the launch sequence is then fixed
+    and capturable (GraphedFramePoses).
     """
     pcld, mask, ctr_of, pred_kp_of = _prep(pcld, mask, ctr_of, pred_kp_of)
     dev = pcld.device
     F, N = pcld.size(0), pcld.size(1)
     K = pred_kp_of.size(1)
-    inst_frame = torch.arange(F, dtype=torch.int32, device=dev)
-    inst_cls = torch.full((F,), int(cls_id), dtype=torch.int32, device=dev)
+    inst_frame = _device_const(("ramp", F), dev, lambda: torch.arange(F, dtype=torch.int32))
+    inst_cls = _device_const(("cls", F, int(cls_id)), dev, lambda: torch.full((F,), int(cls_id), dtype=torch.int32))
     if not use_ctr_clus_flter:
         votes, seg_off, seg_cnt = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame,
                                                inst_cls, 0, K + 1)
@@ -205,7 +206,7 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
     A = mesh_dev.to(torch.float32)[:npts].unsqueeze(0).expand(F, npts, 3).contiguous()
     B = cls_kps[:, :npts].contiguous()
     poses = best_fit_transform_batch(A, B, valid)
-    return dict(poses=poses, cls_kps=cls_kps, iters=iters.view(F, K + 1), counts=counts)
+    return dict(poses=poses, cls_kps=cls_kps, iters=iters.view(F, K + 1), counts=counts, unfinished_min=iters.min())
 
 
 def relabel_by_centre(pcld, ctr_of0, mask, ctrs, present, thr_lst):
@@ -234,14 +235,14 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
 
     mesh_kps_all (n_cls-1, K+1, 3): object-frame keypoints (+centre) per class id.
     Returns dict(poses (F,n_cls-1,3,4), present (F,n_cls-1) bool [original mask], cls_kps (F,n_cls-1,K+1,3),
-                 iters, new_mask).
+                 iters, unfinished_min, new_mask).
     """
     pcld, mask, ctr_of, pred_kp_of = _prep(pcld, mask, ctr_of, pred_kp_of)
     dev = pcld.device
     F, N = pcld.size(0), pcld.size(1)
     K = pred_kp_of.size(1)
     C = n_cls - 1
-    cls_ids = torch.arange(1, n_cls, device=dev, dtype=mask.dtype).view(1, C, 1)
+    cls_ids = _device_const(("cls_ids", C), dev, lambda: torch.arange(1, n_cls, dtype=torch.int32)).view(1, C, 1)
     present = (mask.unsqueeze(1) == cls_ids).any(dim=2)                        # (F,C)
     present0 = present          # pred_cls_ids of the reference come from the ORIGINAL mask (:49)
     # Only the (frame, class) pairs that occur get an instance slot: ONE small device->host copy per batch
@@ -249,73 +250,100 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     # slot instantiated the vote buffer alone is F*C*(K+1)*N*16 bytes (2.4 GB at 64 frames, 21 classes)
     # and every launch carries 21 - (objects in view) empty segments per frame.
     # A single frame (the reference's test_mini_batch_size = 1) instantiates all C class slots instead (40 MB of
-    # votes): no host round trip at all, the absent classes are empty segments.
-    if F == 1:
-        pf = torch.zeros(C, dtype=torch.long, device=dev)
-        pc = torch.arange(C, dtype=torch.long, device=dev)
+    # votes): no host round trip at all, the absent classes are empty segments, and -- the instance list being the
+    # class list -- none of the scatter / gather steps below (each one a launch, ~5 us of a ~0.8 ms call).
+    single = F == 1
+    if single:
+        inst_frame = _device_const(("inst_frame0", C), dev, lambda: torch.zeros(C, dtype=torch.int32))
+        inst_cls = _device_const(("inst_cls", C), dev, lambda: torch.arange(1, C + 1, dtype=torch.int32))
+        pf = pc = None
         n_inst = C
     else:
         pairs = torch.nonzero(present.cpu())                                    # (n_inst, 2) on the host
         n_inst = int(pairs.size(0))
-    poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
-    poses_full[:, :, 0, 0] = 1.0
-    poses_full[:, :, 1, 1] = 1.0
-    poses_full[:, :, 2, 2] = 1.0
-    kps_full = torch.zeros((F, C, K + 1, 3), dtype=torch.float32, device=dev)
-    iters_full = torch.zeros((F, C, K + 1), dtype=torch.int32, device=dev)
-    if n_inst == 0:
-        return dict(poses=poses_full, present=present0, present_new=present, cls_kps=kps_full, iters=iters_full,
-                    new_mask=mask)
-    if F != 1:
+        if n_inst == 0:
+            poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
+            poses_full[:, :, 0, 0] = 1.0
+            poses_full[:, :, 1, 1] = 1.0
+            poses_full[:, :, 2, 2] = 1.0
+            zi = torch.zeros((F, C, K + 1), dtype=torch.int32, device=dev)
+            return dict(poses=poses_full, present=present0, present_new=present,
+                        cls_kps=torch.zeros((F, C, K + 1, 3), dtype=torch.float32, device=dev), iters=zi,
+                        unfinished_min=zi.min(), new_mask=mask)
         pf = pairs[:, 0].to(device=dev, dtype=torch.long)
         pc = pairs[:, 1].to(device=dev, dtype=torch.long)
-    inst_frame = pf.to(torch.int32)
-    inst_cls = (pc + 1).to(torch.int32)
-    out = None
+        inst_frame = pf.to(torch.int32)
+        inst_cls = (pc + 1).to(torch.int32)
+    # a scalar-lane iteration kernel for the two centre batches of a single frame: at most N seeds in all, which
+    # leaves most SIMDs idle either way, and one seed per lane is the shorter dependent chain (identical bits)
+    ctr_kernel = "scalar" if single and DEFAULT_KERNEL is None else None
+
+    n_seg = n_inst * (K + 1)
+    votes = torch.empty((n_seg * N, 4), dtype=torch.float32, device=dev)
+    seg = torch.zeros((2, n_seg), dtype=torch.int32, device=dev)          # segment offsets, counts
+    out = (votes, seg[0], seg[1])
+
+    def seg_slices(lo, hi):
+        """(offsets, counts) of segments lo..hi-1 of every instance: one gather for both tables"""
+        x = seg.view(2, n_inst, K + 1)[:, :, lo:hi].contiguous().view(2, -1)
+        return x[0], x[1]
+
+    it0 = None
     if use_ctr_clus_flter:
-        out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
-        votes, seg_off, seg_cnt = out
-        so = seg_off.view(n_inst, K + 1)
-        sc = seg_cnt.view(n_inst, K + 1)
-        c0, _, it0 = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(), N,
-                                         radius, max_iter, poll_every=poll_every,
-                                         aligned32=(N % 32 == 0), enqueue_limit=async_limit)
+        vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
+        o_c, n_c = seg_slices(K, K + 1)
+        c0, _, it0 = meanshift_fit_batch(votes, o_c, n_c, N, radius, max_iter, poll_every=poll_every,
+                                         aligned32=(N % 32 == 0), enqueue_limit=async_limit, kernel=ctr_kernel)
         thr = _device_const(("ycb_thr", tuple(np.asarray(radius_lst, np.float64).tolist())), dev,
                             lambda: torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)))
-        ctrs = torch.zeros((F, C, 3), dtype=torch.float32, device=dev)
-        ctrs[pf, pc] = c0
+        if single:
+            ctrs = c0.view(1, C, 3)
+        else:
+            ctrs = torch.zeros((F, C, 3), dtype=torch.float32, device=dev)
+            ctrs[pf, pc] = c0
         mask, present = relabel_by_centre(pcld, ctr_of[:, 0], mask, ctrs, present, thr)
     # per-class centre fit on the (re-labelled) mask
-    out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
-    votes, seg_off, seg_cnt = out
-    so = seg_off.view(n_inst, K + 1)
-    sc = seg_cnt.view(n_inst, K + 1)
-    c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(), sc[:, K].contiguous(),
-                                                N, radius, max_iter, poll_every=poll_every,
-                                                aligned32=(N % 32 == 0), enqueue_limit=async_limit)
+    vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
+    o_c, n_c = seg_slices(K, K + 1)
+    c_ctr, labels, it_ctr = meanshift_fit_batch(votes, o_c, n_c, N, radius, max_iter, poll_every=poll_every,
+                                                aligned32=(N % 32 == 0), enqueue_limit=async_limit, kernel=ctr_kernel)
     sel = labels[K * N:] if use_ctr_clus_flter else None
     vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
                  sel_inst_stride=(K + 1) * N, out=out)
-    c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
-                                         sc[:, :K].contiguous().view(-1), N, radius, max_iter,
+    o_k, n_k = seg_slices(0, K)
+    c_kp, _, it_kp = meanshift_fit_batch(votes, o_k, n_k, N, radius, max_iter,
                                          poll_every=poll_every, aligned32=(N % 32 == 0), enqueue_limit=async_limit)
     cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
-    iters = torch.cat([it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)], 1)
-    if use_ctr_clus_flter:
-        # an unfinished filter-pass fit (async_limit only) taints everything after it: carry its sign
-        iters = torch.where((it0 < 0).view(n_inst, 1).expand_as(iters), -iters.abs(), iters)
+    # iteration counts of every fit batch of the call in one table: columns 0..K are `iters`; the filter pass (whose
+    # centres only re-label the mask) is the last column.  Under async_limit a negative count marks a fit that did not
+    # finish; `unfinished_min` < 0 says that some fit of the call -- the filter pass included, which taints everything
+    # after it -- did not, i.e. the call's results are not final.
+    cols = [it_kp.view(n_inst, K), it_ctr.view(n_inst, 1)] + ([it0.view(n_inst, 1)] if it0 is not None else [])
+    all_it = torch.cat(cols, 1)
+    iters = all_it[:, :K + 1]
+    unfinished_min = all_it.min()
     npts = K + 1 if use_ctr else K
     mesh_dev = mesh_kps_all if mesh_kps_all.device == dev else _device_const(
         ("mesh_all", mesh_kps_all.detach().to(torch.float32).numpy().tobytes()), dev, lambda: mesh_kps_all.to(torch.float32))
-    A = mesh_dev.to(torch.float32)[pc, :npts].contiguous()
+    mesh_dev = mesh_dev.to(torch.float32)
+    A = (mesh_dev[:, :npts] if single else mesh_dev[pc, :npts]).contiguous()
     B = cls_kps[:, :npts].contiguous()
-    valid = present[pf, pc].to(torch.int32).contiguous()
+    valid = (present[0] if single else present[pf, pc]).to(torch.int32).contiguous()
     poses = best_fit_transform_batch(A, B, valid)
-    poses_full[pf, pc] = poses
-    kps_full[pf, pc] = cls_kps
-    iters_full[pf, pc] = iters.to(torch.int32)
+    if single:
+        poses_full, kps_full, iters_full = poses.unsqueeze(0), cls_kps.unsqueeze(0), iters.unsqueeze(0)
+    else:
+        poses_full = torch.zeros((F, C, 3, 4), dtype=torch.float64, device=dev)
+        poses_full[:, :, 0, 0] = 1.0
+        poses_full[:, :, 1, 1] = 1.0
+        poses_full[:, :, 2, 2] = 1.0
+        kps_full = torch.zeros((F, C, K + 1, 3), dtype=torch.float32, device=dev)
+        iters_full = torch.zeros((F, C, K + 1), dtype=torch.int32, device=dev)
+        poses_full[pf, pc] = poses
+        kps_full[pf, pc] = cls_kps
+        iters_full[pf, pc] = iters.to(torch.int32)
     return dict(poses=poses_full, present=present0, present_new=present, cls_kps=kps_full, iters=iters_full,
-                new_mask=mask)
+                unfinished_min=unfinished_min, new_mask=mask)
 
 
 def add_adds_batch(pts_list, pred_RT, gt_RT):

@@ -79,7 +79,7 @@ class GraphedFramePoses(object):
         res = g(pcld, mask, ctr_of, pred_kp_of)                                      # the engine dict, like cal_batch_poses
 
     The captured sequence enqueues at most `async_limit` MeanShift iterations per fit batch and no host poll; fits that
-    have not finished by then mark themselves (iters < 0).  `__call__` reads that flag together with the results and,
+    have not finished by then mark themselves (iters < 0, summarised in `unfinished_min`).  `__call__` reads that flag together with the results and,
     if any fit is unfinished (heavy-tailed votes), repeats the frame through the ordinary polled call -- same results
     either way.  kind: "lm" (cal_batch_poses_lm, needs obj_id) or "ycb" (cal_batch_poses)."""
 
@@ -102,7 +102,7 @@ class GraphedFramePoses(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.res = self._run(async_limit)
-            self.unfinished = (self.res["iters"] < 0).any()
+            self.unfinished = self.res["unfinished_min"]      # < 0: some fit batch of the call hit the limit
 
     def _run(self, limit, poll_every=8):
         p, m, c, k = self.static
@@ -117,7 +117,7 @@ class GraphedFramePoses(object):
                 raise RuntimeError("GraphedFramePoses was captured for shape %s" % (tuple(dst.shape),))
             dst.copy_(src)
         self.graph.replay()
-        if bool(self.unfinished.item()):                  # the one host read of the call (results are read next anyway)
+        if int(self.unfinished.item()) < 0:               # the one host read of the call (results are read next anyway)
             self.fallbacks += 1
             return self._run(None)
         return self.res
