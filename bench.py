@@ -206,8 +206,9 @@ def make_net(dev):
     return Pointnet2MSG(input_channels=6).to(dev).eval()
 
 
-def run_net(net, inp, timer):
-    """(A) the fused Pointnet2MSG forward; `timer` (if enabled) brackets its stages."""
+def run_net(net, inp, timer, geometry=None):
+    """(A) the fused Pointnet2MSG forward; `timer` (if enabled) brackets its stages.  geometry: a handle from
+    net.geometry_ahead(inp["pc"]) -- this batch's xyz-only work, enqueued one step earlier."""
     from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm
     from pvn3d_amd.lib import pointnet2_msg
     pm.STAGE_HOOK = (lambda name: _HookStage(timer, name)) if timer.enabled else None
@@ -217,7 +218,7 @@ def run_net(net, inp, timer):
     try:
         with torch.no_grad():
             t = timer.start("pointnet2_msg_total")
-            out = net(inp["pc"])
+            out = net(inp["pc"], geometry=geometry)
             timer.stop(t)
     finally:
         pm.STAGE_HOOK = None
@@ -614,6 +615,9 @@ def main():
     ap.add_argument("--ms-kernel", default=None,
                     help="MeanShift iteration kernel for the timed steps, e.g. 'sgpr+cap1024' (LDS-free, 1024 waves); "
                          "default: the library's choice")
+    ap.add_argument("--geometry-ahead", action="store_true",
+                    help="enqueue the NEXT step's xyz-only work (FPS, ball query, three_nn) beside this step's MLPs "
+                         "(measured: 14.10 -> 13.98 ms per step; off by default, every step then stands alone)")
     ap.add_argument("--ops-only", action="store_true",
                     help="island (A) = bare SA/FP op chain with synthetic features (no MLP GEMMs)")
     ap.add_argument("--strong", action="store_true",
@@ -685,6 +689,16 @@ def main():
     def gather_results(res):
         return gather_step_results(res, frames_local, frames_total, world, args.strong)
 
+    # --geometry-ahead: software pipelining across steps (a pipelined evaluator has the next batch's cloud while it works
+    # on this one): the xyz-only work of step i+1's batch is enqueued on the network's geometry stream BEFORE step i's
+    # MLP kernels, which then start at once on the handle that step i-1 left.  Every step still enqueues exactly one
+    # geometry pass, one MLP pass and one vote pass.  It buys 1 % (tools/step_timeline.py: inside a step the MLP stream
+    # waits 5.7 ms for level 0's FPS and then runs 5 ms alone, but the MeanShift iterations that run meanwhile are
+    # VALU-throughput-bound on the whole chip -- moving the MLPs beside them only makes both slower), so the default
+    # keeps every step self-contained.
+    geo_ahead = args.geometry_ahead and net is not None and not args.serial
+    geo_next = [None]
+
     def step(timer):
         if args.serial:
             keep = island_a(timer)
@@ -692,7 +706,13 @@ def main():
             return keep, res, gather_results(res)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            keep = island_a(timer_off)
+            if geo_ahead:
+                with torch.no_grad():
+                    geo = geo_next[0] if geo_next[0] is not None else net.geometry_ahead(inp["pc"])
+                    geo_next[0] = net.geometry_ahead(inp["pc"])
+                keep = run_net(net, inp, timer_off, geometry=geo)
+            else:
+                keep = island_a(timer_off)
         res = run_postproc(inp, timer_off, args.poll_every)
         torch.cuda.current_stream(dev).wait_stream(side)
         return keep, res, gather_results(res)
