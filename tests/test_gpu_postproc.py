@@ -110,6 +110,43 @@ def test_kabsch_vs_reference_golden_and_icp_test(dev, golden):
         assert np.allclose(Tg[:, :3].T, R, atol=0.06)
 
 
+@pytest.mark.parametrize("npts", [1, 3, 9, 63, 64, 65, 200])
+def test_kabsch_point_set_sizes_against_the_oracle(dev, npts):
+    """csrc/pose.hip fetches a point set 64 points (one per lane) at a time: sizes around that boundary, a batch of
+    sets with some marked invalid (identity, pvn3d_eval_utils.py:172-173), against the restated
+    basic_utils.best_fit_transform (oracle/torch_port.py; fp64 LAPACK SVD) -- and R orthonormal to 1e-12, which the
+    kernel's 4-ulp Jacobi stop test has to deliver."""
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    from oracle import torch_port
+    rng = np.random.default_rng(100 + npts)
+    S = 11
+    A = rng.normal(size=(S, npts, 3)).astype(np.float32) * 0.1
+    B = np.empty_like(A)
+    for s_ in range(S):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        B[s_] = (A[s_] @ R.T + rng.normal(size=3) + rng.normal(size=(npts, 3)) * 1e-3).astype(np.float32)
+    valid = np.ones(S, np.int32); valid[[2, 7]] = 0
+    Tg = eng.best_fit_transform_batch(T(A, dev), T(B, dev), torch.from_numpy(valid).to(dev)).cpu().numpy()
+    assert Tg.shape == (S, 3, 4) and Tg.dtype == np.float64
+    for s_ in range(S):
+        if not valid[s_]:
+            assert np.array_equal(Tg[s_], np.eye(4)[:3])
+            continue
+        R = Tg[s_][:, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1.0) < 1e-12
+        if npts >= 3:         # fewer points: the rotation is not unique, only the residual is
+            # the reference's call (float32 arrays: float32 means, sgesdd) within the pose tolerance; the same
+            # restatement on float64 copies of the inputs (dgesdd) much closer -- the kernel works in fp64
+            assert np.abs(Tg[s_] - torch_port.best_fit_transform_np(A[s_], B[s_])).max() < TOL
+            assert np.abs(Tg[s_] - torch_port.best_fit_transform_np(A[s_].astype(np.float64), B[s_].astype(np.float64))).max() < 1e-9
+        resid = np.abs(A[s_].astype(np.float64) @ R.T + Tg[s_][:, 3] - B[s_]).max()
+        assert resid < (1e-2 if npts >= 3 else 1e-5)          # 1 mm noise on B; a single point is met exactly
+
+
 def test_frames_vs_reference_driven_golden(dev, golden):
     from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
     z = golden("frames_ref.npz")
