@@ -40,7 +40,8 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* iters;           // [n_seg]
   unsigned long long* best;  // [n_seg]  (count << 32) | ~index
   int* active;          // [2]
-  int* counts;          // [total]  neighbour count of every point (pruned count, below)
+  int* counts;          // [total]  pruned neighbour count of every point (core rows: without their n_core core
+                        //          neighbours, which ms_argmax_kernel adds)
   int* core_idx;        // [total]  per segment: indices of "core" points, ascending
   int* nc_idx;          // [total]  per segment: indices of the other points, ascending
   int* n_core;          // [n_seg]
@@ -65,7 +66,6 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_c1 = take(sizeof(float4) * (size_t)total);
   const size_t o_aidx = take(sizeof(int) * (size_t)total);
   const size_t o_apts = take(sizeof(float4) * ((size_t)total + 32));
-  const size_t o_small = off;  // everything from here is zero-filled per call
   const size_t o_ms = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_cm = take(sizeof(unsigned) * (size_t)n_seg * (max_iter + 2));
   const size_t o_it = take(sizeof(int) * (size_t)n_seg);
@@ -100,12 +100,15 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->win_pos = (float4*)(base + o_wpos);
     st->win_it = (int*)(base + o_wit);
   }
-  (void)o_small;
   return off;
 }
 
 // ---------------------------------------------------------------------------------------
 // vote assembly + order-preserving compaction.  grid: (n_inst, n_kps+1), block 1024.
+// Every wave owns one contiguous range of the cloud (ceil(n_pts / 16) rounded up to whole 64-point steps): it counts
+// its matches, the sixteen counts are prefixed once, and the wave walks its range again writing at its own running
+// offset -- three workgroup barriers per pass instead of four per 1024 points (48 at N = 12 288: the kernel is one
+// workgroup's latency, 22-29 us of a 0.7 ms single-frame call).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void vote_compact_kernel(
     int n_pts, int n_kps, int v_first, const float* __restrict__ pcld,
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
     const int* __restrict__ inst_cls, const uint8_t* __restrict__ sel, long long sel_inst_stride,
     float4* __restrict__ votes, int* __restrict__ seg_off, int* __restrict__ seg_cnt) {
   __shared__ int s_w1[16], s_w2[16];
-  __shared__ int s_run1, s_run2, s_nsel;
+  __shared__ int s_nsel;
   const int inst = blockIdx.x, v = v_first + blockIdx.y;
   const int f = inst_frame[inst], cls = inst_cls[inst];
   const int seg = inst * (n_kps + 1) + v;
@@ -124,61 +127,69 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
                                : ctr_of + (size_t)f * n_pts * 3;
   const uint8_t* S = sel ? sel + (size_t)inst * sel_inst_stride : nullptr;
   float4* out = votes + (size_t)seg * n_pts;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) { s_run1 = 0; s_run2 = 0; s_nsel = 0; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int span = ((n_pts + 15) / 16 + 63) & ~63;          // points per wave
+  const int p_lo = w * span, p_hi = min(n_pts, p_lo + span);
+  if (tid == 0) s_nsel = 0;
+  // pass 1: rows (mask matches) per wave
+  int c1 = 0;
+  for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+    const int p = p0 + lane;
+    c1 += __builtin_popcountll(__ballot(p < p_hi && M[p] == cls));
+  }
+  if (lane == 0) s_w1[w] = c1;
   __syncthreads();
+  int row0 = 0, total = 0;
+  for (int i = 0; i < 16; ++i) { const int c = s_w1[i]; row0 += i < w ? c : 0; total += c; }
   // row filter: S[r] refers to the r-th row of the mask-compacted sequence (the labels of an
   // earlier fit on the same instance).  "if ctr_labels.sum() < 1: ctr_labels[0] = 1"
   // (pvn3d_eval_utils.py:86-87,178-179): with no selected row, row 0 is kept.
   bool force_row0 = false;
+  int pos0 = row0, kept = total;
   if (S) {
     int mine = 0;
-    int total_rows = 0;
-    for (int p = tid; p < n_pts; p += 1024) total_rows += (M[p] == cls) ? 1 : 0;
-    // rows are [0, total); count selected among them
-    // (a block-wide sum of total_rows first, then of the selected flags)
-    for (int o = 32; o >= 1; o >>= 1) total_rows += __shfl_xor(total_rows, o, 64);
-    if (lane == 0) s_w1[w] = total_rows;
-    __syncthreads();
-    int total = 0;
-    for (int i = 0; i < 16; ++i) total += s_w1[i];
     for (int r = tid; r < total; r += 1024) mine += S[r] ? 1 : 0;
     if (mine) atomicAdd(&s_nsel, mine);
     __syncthreads();
     force_row0 = (s_nsel == 0);
+    // pass 2: kept rows per wave
+    int c2 = 0, row = row0;
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+      const int p = p0 + lane;
+      const bool m1 = p < p_hi && M[p] == cls;
+      const unsigned long long bal1 = __ballot(m1);
+      const int r = row + pvn3d_mbcnt(bal1);
+      const bool keep = m1 && (S[r] != 0 || (force_row0 && r == 0));
+      c2 += __builtin_popcountll(__ballot(keep));
+      row += __builtin_popcountll(bal1);
+    }
+    if (lane == 0) s_w2[w] = c2;
     __syncthreads();
+    pos0 = 0; kept = 0;
+    for (int i = 0; i < 16; ++i) { const int c = s_w2[i]; pos0 += i < w ? c : 0; kept += c; }
   }
-  for (int p0 = 0; p0 < n_pts; p0 += 1024) {
-    const int p = p0 + tid;
-    const bool m1 = (p < n_pts) && (M[p] == cls);
+  // pass 3: write
+  int row = row0, pos = pos0;
+  for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+    const int p = p0 + lane;
+    const bool m1 = p < p_hi && M[p] == cls;
     const unsigned long long bal1 = __ballot(m1);
-    if (lane == 0) s_w1[w] = __builtin_popcountll(bal1);
-    __syncthreads();
-    int row = s_run1 + pvn3d_mbcnt(bal1);
-    for (int i = 0; i < w; ++i) row += s_w1[i];
     bool keep = m1;
-    if (S && m1) keep = S[row] != 0 || (force_row0 && row == 0);
+    if (S && m1) {
+      const int r = row + pvn3d_mbcnt(bal1);
+      keep = S[r] != 0 || (force_row0 && r == 0);
+    }
     const unsigned long long bal2 = __ballot(keep);
-    if (lane == 0) s_w2[w] = __builtin_popcountll(bal2);
-    __syncthreads();
-    if (keep) {
-      int pos = s_run2 + pvn3d_mbcnt(bal2);
-      for (int i = 0; i < w; ++i) pos += s_w2[i];
-      out[pos] = make_float4(P[p * 3 + 0] - O[p * 3 + 0], P[p * 3 + 1] - O[p * 3 + 1],
-                             P[p * 3 + 2] - O[p * 3 + 2], 0.f);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int t1 = 0, t2 = 0;
-      for (int i = 0; i < 16; ++i) { t1 += s_w1[i]; t2 += s_w2[i]; }
-      s_run1 += t1;
-      s_run2 += t2;
-    }
-    __syncthreads();
+    if (keep)
+      out[pos + pvn3d_mbcnt(bal2)] = make_float4(P[p * 3 + 0] - O[p * 3 + 0], P[p * 3 + 1] - O[p * 3 + 1],
+                                                 P[p * 3 + 2] - O[p * 3 + 2], 0.f);
+    row += __builtin_popcountll(bal1);
+    pos += __builtin_popcountll(bal2);
   }
   if (tid == 0) {
     seg_off[seg] = seg * n_pts;
-    seg_cnt[seg] = s_run2;
+    seg_cnt[seg] = kept;
   }
 }
 
@@ -786,13 +797,25 @@ __global__ void ms_poll_kernel(const unsigned* __restrict__ maxshift,
 // Worst case (no core points) = the full n^2 scan; typical votes: ~10 % of it.
 // ---------------------------------------------------------------------------------------
 // grid (n_seg), block 1024
+// It is also the first kernel of a fit batch and zeroes its segment's per-call state (a zero-fill pass of its own was
+// one more launch per batch -- a tenth of a single-frame call).
 __global__ __launch_bounds__(1024) void ms_classify_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
-    float r_core, int* __restrict__ core_idx, int* __restrict__ nc_idx, int* __restrict__ n_core) {
+    float r_core, int* __restrict__ core_idx, int* __restrict__ nc_idx, int* __restrict__ n_core, MsState S,
+    int ms_stride) {
   __shared__ double s_sum[3][16];
   __shared__ float s_mean[3];
   __shared__ int s_wc[16], s_run[2];
   const int seg = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < ms_stride; i += 1024) {
+    S.maxshift[(size_t)seg * ms_stride + i] = 0u;
+    S.cmmax[(size_t)seg * ms_stride + i] = 0u;
+  }
+  if (tid == 0) {
+    S.iters[seg] = 0; S.best[seg] = 0ULL; S.frozen_cm[seg] = 0u; S.act_cnt[seg] = 0; S.act_form[seg] = 0;
+    S.win_pos[seg] = make_float4(0.f, 0.f, 0.f, 0.f); S.win_it[seg] = 0;
+    if (seg == 0) { S.active[0] = 0; S.active[1] = 0; }
+  }
   const int n = seg_cnt[seg];
   if (n <= 0) { if (tid == 0) n_core[seg] = 0; return; }
   const int base = seg_off[seg];
@@ -907,22 +930,13 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
   else counts[base + i] = count;
 }
 
-// counts[i] += n_core for the core rows (every core point is within bw of every core point).
-// grid (ceil(max_cnt/256), n_seg), block 256
-__global__ __launch_bounds__(MS_THREADS) void ms_count_addcore_kernel(
-    const int* __restrict__ seg_off, const int* __restrict__ core_idx, const int* __restrict__ n_core,
-    int* __restrict__ counts) {
-  const int seg = blockIdx.y;
-  const int ncore = n_core[seg];
-  const int r = blockIdx.x * MS_THREADS + threadIdx.x;
-  if (r >= ncore) return;
-  const int base = seg_off[seg];
-  counts[base + core_idx[base + r]] += ncore;
-}
-
-// arg-max of the counts with the reference's first-maximum rule.  grid as above.
+// arg-max of the neighbour counts with the reference's first-maximum rule.  grid (ceil(max_cnt/256), n_seg), block 256.
+// The rows are walked list by list (core list, then the others): a core row's count is its stored count (hits among
+// the non-core columns) + n_core -- every core point is within bw of every core point -- added here instead of in a
+// pass of its own; the key carries ~index, so the walk order does not matter.
 __global__ __launch_bounds__(MS_THREADS) void ms_argmax_kernel(
     const int* __restrict__ seg_off, const int* __restrict__ seg_cnt, const int* __restrict__ counts,
+    const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
     unsigned long long* __restrict__ best) {
   __shared__ unsigned long long s_red[MS_THREADS / 64];
   const int seg = blockIdx.y;
@@ -930,10 +944,15 @@ __global__ __launch_bounds__(MS_THREADS) void ms_argmax_kernel(
   const int tile0 = blockIdx.x * MS_THREADS;
   if (tile0 >= n) return;
   const int base = seg_off[seg];
+  const int ncore = n_core[seg];
   const int tid = threadIdx.x;
-  const int i = tile0 + tid;
+  const int r = tile0 + tid;
   unsigned long long key = 0ULL;
-  if (i < n) key = ((unsigned long long)(unsigned)counts[base + i] << 32) | (unsigned long long)(~(unsigned)i);
+  if (r < n) {
+    const int i = r < ncore ? core_idx[base + r] : nc_idx[base + r - ncore];
+    const int c = counts[base + i] + (r < ncore ? ncore : 0);
+    key = ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(~(unsigned)i);
+  }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const unsigned lo = __shfl_xor((unsigned)key, o, 64);
@@ -1046,14 +1065,11 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   hipStream_t st = (hipStream_t)stream;
   MsState S;
   ms_layout(n_seg, total, max_iter, (char*)workspace, &S);
-  const size_t small_bytes =
-      ((char*)workspace + pvn3d_meanshift_workspace_bytes(n_seg, total, max_iter)) -
-      (char*)S.maxshift;
-  // zero the per-call state with a kernel of this library, not hipMemsetAsync: inside a captured HIP graph
-  // (GraphedFramePoses) the runtime's memset node was observed to land out of order with the kernels around it
-  // (random memory faults from a zeroed-too-late n_core / counts), a kernel node is an ordinary link of the chain
-  pvn3d_fill_u32(S.maxshift, 0u, small_bytes / 4, st);
-  PVN3D_LAUNCH_CHECK();
+  // The per-call state (stop-rule tables, winner records, seed lists' headers) is zeroed by the batch's first kernel,
+  // ms_classify_kernel -- not by hipMemsetAsync: inside a captured HIP graph (GraphedFramePoses) the runtime's memset
+  // node was observed to land out of order with the kernels around it (random memory faults from a zeroed-too-late
+  // n_core / counts); a kernel is an ordinary link of the chain.  counts / core_idx / nc_idx / act_idx need no zeroing
+  // (every entry that is read has been written by this call).
 
   const float thresh = (float)((double)bandwidth * 1e-3);  // meanshift_pytorch.py:21
   const float kappa = sqrtf(0.5f * 1.44269504088896341f) / bandwidth;
@@ -1094,17 +1110,15 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   {
     const float r_core = 0.499f * bandwidth;
     hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
-                       S.core_idx, S.nc_idx, S.n_core);
+                       S.core_idx, S.nc_idx, S.n_core, S, max_iter + 2);
     const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
     const dim3 grid_ts(n_seg, pvn3d_ceil_div(max_cnt_host, 64));
     hipLaunchKernelGGL((ms_count_pruned_kernel<false, false>), grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
                        S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
     hipLaunchKernelGGL((ms_count_pruned_kernel<true, true>), grid_ts, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
                        S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL(ms_count_addcore_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, S.core_idx,
-                       S.n_core, S.counts);
     hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts,
-                       S.best);
+                       S.core_idx, S.nc_idx, S.n_core, S.best);
   }
   PVN3D_LAUNCH_CHECK();
   const int stop_on_win = (flags & PVN3D_MS_NO_WINNER_STOP) ? 0 : 1;
@@ -1146,7 +1160,8 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     // duration is ~1.2 us per still-running fit + 7 us whatever the number of busy workgroups (measured; a
     // 16-wave workgroup shape and batched prologue loads changed nothing), so the long tail of a heavy-tailed
     // batch stays (iterations) x (that floor).
-    if (!(flags & PVN3D_MS_NO_EARLY_OUT) && t >= 5 && (t & 3) == 1 && t <= max_iter) {
+    // (a fixed sequence of at most 8 iterations -- the single-frame graph -- is over before a list pays for itself)
+    if (!(flags & PVN3D_MS_NO_EARLY_OUT) && t >= 5 && (t & 3) == 1 && t <= max_iter && iter_limit > 8) {
       hipLaunchKernelGGL(ms_compact_kernel, dim3(n_seg), dim3(1024), 0, st, seg_off, seg_cnt, cout, S.maxshift,
                          S.cmmax, S.frozen_cm, t, max_iter, thresh, S.act_cnt, S.act_form, S.act_idx, S.win_it,
                          stop_on_win);
