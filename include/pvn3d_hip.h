@@ -232,6 +232,27 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
                               const float* const* bias_padded, float* out, int out_point_major, int ld_out,
                               void* stream);
 
+/* Layer-by-layer split-bf16 SharedMLP for chains whose hidden layer is too wide for the fused kernel (FP levels 2-3 of
+ * PVN3D's backbone, lib/pvn3d.py:114-118; the module code is pointnet2_modules.py:188-206) -- csrc/split_gemm.hip.
+ * "s16" layout of a matrix [rows][K]: rows x slabs (= 16 k each) x 3 pieces x 16 bf16, i.e. entry (r, k, piece) at
+ * byte ((r * slabs + k / 16) * 3 + piece) * 32 + 2 * (k % 16); piece 0 + piece 1 + piece 2 == the fp32 value
+ * (activations: truncation split, exact; weights: round-to-nearest pieces, |rest| <= 2^-26 |w|).
+ *   pvn3d_split_rows: fp32 rows [rows][ld_src] (channels [0, c)) -> s16 [rows][slabs], channels >= c zero.
+ *   pvn3d_split_gemm: out[p][o] = act( sum_k W[o][k] X[p][k]  (+ sum_t weight[p][t] * z[frame(p) * z_rows_per_frame +
+ *                     idx[p][t]][o], frame(p) = p / z_points_per_frame, when z != NULL: three_interpolate of an fp32
+ *                     table, pointnet2_utils.py:136-170)  (+ bias_padded[o]) ), act = relu or identity;
+ *       x_s16 [n_points][slabs], w_s16 [roundup128(n_out)][slabs] with zero rows beyond n_out; slabs even;
+ *       results as fp32 rows out_f32 [n_points][ld_out] (channels < n_out) and / or as s16 rows out_s16
+ *       [n_points][slabs_out] (every channel < 16 * slabs_out <= roundup128(n_out) is written; channels >= n_out hold
+ *       act(z-term + bias pad) -- exact zeros when z's and bias's pad columns are zero).
+ * The chain H = relu(Wb.skip + interp(Wa.known) + b1), Y = relu(W2.H + b2) equals the reference's
+ * conv([interp(known); skip]) -> ... by linearity of the interpolation; the fp32 rounding sequence differs (1e-6). */
+int pvn3d_split_rows(long long rows, int c, const float* src, int ld_src, void* dst_s16, int slabs, void* stream);
+int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* x_s16, const void* w_s16,
+                     const float* bias_padded, int relu, const float* z, int ldz, int z_points_per_frame,
+                     int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
+                     void* out_s16, int slabs_out, void* stream);
+
 /* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */
 int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out, int ld_out,
                                void* stream);

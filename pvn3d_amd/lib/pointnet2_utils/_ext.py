@@ -453,6 +453,38 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
     return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
 
 
+# Wide two-layer FP chains (hidden layer >= 256 channels: 64 columns of it do not fit one CU's LDS as three bf16 pieces)
+# run layer by layer on the split-bf16 GEMM of csrc/split_gemm.hip instead of the fused fp32-MFMA chain.
+FP_LAYERWISE_SPLIT = True
+
+
+def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out):
+    """H = relu(Wb.skip + interp(Wa.known) + b1); out = relu(W2.H + b2) -- the FP module's
+    conv([interp(known); skip]) -> bn -> relu -> conv -> bn -> relu (pointnet2_modules.py:188-206) with the first
+    conv pulled through the (linear) interpolation, so that it runs over the m known points.  Three launches of
+    pvn3d_split_gemm + two row splits; every intermediate is a torch allocation (caching allocator)."""
+    dev = kf.device
+    w = packed.s16(C2)
+    n1p = w["b1"].numel()
+    st = _stream(kf)
+    P, Pk = B * n, B * m
+    xk = torch.empty((Pk * w["s_a"] * 96,), dtype=torch.uint8, device=dev)
+    xu = torch.empty((P * w["s_b"] * 96,), dtype=torch.uint8, device=dev)
+    z = torch.empty((Pk, n1p), dtype=torch.float32, device=dev)
+    h = torch.empty((P * w["s_h"] * 96,), dtype=torch.uint8, device=dev)
+    with on_device(dev):
+        check(lib.pvn3d_split_rows(Pk, C2, kf.data_ptr(), ld_k, xk.data_ptr(), w["s_a"], st), "split_rows")
+        check(lib.pvn3d_split_rows(P, C1, uf.data_ptr(), ld_u, xu.data_ptr(), w["s_b"], st), "split_rows")
+        # Z over all n1p columns: the pad columns are computed zeros (zero weight rows), the gather below reads them
+        check(lib.pvn3d_split_gemm(Pk, n1p, w["s_a"], xk.data_ptr(), w["wa"].data_ptr(), None, 0, None, 0, 0, 0, None,
+                                   None, z.data_ptr(), n1p, None, 0, st), "split_gemm")
+        check(lib.pvn3d_split_gemm(P, w["n1"], w["s_b"], xu.data_ptr(), w["wb"].data_ptr(), w["b1"].data_ptr(), 1,
+                                   z.data_ptr(), n1p, n, m, idx.data_ptr(), weight.data_ptr(), None, 0, h.data_ptr(),
+                                   w["s_h"], st), "split_gemm")
+        check(lib.pvn3d_split_gemm(P, w["n2"], w["s_h"], h.data_ptr(), w["w2"].data_ptr(), w["b2"].data_ptr(), 1,
+                                   None, 0, 0, 0, None, None, out.data_ptr(), ld_out, None, 0, st), "split_gemm")
+
+
 def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_out=False):
     """Fused three_interpolate ++ unknow_feats -> SharedMLP (BN folded, fp32 MFMA), inference
     only.  known_feats (B, C2, m), unknow_feats (B, C1, n) in any layout (see _point_major).
@@ -493,6 +525,11 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                                                 packed.b_c, out.data_ptr(), 1 if point_major_out else 0, ld_out,
                                                 _stream(known_feats)), "fp_interp_mlp_split")
         return out[:, :, :M].transpose(1, 2) if point_major_out else out
+    if (_fused_mlp.MLP_ARITH == "bf16x3" and FP_LAYERWISE_SPLIT and point_major_out and packed.n_layers == 2 and C1 > 0
+            and min(packed.dims[1], packed.dims[2]) >= 256 and B * n >= 4096
+            and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and ld_u % 4 == 0 and uf.data_ptr() % 16 == 0):
+        _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out)
+        return out[:, :, :M].transpose(1, 2)
     with on_device(known_feats.device):
         check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                       uf.data_ptr() if uf is not None else None, ld_u,

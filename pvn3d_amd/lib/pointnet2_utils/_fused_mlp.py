@@ -48,6 +48,28 @@ class PackedMLP(object):
         self._folded = folded      # [(W' (M, K) fp32 in the kernels' layer-0 channel order)]: source of the split packing
         self._split = None
 
+    def s16(self, c_first):
+        """Two-layer chain for csrc/split_gemm.hip, built on first use: layer 0 split at input channel `c_first`
+        (W = [Wa | Wb]: interpolated channels | skip channels), every matrix in the s16 layout.
+        -> dict(wa, wb, w2 int16 buffers, b1, b2 fp32 biases padded to 128, n1, n2, s_a, s_b, s_h slab counts)."""
+        cache = getattr(self, "_s16", None)
+        if cache is not None and cache[0] == c_first:
+            return cache[1]
+        assert self.n_layers == 2
+        (W1, W2) = self._folded
+        n1, n2 = W1.shape[0], W2.shape[0]
+        s_a, s_b, s_h = _slabs(c_first), _slabs(W1.shape[1] - c_first), _slabs(n1)
+
+        def pad_bias(b, n):
+            out = torch.zeros(((n + 127) // 128) * 128, dtype=torch.float32, device=b.device)
+            out[:n] = b[:n]
+            return out
+        d = dict(wa=_pack_weight_s16(W1[:, :c_first], s_a), wb=_pack_weight_s16(W1[:, c_first:], s_b),
+                 w2=_pack_weight_s16(W2, s_h), b1=pad_bias(self.b[0], n1), b2=pad_bias(self.b[1], n2),
+                 n1=n1, n2=n2, s_a=s_a, s_b=s_b, s_h=s_h)
+        self._s16 = (c_first, d)
+        return d
+
     def split(self):
         """-> ctypes array of the split-bf16 weight buffers (csrc/sa_mlp_split.hip), built on first use."""
         if self._split is None:
@@ -73,6 +95,28 @@ def _pack_weight_split(W):
     # (piece, mt, r, s, half, j) -> (s, mt, piece, half, r, j)
     out = pieces.view(3, MT, 32, S, 2, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
     return out.view(torch.int16).view(S, MT, 3, 64, 8)
+
+
+def _slabs(k):
+    """16-k slabs of a contraction of k channels, rounded up to whole 32-k chunks"""
+    return ((k + 31) // 32) * 2
+
+
+def _pack_weight_s16(W, slabs):
+    """W (M, K) float32 -> int16 [roundup128(M)][slabs][3 pieces][16]: the s16 layout of include/pvn3d_hip.h, pieces
+    rounded to nearest (hi = bf16(W), mid = bf16(W - hi), lo = bf16(W - hi - mid)), zero outside M x K."""
+    M, K = W.shape
+    Mp = ((M + 127) // 128) * 128
+    assert K <= 16 * slabs
+    Wp = torch.zeros((Mp, slabs * 16), dtype=torch.float32, device=W.device)
+    Wp[:M, :K] = W
+    hi = Wp.to(torch.bfloat16)
+    r1 = Wp - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    pieces = torch.stack([hi, mid, lo], 0)                       # (3, Mp, slabs*16)
+    out = pieces.view(3, Mp, slabs, 16).permute(1, 2, 0, 3).contiguous()
+    return out.view(torch.int16)
 
 
 def _pack_weight(W):

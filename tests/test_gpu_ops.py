@@ -1121,6 +1121,108 @@ def test_split_bf16_fp_chain_matches_fp32_mfma(dev, c2, c1, mlp, n, m, b, pm_out
     assert (outs["bf16x3"] - ref).abs().max().item() / scale < 1e-4
 
 
+@pytest.mark.parametrize("c2,c1,mlp,n,m,b", [
+    (512, 256, [768, 512, 512], 1024, 512, 64),          # FP level 2 of the backbone (lib/pvn3d.py:116), all 64 frames:
+                                                          # the size at which a gather interleaved with stores went wrong
+    (1024, 512, [1536, 512, 512], 512, 128, 16),         # FP level 3
+    (200, 70, [270, 300, 260], 1100, 90, 24),            # ragged widths, point count not a multiple of 128
+])
+def test_layerwise_split_fp_chain_against_fp64_and_fp32_chain(dev, c2, c1, mlp, n, m, b):
+    """csrc/split_gemm.hip: wide two-layer FP chains as three split-bf16 GEMM launches, the first conv pulled through
+    the interpolation (H = relu(Wb.skip + interp(Wa.known) + b1), pointnet2_modules.py:188-206 regrouped) -- against a
+    float64 evaluation of the reference's formula (2e-5 of the output scale, like the fused chains) and against the
+    fused fp32-MFMA chain; two runs return identical bits."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp, _ext
+    torch.manual_seed(11)
+    fp = pm.PointnetFPModule(mlp=list(mlp)).to(dev).eval()
+    _randomize_bn(fp)
+    fp._point_major_out = True
+    unknown = T(clouds(61, b, n, 0.1), dev)
+    known = unknown[:, :m].contiguous()
+    kf = torch.randn(b, m, c2, device=dev).transpose(1, 2)
+    # a strided view of a wider point-major buffer (row stride a multiple of 4 floats, as the fused modules hand over)
+    uf = torch.randn(b, n, (c1 + 7) // 4 * 4, device=dev)[:, :, :c1].transpose(1, 2)
+    calls = []
+    orig = _ext._fp_layerwise_split
+    _ext._fp_layerwise_split = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            nb = fp.neighbours(unknown, known)
+            got = fp(unknown, known, uf, kf, neighbours=nb).clone()
+            again = fp(unknown, known, uf, kf, neighbours=nb).clone()
+            _fused_mlp.MLP_ARITH = "fp32"
+            chain = fp(unknown, known, uf, kf, neighbours=nb).clone()
+    finally:
+        _fused_mlp.MLP_ARITH = "bf16x3"
+        _ext._fp_layerwise_split = orig
+    assert len(calls) == 2                                   # the layer-wise path really ran (and not under "fp32")
+    assert torch.equal(got, again)
+    idx, wgt = nb
+    packed = _fused_mlp.pack_shared_mlp(fp.mlp)
+    W1, W2 = [w.double() for w in packed._folded]
+    b1, b2 = packed.b[0][:mlp[1]].double(), packed.b[1][:mlp[2]].double()
+    bi = torch.arange(b, device=dev)[:, None, None]
+    interp = (kf.transpose(1, 2).double()[bi, idx.long()] * wgt.double()[..., None]).sum(2)
+    x = torch.cat([interp, uf.transpose(1, 2).double()], 2)
+    want = torch.relu(torch.relu(x @ W1.T + b1) @ W2.T + b2).transpose(1, 2)
+    scale = max(1.0, want.abs().max().item())
+    e_lw, e_chain = (got.double() - want).abs().max().item() / scale, (chain.double() - want).abs().max().item() / scale
+    print("FP chain %s: max err / scale vs fp64: layer-wise split %.2e, fused fp32 %.2e" % (mlp, e_lw, e_chain))
+    assert got.shape == (b, mlp[-1], n) and e_lw < 2e-5 and e_chain < 2e-5
+
+
+def test_split_gemm_c_abi(dev):
+    """pvn3d_split_rows / pvn3d_split_gemm through the C-ABI: the s16 rows carry the fp32 values exactly, a GEMM's
+    fp32 and s16 outputs agree exactly with each other and to fp32 accuracy with float64, pad channels are zeros, the
+    gathered-add epilogue equals three_interpolate of the table; bad arguments come back as an error code."""
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp as fm
+    st = torch.cuda.current_stream(dev).cuda_stream
+    torch.manual_seed(3)
+
+    def s16_to_float(buf, rows, S):
+        v = buf.view(torch.int16).view(rows, S, 3, 16).to(torch.int32) << 16
+        return v.view(torch.float32).double().sum(2).reshape(rows, S * 16)
+
+    for (P, K, N) in ((300, 72, 200), (1000, 512, 384)):
+        X = torch.randn(P, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        bias = torch.randn(N, device=dev)
+        S, S_out = fm._slabs(K), fm._slabs(N)
+        xs = torch.empty(P * S * 96, dtype=torch.uint8, device=dev)
+        assert lib.pvn3d_split_rows(P, K, X.data_ptr(), K, xs.data_ptr(), S, st) == 0
+        back = s16_to_float(xs, P, S)
+        assert bool((back[:, :K] == X.double()).all()) and bool((back[:, K:] == 0).all())
+        ws = fm._pack_weight_s16(W, S)
+        Np = ws.size(0)
+        bp = torch.zeros(Np, device=dev); bp[:N] = bias
+        out = torch.full((P, Np), float("nan"), device=dev)
+        outs = torch.empty(P * S_out * 96, dtype=torch.uint8, device=dev)
+        assert lib.pvn3d_split_gemm(P, N, S, xs.data_ptr(), ws.data_ptr(), bp.data_ptr(), 1, None, 0, 0, 0, None, None,
+                                    out.data_ptr(), Np, outs.data_ptr(), S_out, st) == 0
+        want = torch.relu(X.double() @ W.double().T + bias.double())
+        got = out[:, :N].double()
+        assert (got - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+        dec = s16_to_float(outs, P, S_out)
+        assert bool((dec[:, :N] == got).all()) and bool((dec[:, N:] == 0).all())
+        B, n, m = 4, P // 4, 37
+        Z = torch.randn(B * m, Np, device=dev)
+        idx = torch.randint(0, m, (P, 3), device=dev, dtype=torch.int32)
+        wg = torch.rand(P, 3, device=dev)
+        out2 = torch.empty((P, Np), device=dev)
+        assert lib.pvn3d_split_gemm(B * n, N, S, xs.data_ptr(), ws.data_ptr(), None, 0, Z.data_ptr(), Np, n, m,
+                                    idx.data_ptr(), wg.data_ptr(), out2.data_ptr(), Np, None, 0, st) == 0
+        f = (torch.arange(B * n, device=dev) // n).long()
+        zg = sum(Z.double()[f * m + idx[:B * n, t].long()] * wg[:B * n, t:t + 1].double() for t in range(3))
+        want2 = X[:B * n].double() @ W.double().T + zg[:, :N]
+        assert (out2[:B * n, :N].double() - want2).abs().max().item() < 1e-5 * max(1.0, want2.abs().max().item())
+        # odd slab count, no output at all, a z table narrower than the channel tiles
+        assert lib.pvn3d_split_gemm(P, N, 3, xs.data_ptr(), ws.data_ptr(), None, 0, None, 0, 0, 0, None, None, out.data_ptr(), Np, None, 0, st) != 0
+        assert lib.pvn3d_split_gemm(P, N, S, xs.data_ptr(), ws.data_ptr(), None, 0, None, 0, 0, 0, None, None, None, 0, None, 0, st) != 0
+        assert lib.pvn3d_split_gemm(P, N, S, xs.data_ptr(), ws.data_ptr(), None, 0, Z.data_ptr(), N - 4 if N % 128 else 64, n, m,
+                                    idx.data_ptr(), wg.data_ptr(), out2.data_ptr(), Np, None, 0, st) != 0
+
+
 def test_three_nn_weights_kernel_matches_the_torch_formula(dev, ext):
     """pvn3d_three_nn_weights: the inverse-distance weights of PointnetFPModule.forward (pointnet2_modules.py:184-186)
     as one kernel, against the same fp32 formula written with torch ops."""

@@ -49,7 +49,9 @@ def main():
         cases.append(("SA3 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz3, feats, geometry=geo),
                       2.0 * (515 * mlp[1] + mlp[1] * mlp[2] + mlp[2] * mlp[3]) * 128 * ns * B))
     # FP level 0: 12288 <- 2048, C2 = 256, C1 = 6; FP level 1: 2048 <- 1024, 512 + 96
-    for name, n, m, c2, c1, mlp in (("FP0", 12288, 2048, 256, 6, [262, 128, 128]), ("FP1", 2048, 1024, 512, 96, [608, 256, 256])):
+    # FP level 2: 1024 <- 512, 512 + 256; FP level 3: 512 <- 128, 1024 + 512 (layer-by-layer split GEMM, csrc/split_gemm.hip)
+    for name, n, m, c2, c1, mlp in (("FP0", 12288, 2048, 256, 6, [262, 128, 128]), ("FP1", 2048, 1024, 512, 96, [608, 256, 256]),
+                                    ("FP2", 1024, 512, 512, 256, [768, 512, 512]), ("FP3", 512, 128, 1024, 512, [1536, 512, 512])):
         fp = pm.PointnetFPModule(mlp=mlp).to(dev).eval()
         fp._point_major_out = True
         unk = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=n, n_obj=256)["pcld"] for i in range(B)])).to(dev)
@@ -58,6 +60,13 @@ def main():
         uf = torch.randn(B, n, c1 + 3, device=dev)[:, :, 3:].transpose(1, 2) if c1 < 32 else torch.randn(B, n, c1, device=dev).transpose(1, 2)
         with torch.no_grad():
             nb = fp.neighbours(unk, kn)
+            if name in ("FP2", "FP3"):
+                _fused_mlp.MLP_ARITH = "fp32"
+                want = fp(unk, kn, uf, kf, neighbours=nb)
+                _fused_mlp.MLP_ARITH = "bf16x3"
+                got = fp(unk, kn, uf, kf, neighbours=nb)
+                print(name, "split GEMM vs fp32 chain: max |diff| / scale = %.2e" % (
+                    float((got - want).abs().max()) / max(1.0, float(want.abs().max()))))
         cases.append((name, lambda fp=fp, unk=unk, kn=kn, uf=uf, kf=kf, nb=nb: fp(unk, kn, uf, kf, neighbours=nb),
                       2.0 * sum(a * b for a, b in zip(mlp[:-1], mlp[1:])) * n * B))
     for name, fn, flops in cases:
