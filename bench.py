@@ -243,21 +243,28 @@ def mlp_flops_per_frame(net, scale):
     return sa, fp
 
 
-def mlp_chain_table(net, scale):
+def mlp_chain_table(net, scale, frames=64):
     """One row per fused chain of the forward: stage, widths, algorithmic flops per frame and the matrix pipe it runs on
-    (asked of the library: pvn3d_mlp_split_ok is the dispatch test of lib/pointnet2_utils/_ext.py)."""
+    (asked of the library: pvn3d_mlp_split_ok / fp_layerwise_shape_ok are the dispatch tests of
+    lib/pointnet2_utils/_ext.py; `frames` = frames per forward, part of the second test)."""
     from pvn3d_amd._lib import lib
     from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
     import ctypes
     rows = []
 
     def add(stage, name, dims, cols, is_sa, c_a, c_b, ns):
+        from pvn3d_amd.lib.pointnet2_utils import _ext
         arr = (ctypes.c_int * len(dims))(*dims)
         split = _fused_mlp.MLP_ARITH == "bf16x3" and bool(lib.pvn3d_mlp_split_ok(1 if is_sa else 0, c_a, c_b, ns, len(dims) - 1, arr))
+        # FP levels 2-3: layer by layer on the split GEMM (csrc/split_gemm.hip).  flops_per_frame stays the
+        # reference's formulation (conv over [interp; skip] on the unknown points); the launches execute fewer (the
+        # first conv's interpolated half runs over the known points)
+        layerwise = not split and not is_sa and _ext.fp_layerwise_shape_ok(cols * frames, c_b, dims)
         fl = 2.0 * sum(a * b for a, b in zip(dims[:-1], dims[1:])) * cols
-        rows.append(dict(stage=stage, chain=name, dims=list(dims), flops_per_frame=fl,
-                         arithmetic="bf16x3 split on v_mfma_f32_32x32x16_bf16" if split else "fp32 on v_mfma_f32_32x32x2_f32",
-                         peak_tflops=PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_FP32_MFMA_TFLOPS))
+        kind = ("bf16x3 split on v_mfma_f32_32x32x16_bf16" + (", layer by layer" if layerwise else "")) if (split or layerwise) \
+            else "fp32 on v_mfma_f32_32x32x2_f32"
+        rows.append(dict(stage=stage, chain=name, dims=list(dims), flops_per_frame=fl, arithmetic=kind,
+                         peak_tflops=PEAK_BF16_MFMA_TFLOPS / 6.0 if (split or layerwise) else PEAK_FP32_MFMA_TFLOPS))
 
     for li, mod in enumerate(net.SA_modules):
         m = int(mod.npoint * scale)
@@ -805,7 +812,7 @@ def main():
             # can deliver at most 2500 / 6 = 416.7 TFLOP/s.  A stage mixes both: its `peak` is the rate at which the
             # stage's chains would finish with every pipe at its dense peak (sum of flops / sum of ideal times), its
             # `frac` = ideal time / measured time -- never a ratio against a peak the launch does not run on.
-            chains = mlp_chain_table(net, scale)
+            chains = mlp_chain_table(net, scale, F)
             for name, fl in (("sa_mlp", sa_fl), ("fp_mlp", fp_fl)):
                 if per_step.get(name, 0) > 0:
                     mine = [c for c in chains if c["stage"] == name]

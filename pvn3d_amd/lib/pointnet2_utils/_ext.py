@@ -458,6 +458,14 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
 FP_LAYERWISE_SPLIT = True
 
 
+def fp_layerwise_shape_ok(n_points, c1, dims):
+    """The shape half of the dispatch test of fp_interp_mlp (bench.py prices a chain by the pipe it runs on): a
+    two-layer chain with skip features whose layers are at least 256 wide, on at least 4096 points, that the fused
+    split kernel does not take."""
+    return (_fused_mlp.MLP_ARITH == "bf16x3" and FP_LAYERWISE_SPLIT and len(dims) == 3 and c1 > 0
+            and min(dims[1], dims[2]) >= 256 and n_points >= 4096)
+
+
 def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out):
     """H = relu(Wb.skip + interp(Wa.known) + b1); out = relu(W2.H + b2) -- the FP module's
     conv([interp(known); skip]) -> bn -> relu -> conv -> bn -> relu (pointnet2_modules.py:188-206) with the first
@@ -525,8 +533,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                                                 packed.b_c, out.data_ptr(), 1 if point_major_out else 0, ld_out,
                                                 _stream(known_feats)), "fp_interp_mlp_split")
         return out[:, :, :M].transpose(1, 2) if point_major_out else out
-    if (_fused_mlp.MLP_ARITH == "bf16x3" and FP_LAYERWISE_SPLIT and point_major_out and packed.n_layers == 2 and C1 > 0
-            and min(packed.dims[1], packed.dims[2]) >= 256 and B * n >= 4096
+    if (point_major_out and fp_layerwise_shape_ok(B * n, C1, packed.dims)
             and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and ld_u % 4 == 0 and uf.data_ptr() % 16 == 0):
         _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out)
         return out[:, :, :M].transpose(1, 2)

@@ -108,13 +108,17 @@ def test_train_step_algorithmic_work():
 
 
 def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
-    """bench.mlp_chain_table asks the library's own dispatch test (pvn3d_mlp_split_ok, host-only): SA levels 2-3 and FP
-    levels 0-1 of the backbone run the split-bf16 kernels (peak 2500 / 6 TFLOP/s of algorithmic fp32 flops), the narrow SA
-    levels 0-1 and the 512-wide FP levels 2-3 the fp32-MFMA kernels (157.3)."""
+    """bench.mlp_chain_table asks the library's own dispatch tests (pvn3d_mlp_split_ok, _ext.fp_layerwise_shape_ok;
+    host-only): SA levels 2-3 and FP levels 0-1 of the backbone run the fused split-bf16 kernels, the 512-wide FP levels
+    2-3 the layer-by-layer split GEMM when the forward has enough points (64 frames: yes, one frame: no) -- peak
+    2500 / 6 TFLOP/s of algorithmic fp32 flops -- and the narrow SA levels 0-1 the fp32-MFMA kernels (157.3)."""
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
-    rows = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0)
+    rows = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=64)
     split = {r["chain"] for r in rows if r["arithmetic"].startswith("bf16x3")}
-    assert split == {"SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1"}
+    assert split == {"SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1", "FP2", "FP3"}
+    assert {r["chain"] for r in rows if r["arithmetic"].endswith("layer by layer")} == {"FP2", "FP3"}
+    one = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=1)
+    assert {r["chain"] for r in one if r["arithmetic"].startswith("bf16x3")} == {"SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1"}
     assert len(rows) == 12
     for r in rows:
         assert abs(r["peak_tflops"] - (2500.0 / 6.0 if r["chain"] in split else 157.3)) < 1e-9

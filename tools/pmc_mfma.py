@@ -45,17 +45,27 @@ def main():
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900)
     ctr = collections.OrderedDict()
     for r in csv.DictReader(open(glob.glob(out + "/**/*counter_collection.csv", recursive=True)[0])):
-        if "mlp_chain" in r["Kernel_Name"]:
+        if "mlp_chain" in r["Kernel_Name"] or "sg_gemm" in r["Kernel_Name"]:
             ctr.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     dur = {}
     for r in csv.DictReader(open(glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0])):
-        if "mlp_chain" in r["Kernel_Name"]:
+        if "mlp_chain" in r["Kernel_Name"] or "sg_gemm" in r["Kernel_Name"]:
             dur[int(r["Dispatch_Id"])] = ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                           r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0])
-    ids = sorted(ctr)[-12:]           # the last fused forward of the run
+    # the last fused forward of the run: one launch per chain, except that a chain run layer by layer on the split GEMM
+    # (csrc/split_gemm.hip: FP levels 2-3) is three consecutive sg_gemm launches -- their counters and times are summed
+    all_ids = sorted(ctr)
+    groups, i = [], len(all_ids)
+    for _ in CHAINS:
+        if "sg_gemm" in dur[all_ids[i - 1]][1]:
+            groups.append(all_ids[i - 3:i]); i -= 3
+        else:
+            groups.append(all_ids[i - 1:i]); i -= 1
+    groups.reverse()
     rows, tot_fl, tot_us, tot_busy, tot_act = [], 0.0, 0.0, 0.0, 0.0
-    for (name, dims, cols), d in zip(CHAINS, ids):
-        c, (us, kern) = ctr[d], dur[d]
+    for (name, dims, cols), g in zip(CHAINS, groups):
+        c = {k: sum(ctr[d][k] for d in g) for k in ctr[g[0]]}
+        us, kern = sum(dur[d][0] for d in g), dur[g[0]][1] + (" x%d" % len(g) if len(g) > 1 else "")
         fl = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * cols * FRAMES
         gui = c["GRBM_GUI_ACTIVE"] / N_XCD
         clk = gui / (us * 1e3)
@@ -63,7 +73,7 @@ def main():
         # v_mfma_f32_32x32x16_bf16 (1024 flop/clk/SIMD); the fp32 chains v_mfma_f32_32x32x2_f32 (64 flop/clk/SIMD).
         # `tflops` stays the algorithmic (fp32-equivalent) rate; `tflops_peak_at_clock` is what the pipe the launch runs
         # on could deliver of THAT quantity at the measured clock (bf16 peak / 6 for the split chains).
-        split = "s3_kernel" in kern
+        split = "s3_kernel" in kern or "sg_gemm" in kern
         per_clk = 1024.0 / 6.0 if split else 64.0
         rows.append(dict(chain=name, kernel=kern, arithmetic="bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split
                          else "fp32 MFMA", duration_us=us, effective_clock_ghz=clk,

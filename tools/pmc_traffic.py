@@ -19,6 +19,7 @@ STAGE_OF = [("mlp_chain_s3_kernel<true", "sa_mlp"), ("mlp_chain_s3_kernel<false"
             ("mlp_chain_mid_kernel<true", "sa_mlp"), ("mlp_chain_cols_kernel<true", "sa_mlp"),
             ("mlp_chain_kernel<false", "fp_mlp"), ("mlp_chain_wide_kernel<false", "fp_mlp"),
             ("mlp_chain_mid_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
+            ("sg_gemm_kernel", "fp_mlp"), ("sg_split_rows_kernel", "fp_mlp"),
             ("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
             ("ball_query", "ball_query"), ("grid_build", "ball_query"), ("three_nn", "three_nn"),
             ("fps_", "fps"), ("gather_points", "gather"), ("ms_", "vote_cluster_pose"),
