@@ -453,6 +453,57 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
     return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
 
 
+# Set-abstraction levels whose first layer is narrower than their input (SA levels 2-3 of the backbone: 256 -> 128,
+# 512 -> 256): the feature half of the first conv is applied per SOURCE point before the gather -- one split-bf16 GEMM
+# for all scales of the level (csrc/split_gemm.hip) -- and the fused chain gathers M0 instead of C channels per sample
+# and contracts [I | Wx] over them: grouping is linear, so conv([xyz_rel; f[idx]]) = Wx.xyz_rel + (Wf.f)[idx].
+SA_PRECONTRACT = True
+
+
+def sa_precontract(features, packs, nsamples):
+    """-> [(features' (B, M0, n) view, PackedMLP') per scale] or None when the level does not qualify.
+    pointnet2_modules.py:57-69 / pointnet2_utils.py:293-330 regrouped; the fp32 rounding sequence of layer 0 changes
+    (the identity part of the new layer 0 is exact), accuracy against fp64 does not (tests/test_gpu_ops.py)."""
+    if not (SA_PRECONTRACT and _fused_mlp.MLP_ARITH == "bf16x3") or features is None or not features.is_cuda:
+        return None
+    B, C, n = features.shape
+    if C < 128 or B * n < 4096 or features.dtype != torch.float32:
+        return None
+    pres = []
+    for p, ns in zip(packs, nsamples):
+        if p.n_layers != 3 or p.dims[0] != C + 3 or p.dims[1] % 32 != 0 or 2 * p.dims[1] > C:
+            return None
+        pre, wf = p.precontracted(C)
+        if not lib.pvn3d_mlp_split_ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c):
+            return None
+        pres.append((pre, wf))
+    feat, ld = _point_major(features)
+    if ld % 4 != 0 or feat.data_ptr() % 16 != 0:
+        return None
+    key = tuple(id(p) for p in packs)
+    cache = getattr(packs[0], "_pre_cat", None)
+    if cache is None or cache[0] != key:
+        wcat = torch.cat([wf for _, wf in pres], 0)
+        cache = (key, _fused_mlp._pack_weight_s16(wcat, _fused_mlp._slabs(C)), list(packs))
+        packs[0]._pre_cat = cache
+    ws = cache[1]
+    S, n_out = _fused_mlp._slabs(C), ws.size(0)
+    dev = features.device
+    st = _stream(features)
+    xs = torch.empty((B * n * S * 96,), dtype=torch.uint8, device=dev)
+    y = torch.empty((B, n, n_out), dtype=torch.float32, device=dev)
+    with on_device(dev):
+        check(lib.pvn3d_split_rows(B * n, C, feat.data_ptr(), ld, xs.data_ptr(), S, st), "split_rows")
+        check(lib.pvn3d_split_gemm(B * n, n_out, S, xs.data_ptr(), ws.data_ptr(), None, 0, None, 0, 0, 0, None, None,
+                                   y.data_ptr(), n_out, None, 0, st), "split_gemm")
+    out, off = [], 0
+    for pre, _ in pres:
+        m0 = pre.dims[1]
+        out.append((y[:, :, off:off + m0].transpose(1, 2), pre))
+        off += m0
+    return out
+
+
 # Wide two-layer FP chains (hidden layer >= 256 channels: 64 columns of it do not fit one CU's LDS as three bf16 pieces)
 # run layer by layer on the split-bf16 GEMM of csrc/split_gemm.hip instead of the fused fp32-MFMA chain.
 FP_LAYERWISE_SPLIT = True

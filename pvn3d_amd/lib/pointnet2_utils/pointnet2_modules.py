@@ -180,7 +180,13 @@ class _PointnetSAModuleBase(nn.Module):
             return None                                     # slices would not be contiguous channels
         total = offs[-1]
         out_pm = torch.empty((xyz.size(0), new_xyz.size(1), total), dtype=torch.float32, device=xyz.device)
-        for grouper, mlp, packed, idx, off in zip(self.groupers, self.mlps, packs, idxs, offs):
+        # first conv's feature half per source point, ahead of the gather (wide levels, full batches: _ext.sa_precontract)
+        pre = None
+        cols_min = min(xyz.size(0) * new_xyz.size(1) * g.nsample for g in self.groupers)
+        if features is not None and all(g.use_xyz for g in self.groupers) and cols_min >= 64 * _small_batch.MAX_FUSED_WGS:
+            with _stage("sa_mlp"):
+                pre = _ext.sa_precontract(features, packs, [g.nsample for g in self.groupers])
+        for si, (grouper, mlp, packed, idx, off) in enumerate(zip(self.groupers, self.mlps, packs, idxs, offs)):
             if idx is None:
                 with _stage("ball_query"):
                     idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
@@ -193,6 +199,8 @@ class _PointnetSAModuleBase(nn.Module):
                 if small is not None:
                     _small_batch.sa_scale(xyz, new_xyz, features, idx, grouper.use_xyz or features is None, small, out_pm,
                                           off)
+                elif pre is not None:
+                    _ext.sa_mlp_maxpool(xyz, new_xyz, pre[si][0], idx, True, pre[si][1], out_pm, off)
                 else:
                     _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
         out = out_pm[:, :, :sum(widths)].transpose(1, 2)

@@ -1049,14 +1049,26 @@ def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns,
     # features as a transposed view of a point-major buffer (what Pointnet2MSG hands over between levels)
     feats = T(np.ascontiguousarray(np.transpose(feats_np, (0, 2, 1))), dev).transpose(1, 2)
     outs = {}
-    for arith in ("bf16x3", "fp32"):
-        _fused_mlp.MLP_ARITH = arith
-        try:
-            with torch.no_grad():
-                new_xyz, out = sa(T(xyz_np, dev), feats)
-        finally:
-            _fused_mlp.MLP_ARITH = "bf16x3"
-        outs[arith] = out.cpu().double().numpy()
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    taken = []
+    orig_pre = _ext.sa_precontract
+    _ext.sa_precontract = lambda *a, **k: (lambda r: (taken.append(r is not None), r)[1])(orig_pre(*a, **k))
+    try:
+        for arith in ("bf16x3", "fp32"):
+            _fused_mlp.MLP_ARITH = arith
+            try:
+                with torch.no_grad():
+                    new_xyz, out = sa(T(xyz_np, dev), feats)
+            finally:
+                _fused_mlp.MLP_ARITH = "bf16x3"
+            outs[arith] = out.cpu().double().numpy()
+    finally:
+        _ext.sa_precontract = orig_pre
+    # wide levels on full batches run their first conv's feature half per source point, ahead of the gather
+    # (_ext.sa_precontract: SA levels 2-3 of the backbone); everything else gathers the raw features
+    want_pre = (c_in >= 128 and b * n >= 4096 and 2 * mlp[1] <= c_in and mlp[1] % 32 == 0
+                and b * npoint * ns >= 64 * 128)
+    assert any(taken) == want_pre and taken.count(True) <= 1, (taken, want_pre)      # never under "fp32"
     packed = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
     from pvn3d_amd._lib import lib
     assert lib.pvn3d_mlp_split_ok(1, c_in, 0, ns, packed.n_layers, packed.dims_c) == 1      # the split kernel really ran

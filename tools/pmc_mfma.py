@@ -56,16 +56,21 @@ def main():
     # (csrc/split_gemm.hip: FP levels 2-3) is three consecutive sg_gemm launches -- their counters and times are summed
     all_ids = sorted(ctr)
     groups, i = [], len(all_ids)
-    for _ in CHAINS:
-        if "sg_gemm" in dur[all_ids[i - 1]][1]:
+    for name, _, _ in reversed(CHAINS):
+        if "sg_gemm" in dur[all_ids[i - 1]][1]:                  # an FP level on the split GEMM: Z, H, Y
             groups.append(all_ids[i - 3:i]); i -= 3
+        elif name.endswith("ns16") and i >= 2 and "sg_gemm" in dur[all_ids[i - 2]][1]:
+            # an SA level whose first conv's feature half runs ahead of the gather (_ext.sa_precontract): that GEMM
+            # serves both scales of the level and is booked on the first
+            groups.append(all_ids[i - 2:i]); i -= 2
         else:
             groups.append(all_ids[i - 1:i]); i -= 1
     groups.reverse()
     rows, tot_fl, tot_us, tot_busy, tot_act = [], 0.0, 0.0, 0.0, 0.0
     for (name, dims, cols), g in zip(CHAINS, groups):
         c = {k: sum(ctr[d][k] for d in g) for k in ctr[g[0]]}
-        us, kern = sum(dur[d][0] for d in g), dur[g[0]][1] + (" x%d" % len(g) if len(g) > 1 else "")
+        us = sum(dur[d][0] for d in g)
+        kern = dur[g[-1]][1] + (" x%d" % len(g) if len(g) == 3 else " + sg_gemm (feature half of layer 0)" if len(g) == 2 else "")
         fl = 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * cols * FRAMES
         gui = c["GRBM_GUI_ACTIVE"] / N_XCD
         clk = gui / (us * 1e3)
