@@ -507,6 +507,7 @@ def sa_precontract(features, packs, nsamples):
 # Wide two-layer FP chains (hidden layer >= 256 channels: 64 columns of it do not fit one CU's LDS as three bf16 pieces)
 # run layer by layer on the split-bf16 GEMM of csrc/split_gemm.hip instead of the fused fp32-MFMA chain.
 FP_LAYERWISE_SPLIT = True
+FP_PRECONTRACT = True
 
 
 def fp_layerwise_shape_ok(n_points, c1, dims):
@@ -574,6 +575,25 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     else:
         ld_out = 0
         out = torch.empty((B, M, n), dtype=torch.float32, device=known_feats.device)
+    # FP level 0 (12288 <- 2048 points, 256 -> 128): the interpolated half of the first conv per KNOWN point ahead of the
+    # interpolation (six times fewer points, and the chain then gathers 128 instead of 256 channels per neighbour) --
+    # the regrouping of _fp_layerwise_split with the fused kernel behind it
+    if (FP_PRECONTRACT and _fused_mlp.MLP_ARITH == "bf16x3" and packed.n_layers == 2 and C1 > 0 and C2 >= 256
+            and packed.dims[1] % 32 == 0 and 2 * packed.dims[1] <= C2 and n >= 4 * m and B * m >= 4096
+            and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0):
+        pre, wa = packed.precontracted(C2)
+        if lib.pvn3d_mlp_split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
+            cache = getattr(packed, "_pre_s16", None)
+            if cache is None:
+                cache = packed._pre_s16 = _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2))
+            S, n_out = _fused_mlp._slabs(C2), cache.size(0)
+            xs = torch.empty((B * m * S * 96,), dtype=torch.uint8, device=known_feats.device)
+            z = torch.empty((B, m, n_out), dtype=torch.float32, device=known_feats.device)
+            with on_device(known_feats.device):
+                check(lib.pvn3d_split_rows(B * m, C2, kf.data_ptr(), ld_k, xs.data_ptr(), S, _stream(known_feats)), "split_rows")
+                check(lib.pvn3d_split_gemm(B * m, n_out, S, xs.data_ptr(), cache.data_ptr(), None, 0, None, 0, 0, 0, None,
+                                           None, z.data_ptr(), n_out, None, 0, _stream(known_feats)), "split_gemm")
+            kf, ld_k, C2, packed = z, n_out, pre.dims[1], pre
     if (_fused_mlp.MLP_ARITH == "bf16x3" and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0
             and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
             and lib.pvn3d_mlp_split_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):

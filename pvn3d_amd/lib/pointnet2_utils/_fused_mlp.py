@@ -49,18 +49,19 @@ class PackedMLP(object):
         self._split = None
 
     def precontracted(self, c_feat):
-        """The chain with its first conv's FEATURE half taken out (the caller applies it per source point, before the
-        gather: _ext.sa_precontract): layer 0 becomes [I | Wx] over [Wf.f (M0 channels); relative xyz (3)], the other
-        layers are unchanged.  -> (PackedMLP for dims [M0 + 3, M0, ...], Wf (M0, c_feat) fp32)."""
+        """The chain with the GATHERED half of its first conv taken out (the caller applies it per source point, before
+        the gather / interpolation: _ext.sa_precontract, _ext.fp_interp_mlp): layer 0 becomes [I | Wr] over
+        [Wf.f (M0 channels); the rest (SA: relative xyz, FP: skip features)], the other layers are unchanged.
+        -> (PackedMLP for dims [M0 + rest, M0, ...], Wf (M0, c_feat) fp32)."""
         cache = getattr(self, "_pre", None)
         if cache is not None and cache[0] == c_feat:
             return cache[1], cache[2]
         W0 = self._folded[0]                                  # kernel order: features first, then the xyz columns
         m0 = W0.shape[0]
-        assert W0.shape[1] == c_feat + 3
+        assert W0.shape[1] > c_feat
         w0 = torch.cat([torch.eye(m0, dtype=torch.float32, device=W0.device), W0[:, c_feat:]], 1).contiguous()
         folded = [w0] + list(self._folded[1:])
-        pre = PackedMLP([m0 + 3] + self.dims[1:], [_pack_weight(W) for W in folded], self.b, folded=folded)
+        pre = PackedMLP([w0.shape[1]] + self.dims[1:], [_pack_weight(W) for W in folded], self.b, folded=folded)
         self._pre = (c_feat, pre, W0[:, :c_feat].contiguous())
         return pre, self._pre[2]
 
