@@ -35,6 +35,29 @@ FRAMES = 64
 N_XCD = 8          # GRBM_GUI_ACTIVE comes back summed over the XCDs
 
 
+def group_launches(launches):
+    """launches: [(dispatch id, kernel name)] of the whole run, in order -> one list of dispatch ids per entry of CHAINS
+    for the LAST fused forward.  A forward starts at SA level 0's first kernel.  A chain is one mlp_chain* launch, except:
+    FP levels 3 / 2 run layer by layer on the split GEMM (three consecutive sg_gemm launches, csrc/split_gemm.hip), and
+    a single sg_gemm in front of a chain kernel is that level's pre-contraction (_ext.sa_precontract, the FP level-0
+    form in _ext.fp_interp_mlp) -- booked on the chain that follows it."""
+    first = next(k for _, k in launches if "mlp_chain" in k)
+    start = max(i for i, (_, k) in enumerate(launches) if k == first)
+    groups, pending = [], []
+    for d, k in launches[start:]:
+        nxt = CHAINS[len(groups)][0] if len(groups) < len(CHAINS) else None
+        if nxt is None:
+            break
+        if "sg_gemm" in k:
+            pending.append(d)
+            if len(pending) == 3 and nxt in ("FP3", "FP2"):
+                groups.append(pending); pending = []
+        else:
+            groups.append(pending + [d]); pending = []
+    assert len(groups) == len(CHAINS), "launch pattern of the forward not recognised: %d groups" % len(groups)
+    return groups
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
     out = "/tmp/pmc_mfma"
@@ -52,20 +75,7 @@ def main():
         if "mlp_chain" in r["Kernel_Name"] or "sg_gemm" in r["Kernel_Name"]:
             dur[int(r["Dispatch_Id"])] = ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                           r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0])
-    # the last fused forward of the run: one launch per chain, except that a chain run layer by layer on the split GEMM
-    # (csrc/split_gemm.hip: FP levels 2-3) is three consecutive sg_gemm launches -- their counters and times are summed
-    all_ids = sorted(ctr)
-    groups, i = [], len(all_ids)
-    for name, _, _ in reversed(CHAINS):
-        if "sg_gemm" in dur[all_ids[i - 1]][1]:                  # an FP level on the split GEMM: Z, H, Y
-            groups.append(all_ids[i - 3:i]); i -= 3
-        elif name.endswith("ns16") and i >= 2 and "sg_gemm" in dur[all_ids[i - 2]][1]:
-            # an SA level whose first conv's feature half runs ahead of the gather (_ext.sa_precontract): that GEMM
-            # serves both scales of the level and is booked on the first
-            groups.append(all_ids[i - 2:i]); i -= 2
-        else:
-            groups.append(all_ids[i - 1:i]); i -= 1
-    groups.reverse()
+    groups = group_launches([(d, dur[d][1]) for d in sorted(ctr)])
     rows, tot_fl, tot_us, tot_busy, tot_act = [], 0.0, 0.0, 0.0, 0.0
     for (name, dims, cols), g in zip(CHAINS, groups):
         c = {k: sum(ctr[d][k] for d in g) for k in ctr[g[0]]}

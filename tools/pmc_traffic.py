@@ -14,12 +14,12 @@ import subprocess
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-STAGE_OF = [("mlp_chain_s3_kernel<true", "sa_mlp"), ("mlp_chain_s3_kernel<false", "fp_mlp"),
+STAGE_OF = [("[sa_mlp]", "sa_mlp"), ("[fp_mlp]", "fp_mlp"),      # split-GEMM launches, tagged by run_pass
+            ("mlp_chain_s3_kernel<true", "sa_mlp"), ("mlp_chain_s3_kernel<false", "fp_mlp"),
             ("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
             ("mlp_chain_mid_kernel<true", "sa_mlp"), ("mlp_chain_cols_kernel<true", "sa_mlp"),
             ("mlp_chain_kernel<false", "fp_mlp"), ("mlp_chain_wide_kernel<false", "fp_mlp"),
             ("mlp_chain_mid_kernel<false", "fp_mlp"), ("mlp_chain_cols_kernel<false", "fp_mlp"),
-            ("sg_gemm_kernel", "fp_mlp"), ("sg_split_rows_kernel", "fp_mlp"),
             ("group_points", "group"), ("group_xyz_rel", "group"), ("three_interpolate", "three_interpolate"),
             ("ball_query", "ball_query"), ("grid_build", "ball_query"), ("three_nn", "three_nn"),
             ("fps_", "fps"), ("gather_points", "gather"), ("ms_", "vote_cluster_pose"),
@@ -38,8 +38,21 @@ def run_pass(counter, outdir, extra=()):
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
     per_kernel = collections.defaultdict(float)
     with open(os.path.join(outdir, "p_counter_collection.csv")) as f:
-        for r in csv.DictReader(f):
-            per_kernel[r["Kernel_Name"]] += float(r["Counter_Value"]) * 1024.0
+        rows = sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
+    # The split GEMM (csrc/split_gemm.hip: sg_gemm_kernel, sg_split_rows_kernel) serves both MLP stages: a launch belongs
+    # to the stage of the next fused-chain kernel after it -- an SA level's pre-contraction precedes that level's chains,
+    # FP levels 3 / 2 (GEMM only) precede FP level 1's chain, FP level 0's pre-contraction precedes its chain.
+    nxt, stage_after = None, [None] * len(rows)
+    for i in range(len(rows) - 1, -1, -1):
+        k = rows[i]["Kernel_Name"]
+        if "mlp_chain" in k:
+            nxt = "sa_mlp" if "<true" in k else "fp_mlp"
+        stage_after[i] = nxt
+    for r, st in zip(rows, stage_after):
+        name = r["Kernel_Name"]
+        if "sg_gemm_kernel" in name or "sg_split_rows_kernel" in name:
+            name = "%s [%s]" % (name.split("(")[0] if not name.startswith("(") else name[:60], st or "fp_mlp")
+        per_kernel[name] += float(r["Counter_Value"]) * 1024.0
     return per_kernel
 
 
