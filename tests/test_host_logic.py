@@ -254,3 +254,76 @@ def test_split_weight_packing_is_exact_and_in_fragment_order():
     rel = ((full[:70, :37] - W.double()).abs() / W.double().abs().clamp_min(1e-30)).max()
     assert float(rel) <= 2.0 ** -23
     assert float(full[70:].abs().max()) == 0.0 and float(full[:, 37:].abs().max()) == 0.0
+
+
+def test_s16_weight_packing_precontraction_and_dispatch_predicates():
+    """Host side of csrc/split_gemm.hip: _pack_weight_s16 lays a matrix out as rows x 16-k slabs x 3 pieces x 16 with the
+    pieces adding back to the weight (2^-23 relative), rows padded to 128 and k to whole 32-k chunks with zeros;
+    PackedMLP.precontracted splits layer 0 into the gathered half Wf and [I | rest]; s16() splits it at the skip
+    boundary; fp_layerwise_shape_ok is the shape half of the FP dispatch."""
+    import torch
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp, _ext, pointnet2_modules as pm
+    torch.manual_seed(1)
+    assert [_fused_mlp._slabs(k) for k in (1, 16, 32, 33, 96, 256, 1536)] == [2, 2, 2, 4, 6, 16, 96]
+    W = torch.randn(200, 70) * torch.logspace(-2, 2, 70)[None]
+    S = _fused_mlp._slabs(70)
+    P = _fused_mlp._pack_weight_s16(W, S)
+    assert P.shape == (256, S, 3, 16) and P.dtype == torch.int16
+    full = P.view(torch.bfloat16).double().sum(2).reshape(256, S * 16)
+    rel = ((full[:200, :70] - W.double()).abs() / W.double().abs().clamp_min(1e-30)).max()
+    assert float(rel) <= 2.0 ** -23
+    assert float(full[200:].abs().max()) == 0.0 and float(full[:, 70:].abs().max()) == 0.0
+
+    sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).eval()
+    packed = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
+    pre, wf = packed.precontracted(256)
+    assert pre.dims == [131, 128, 196, 256] and wf.shape == (128, 256) and pre.n_layers == 3
+    w0 = pre._folded[0]
+    assert torch.equal(w0[:, :128], torch.eye(128)) and torch.equal(w0[:, 128:], packed._folded[0][:, 256:])
+    assert torch.equal(wf, packed._folded[0][:, :256]) and pre._folded[1] is packed._folded[1]
+    assert packed.precontracted(256)[0] is pre                                   # cached
+
+    fp = pm.PointnetFPModule(mlp=[768, 512, 512]).eval()
+    pk = _fused_mlp.pack_shared_mlp(fp.mlp)
+    d = pk.s16(512)
+    assert (d["n1"], d["n2"], d["s_a"], d["s_b"], d["s_h"]) == (512, 512, 32, 16, 32)
+    assert d["wa"].shape == (512, 32, 3, 16) and d["wb"].shape == (512, 16, 3, 16) and d["w2"].shape == (512, 32, 3, 16)
+    wa = d["wa"].view(torch.bfloat16).double().sum(2).reshape(512, 512)
+    assert float((wa - pk._folded[0][:, :512].double()).abs().max()) <= 2.0 ** -23 * float(pk._folded[0].abs().max())
+    assert d["b1"].shape == (512,) and torch.equal(d["b1"], pk.b[0][:512])
+
+    keep = _fused_mlp.MLP_ARITH
+    try:
+        _fused_mlp.MLP_ARITH = "bf16x3"
+        ok = _ext.fp_layerwise_shape_ok
+        assert ok(65536, 256, [768, 512, 512]) and ok(32768, 512, [1536, 512, 512])
+        assert not ok(1024, 256, [768, 512, 512])            # one frame: the fused fp32 chain
+        assert not ok(65536, 0, [768, 512, 512])             # no skip features
+        assert not ok(65536, 96, [608, 256, 128])            # a narrow layer
+        assert not ok(65536, 256, [768, 512, 512, 512])      # three layers
+        _fused_mlp.MLP_ARITH = "fp32"
+        assert not ok(65536, 256, [768, 512, 512])
+    finally:
+        _fused_mlp.MLP_ARITH = keep
+
+
+def test_pmc_mfma_groups_the_launches_of_a_forward_by_chain():
+    """tools/pmc_mfma.py books the counters of a forward's launches on the twelve chains: FP levels 3 / 2 are three
+    split-GEMM launches each, a single split GEMM in front of a chain kernel is that level's pre-contraction."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("pmc_mfma", os.path.join(ROOT, "tools", "pmc_mfma.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    s3, sg = "mlp_chain_s3_kernel<%s>", "sg_gemm_kernel"
+    fwd = ["mlp_chain_cols_kernel<true, 1>", "mlp_chain_cols_kernel<true, 2>", "mlp_chain_kernel<true, false>",
+           "mlp_chain_kernel<true, false>", sg, s3 % "true, 1, 2, 2, 1", s3 % "true, 1, 2, 2, 1", sg,
+           s3 % "true, 2, 2, 2, 2", s3 % "true, 2, 3, 2, 2", sg, sg, sg, sg, sg, sg, s3 % "false, 2, 2, 0, 1", sg,
+           s3 % "false, 1, 1, 0, 1"]
+    groups = mod.group_launches(list(enumerate(fwd + fwd)))
+    assert [len(g) for g in groups] == [1, 1, 1, 1, 2, 1, 2, 1, 3, 3, 1, 2]
+    assert groups[0] == [19] and groups[-1] == [36, 37]                           # the LAST forward
+    plain = ["mlp_chain_cols_kernel<true, 1>", "mlp_chain_cols_kernel<true, 2>"] + ["mlp_chain_kernel<true, false>"] * 6 + \
+        ["mlp_chain_wide_kernel<false, false>"] * 2 + ["mlp_chain_kernel<false, false>"] * 2
+    assert [len(g) for g in mod.group_launches(list(enumerate(plain)))] == [1] * 12
