@@ -1,3 +1,5 @@
+# Kernel timeline of the single-frame vote -> cluster -> pose call as a HIP-graph replay (run on the GPU box from the repo root):
+# plain timing, then a rocprofv3 kernel trace of tools/graph_trace.py; gpurun_out/gt/timeline.txt lists the last launches.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/gt; mkdir -p $O
 timeout 200 python tools/graph_trace.py > $O/plain.log 2>&1

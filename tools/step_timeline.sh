@@ -1,3 +1,5 @@
+# Per-stream timeline of one pipelined bench step (run on the GPU box from the repo root): rocprofv3 kernel trace of a short
+# bench.py run, then tools/step_timeline.py -> gpurun_out/tl/timeline.txt (profiles/r04_step_timeline.txt).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tl; mkdir -p $O
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof -o tl -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs > $O/bench.json 2> $O/prof.err)
