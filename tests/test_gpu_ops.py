@@ -1212,6 +1212,44 @@ def test_layerwise_split_fp_chain_against_fp64_and_fp32_chain(dev, c2, c1, mlp, 
     assert got.shape == (b, mlp[-1], n) and e_lw < 2e-5 and e_chain < 2e-5
 
 
+def test_split_chains_at_the_bench_batch_size_repeat_bit_for_bit(dev):
+    """The 64-frame shapes of the bench through the split-bf16 kernels (SA level 2 with its pre-contraction GEMM, FP level
+    0 with its, FP level 2 layer by layer), twice: identical bits, and within 4e-6 of the fp32-MFMA chain -- the size at
+    which the one timing-dependent fault of this code base showed (csrc/split_gemm.hip, epilogue note)."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp
+    torch.manual_seed(21)
+    B = 64
+    xyz = T(clouds(71, B, 1024, 0.1), dev)
+    sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
+    _randomize_bn(sa)
+    feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+    unk = T(clouds(72, B, 12288, 0.1), dev)
+    fp0 = pm.PointnetFPModule(mlp=[262, 128, 128]).to(dev).eval()
+    fp2 = pm.PointnetFPModule(mlp=[768, 512, 512]).to(dev).eval()
+    _randomize_bn(fp0); _randomize_bn(fp2)
+    fp2._point_major_out = True
+    kf0 = torch.randn(B, 2048, 256, device=dev).transpose(1, 2)
+    uf0 = torch.randn(B, 12288, 9, device=dev)[:, :, 3:].transpose(1, 2)
+    kf2 = torch.randn(B, 512, 512, device=dev).transpose(1, 2)
+    uf2 = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+    with torch.no_grad():
+        geo = sa.sample_and_query(xyz)
+        nb0 = fp0.neighbours(unk, unk[:, :2048].contiguous())
+        nb2 = fp2.neighbours(unk[:, :1024].contiguous(), unk[:, :512].contiguous())
+        runs = []
+        for arith in ("bf16x3", "bf16x3", "fp32"):
+            _fused_mlp.MLP_ARITH = arith
+            try:
+                runs.append([sa(xyz, feats, geometry=geo)[1].clone(),
+                             fp0(unk, unk[:, :2048].contiguous(), uf0, kf0, neighbours=nb0).clone(),
+                             fp2(unk[:, :1024].contiguous(), unk[:, :512].contiguous(), uf2, kf2, neighbours=nb2).clone()])
+            finally:
+                _fused_mlp.MLP_ARITH = "bf16x3"
+    for a, b, c in zip(*runs):
+        assert torch.equal(a, b) and not torch.equal(a, c)
+        assert (a - c).abs().max().item() / max(1.0, c.abs().max().item()) < 4e-6
+
+
 def test_split_gemm_c_abi(dev):
     """pvn3d_split_rows / pvn3d_split_gemm through the C-ABI: the s16 rows carry the fp32 values exactly, a GEMM's
     fp32 and s16 outputs agree exactly with each other and to fp32 accuracy with float64, pad channels are zeros, the
