@@ -66,8 +66,7 @@ __device__ __forceinline__ void sg_split4(const float (&x)[4], uint2& h, uint2& 
   l.x = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u); l.y = __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u);
 }
 
-// grid (channel tiles, point tiles): the channel tiles of one point tile are adjacent in launch order and share the
-// X tile through L2.
+// grid (channel tiles, point tiles), remapped per XCD below.
 __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * SG_OPB];
   char* sW = smem;
@@ -75,7 +74,18 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 1, wc = wave >> 1;           // 64-channel / 64-point quadrant of this wave
-  const int c0 = blockIdx.x * SG_T, p0 = blockIdx.y * SG_T;
+  // (channel tile, point tile) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order, each
+  // XCD with its own L2: in the plain (x = channel tile, y = point tile) reading the channel tiles of one point tile land
+  // on different XCDs and every one of them pulls the X tile from HBM.  Here XCD x works through point tiles x, x + 8,
+  // ..., all channel tiles of a point tile back to back on the same XCD: the X tile comes from HBM once.
+  int ct = blockIdx.x, pt = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned q = lin >> 3;
+    ct = (int)(q % gridDim.x);
+    pt = (int)(q / gridDim.x) * 8 + (int)(lin & 7);
+  }
+  const int c0 = ct * SG_T, p0 = pt * SG_T;
   const size_t rowb = (size_t)a.S * 96;              // bytes per s16 row
   const int nch = a.S >> 1;
 
