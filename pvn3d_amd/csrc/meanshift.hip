@@ -198,7 +198,8 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
 // PK = false: one seed per lane, 8 (fast form) or 9 VALU instructions per (seed, point) pair.
 // PK = true : two seeds per lane held as float2; the exponent and the four accumulations are packed
 //             fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 with the point operand broadcast through
-//             op_sel), 3.5 packed + 1 v_exp_f32 per pair instead of 7 + 1.
+//             op_sel / op_sel_hi -- operand positions chosen by hand, see ms_pair2_packed), 3.5 packed + 1
+//             v_exp_f32 per pair instead of 7 + 1.
 // SPLIT = false: a workgroup owns 256 * S seeds, every wave walks ALL points of the fit for its seeds.
 // SPLIT = true : a workgroup owns 64 * S seeds and its four waves walk one quarter of every staged point
 //             chunk each, then add their partial sums through LDS: a workgroup's latency -- the floor
@@ -234,25 +235,84 @@ struct MsAcc {
   ms_f2 w, x, y, z;
 };
 
+// A staged point record is (x', y', -|a'|^2, z'): the register pairs (x', y') and (-|a'|^2, z').
+//
+// Operand placement of the packed path is hand-written, for a measured reason (round 5, tools/sg_fault_repro.hip
+// variant 20, tools/ms_beside_mfma.py, profiles/r05_pk_opsel_fault.txt): on gfx950 a packed-fp32 instruction whose
+// LOW half selects the HIGH register of a VGPR pair in its src1 or src2 position (op_sel bit 1 / bit 2) returns that
+// operand as +0 in lanes 48-63 now and then WHILE the other wave of its SIMD runs an MFMA / LDS K loop -- i.e. while a
+// kernel of the MLP stream shares the SIMD.  (The compiler's own code for ms_splat(a.y) was exactly that form, and a
+// MeanShift batch beside the split GEMM changed the y of 2-5 % of its centres by up to 1.5e-5.)  The same selection in
+// the src0 position, the opposite one (high half takes the low register, op_sel_hi = 0) in any position, and scalar
+// (SGPR) sources never failed in 5e7 executions each.  So: a value that sits in the HIGH register of its pair (y', z')
+// always enters as src0, values in LOW registers (x', -|a'|^2) are broadcast with op_sel_hi = 0.  fma(a, b, c) ==
+// fma(b, a, c) bit for bit, so the results are those of the one-seed-per-lane path, as before.
+template <bool FAST>
+__device__ __forceinline__ void ms_pair2_packed(MsAcc& A, const float4 ra, const float4 rb, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z,
+                                                ms_f2 pcm) {
+  const ms_f2 xa = {ra.x, ra.y}, ya = {ra.z, ra.w}, xb = {rb.x, rb.y}, yb = {rb.z, rb.w};
+  ms_f2 ea, eb;
+  // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : (one subtract +) three FMAs
+  if (FAST)
+    asm("v_pk_fma_f32 %[ea], %[p2x], %[xa], %[ya] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2x], %[xb], %[yb] op_sel_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[ea], %[xa], %[p2y], %[ea] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[xb], %[p2y], %[eb] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[ea], %[ya], %[p2z], %[ea] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[yb], %[p2z], %[eb] op_sel:[1,0,0]"
+        : [ea] "=&v"(ea), [eb] "=&v"(eb)
+        : [p2x] "v"(p2x), [p2y] "v"(p2y), [p2z] "v"(p2z), [xa] "v"(xa), [ya] "v"(ya), [xb] "v"(xb), [yb] "v"(yb));
+  else
+    asm("v_pk_add_f32 %[ea], %[ya], %[pcm] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[eb], %[yb], %[pcm] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[p2x], %[xa], %[ea] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[eb], %[p2x], %[xb], %[eb] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %[ea], %[xa], %[p2y], %[ea] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[xb], %[p2y], %[eb] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[ea], %[ya], %[p2z], %[ea] op_sel:[1,0,0]\n\t"
+        "v_pk_fma_f32 %[eb], %[yb], %[p2z], %[eb] op_sel:[1,0,0]"
+        : [ea] "=&v"(ea), [eb] "=&v"(eb)
+        : [p2x] "v"(p2x), [p2y] "v"(p2y), [p2z] "v"(p2z), [pcm] "v"(pcm), [xa] "v"(xa), [ya] "v"(ya), [xb] "v"(xb),
+          [yb] "v"(yb));
+  const ms_f2 wa = ms_f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+  const ms_f2 wb = ms_f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+  asm("s_nop 0\n\t"                                         // v_exp_f32 (trans) -> VALU read of its result
+      "v_pk_add_f32 %[Aw], %[Aw], %[wa]\n\t"
+      "v_pk_fma_f32 %[Ax], %[wa], %[xa], %[Ax] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Ay], %[xa], %[wa], %[Ay] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[Az], %[ya], %[wa], %[Az] op_sel:[1,0,0]\n\t"
+      "v_pk_add_f32 %[Aw], %[Aw], %[wb]\n\t"
+      "v_pk_fma_f32 %[Ax], %[wb], %[xb], %[Ax] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %[Ay], %[xb], %[wb], %[Ay] op_sel:[1,0,0]\n\t"
+      "v_pk_fma_f32 %[Az], %[yb], %[wb], %[Az] op_sel:[1,0,0]"
+      : [Aw] "+v"(A.w), [Ax] "+v"(A.x), [Ay] "+v"(A.y), [Az] "+v"(A.z)
+      : [wa] "v"(wa), [wb] "v"(wb), [xa] "v"(xa), [ya] "v"(ya), [xb] "v"(xb), [yb] "v"(yb));
+}
+
+// one seed per lane: record fields as single registers, nothing to select
+template <bool FAST>
+__device__ __forceinline__ void ms_pair_scalar(MsAcc& A, const float4 r, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
+  const float ax = r.x, ay = r.y, aw = r.z, az = r.w;
+  const float e0 = FAST ? aw : aw - pcm.x;
+  const float e = fmaf(p2z.x, az, fmaf(p2y.x, ay, fmaf(p2x.x, ax, e0)));
+  const float w = __builtin_amdgcn_exp2f(e);
+  A.w.x += w;
+  A.x.x = fmaf(w, ax, A.x.x);
+  A.y.x = fmaf(w, ay, A.y.x);
+  A.z.x = fmaf(w, az, A.z.x);
+}
+
 template <bool PK, bool FAST>
-__device__ __forceinline__ void ms_pair(MsAcc& A, const float4 a, ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
+__device__ __forceinline__ void ms_four(MsAcc& A, const float4 r0, const float4 r1, const float4 r2, const float4 r3,
+                                        ms_f2 p2x, ms_f2 p2y, ms_f2 p2z, ms_f2 pcm) {
   if (PK) {
-    // -|c'-a'|^2 = 2c'.a' - |a'|^2 - |c'|^2 : (one subtract +) three FMAs
-    const ms_f2 e0 = FAST ? ms_splat(a.w) : ms_splat(a.w) - pcm;
-    const ms_f2 e = ms_fma2(p2z, ms_splat(a.z), ms_fma2(p2y, ms_splat(a.y), ms_fma2(p2x, ms_splat(a.x), e0)));
-    const ms_f2 w = ms_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-    A.w += w;
-    A.x = ms_fma2(w, ms_splat(a.x), A.x);
-    A.y = ms_fma2(w, ms_splat(a.y), A.y);
-    A.z = ms_fma2(w, ms_splat(a.z), A.z);
+    ms_pair2_packed<FAST>(A, r0, r1, p2x, p2y, p2z, pcm);
+    ms_pair2_packed<FAST>(A, r2, r3, p2x, p2y, p2z, pcm);
   } else {
-    const float e0 = FAST ? a.w : a.w - pcm.x;
-    const float e = fmaf(p2z.x, a.z, fmaf(p2y.x, a.y, fmaf(p2x.x, a.x, e0)));
-    const float w = __builtin_amdgcn_exp2f(e);
-    A.w.x += w;
-    A.x.x = fmaf(w, a.x, A.x.x);
-    A.y.x = fmaf(w, a.y, A.y.x);
-    A.z.x = fmaf(w, a.z, A.z.x);
+    ms_pair_scalar<FAST>(A, r0, p2x, p2y, p2z, pcm);
+    ms_pair_scalar<FAST>(A, r1, p2x, p2y, p2z, pcm);
+    ms_pair_scalar<FAST>(A, r2, p2x, p2y, p2z, pcm);
+    ms_pair_scalar<FAST>(A, r3, p2x, p2y, p2z, pcm);
   }
 }
 
@@ -269,19 +329,27 @@ __device__ __forceinline__ void ms_accumulate(MsAcc& A, const float4* __restrict
     const int qb = min(q + 4, q_end - 4);         // the last group re-reads itself (unused)
     b0 = sp[qb]; b1 = sp[qb + 1]; b2 = sp[qb + 2]; b3 = sp[qb + 3];
     __builtin_amdgcn_sched_barrier(0);            // or the scheduler sinks the reads to the end of the block again
-    ms_pair<PK, FAST>(A, a0, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, a1, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, a2, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, a3, p2x, p2y, p2z, pcm);
+    ms_four<PK, FAST>(A, a0, a1, a2, a3, p2x, p2y, p2z, pcm);
     if (q + 4 >= q_end) break;
     const int qa = min(q + 8, q_end - 4);
     a0 = sp[qa]; a1 = sp[qa + 1]; a2 = sp[qa + 2]; a3 = sp[qa + 3];
     __builtin_amdgcn_sched_barrier(0);
-    ms_pair<PK, FAST>(A, b0, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, b1, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, b2, p2x, p2y, p2z, pcm);
-    ms_pair<PK, FAST>(A, b3, p2x, p2y, p2z, pcm);
+    ms_four<PK, FAST>(A, b0, b1, b2, b3, p2x, p2y, p2z, pcm);
   }
+}
+
+// (a + b) + (c + d) of the four quarter sums.  With one seed per lane only element .x is live and the compiler's SLP
+// pass packs the four independent scalar chains across the accumulators, shuffling through op_sel (the operand form
+// of the note above, found by tools/pk_opsel_lint.py): there the three additions are single-lane instructions.
+__device__ __forceinline__ float ms_add1(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <bool PK>
+__device__ __forceinline__ ms_f2 ms_sum4(ms_f2 a, ms_f2 b, ms_f2 c, ms_f2 d) {
+  if (PK) return (a + b) + (c + d);
+  return ms_f2{ms_add1(ms_add1(a.x, b.x), ms_add1(c.x, d.x)), 0.f};
 }
 
 template <bool PK, bool SPLIT>
@@ -379,9 +447,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
         const float4 r = pre[u];
         const float ax = (r.x - org.x) * kappa, ay = (r.y - org.y) * kappa,
                     az = (r.z - org.z) * kappa;
-        a = make_float4(ax, ay, az, -fmaf(az, az, fmaf(ay, ay, ax * ax)));   // w = -|a'|^2
+        a = make_float4(ax, ay, -fmaf(az, az, fmaf(ay, ay, ax * ax)), az);   // (x', y', -|a'|^2, z')
       } else {
-        a = make_float4(0.f, 0.f, 0.f, -1e30f);  // exp2(-huge) == 0: padded rows weigh 0
+        a = make_float4(0.f, 0.f, -1e30f, 0.f);  // exp2(-huge) == 0: padded rows weigh 0
       }
       s_pts[q] = a;
     }
@@ -411,10 +479,10 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
     __syncthreads();
     if (wave > 0) return;
     const MsAcc p1 = s_part[0][sl], p2 = s_part[1][sl], p3 = s_part[2][sl];
-    tot.w = (acc[0].w + p1.w) + (p2.w + p3.w);
-    tot.x = (acc[0].x + p1.x) + (p2.x + p3.x);
-    tot.y = (acc[0].y + p1.y) + (p2.y + p3.y);
-    tot.z = (acc[0].z + p1.z) + (p2.z + p3.z);
+    tot.w = ms_sum4<PK>(acc[0].w, p1.w, p2.w, p3.w);
+    tot.x = ms_sum4<PK>(acc[0].x, p1.x, p2.x, p3.x);
+    tot.y = ms_sum4<PK>(acc[0].y, p1.y, p2.y, p3.y);
+    tot.z = ms_sum4<PK>(acc[0].z, p1.z, p2.z, p3.z);
   } else {
     tot.w = (acc[0].w + acc[NACC > 1 ? 1 : 0].w) + (acc[NACC > 2 ? 2 : 0].w + acc[NACC > 3 ? 3 : 0].w);
     tot.x = (acc[0].x + acc[NACC > 1 ? 1 : 0].x) + (acc[NACC > 2 ? 2 : 0].x + acc[NACC > 3 ? 3 : 0].x);
