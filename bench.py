@@ -337,8 +337,11 @@ def cpu_baseline(frame, budget_s=20.0, one_thread_budget_s=8.0):
                                frame["mesh_kps"])
     t_c = time.perf_counter() - t0
     n_obj = int((frame["mask"] == 1).sum())
-    sample = ("1 frame (N=%d, n_obj=%d, 9 fits) vote+cluster+pose, dense torch-CPU restatement of "
-              "MeanShiftTorch.fit + numpy Kabsch" % (len(frame["pcld"]), n_obj))
+    sample = ("1 frame (N=%d, n_obj=%d, 9 fits) vote+cluster+pose; kind 'port' = oracle/torch_port.py, the dense "
+              "torch-CPU restatement of MeanShiftTorch.fit (+ numpy Kabsch), pinned to the reference's own outputs "
+              "(tests/golden/meanshift_ref.npz) and timed at 0.68-1.02x the reference's own fit on the same inputs "
+              "(profiles/r04_meanshift_ref_vs_port.json, 8 threads, build container; /root/reference is absent on the "
+              "bench host)" % (len(frame["pcld"]), n_obj))
     if extrapolated:
         sample += "; %d of 9 fits timed, frame time extrapolated x9/%d" % (n_fits, n_fits)
     return dict(value=1.0 / t_ref, unit="frames/s", cores=threads, kind="port", sample=sample,
@@ -589,6 +592,94 @@ def extra_configs(net, dev, poll_every, with_cpu):
     return out
 
 
+def distributed_train_entry(dev, rank, world, steps=5, warm=2, frames=24, bucket_bytes=4 << 20, standin=False):
+    """BASELINE config 5 at N > 1 (weak: `frames` frames per GPU): the bf16 training step of the voting branch with its
+    gradient buckets all-reduced from inside backward (sharding.OverlappedGradientReducer over RCCL / xGMI) -- what
+    replaces the reference's nn.DataParallel (train_linemod_pvn3d.py:480,502-503).  Every rank calls this; the timing
+    is bracketed by barrier + synchronize on both sides and the MAX over ranks is reported.  The same K steps are then
+    repeated WITHOUT the exchange (group of one) so that the exposed all-reduce time -- what the collectives add to a
+    step after their overlap with backward -- is a measured difference, not an estimate.
+    standin=True (CPU test of this code path only, PVN3D_BENCH_TRAIN_STANDIN=1 under the gloo override): a small
+    torch-only model on CPU tensors goes through the SAME exchange / timing / reporting code; labelled in the entry."""
+    from pvn3d_amd import sharding
+    group = dist.group.WORLD
+    if standin:
+        torch.manual_seed(3)
+        model = torch.nn.Sequential(torch.nn.Linear(64, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                                    torch.nn.Linear(512, 27))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        torch.manual_seed(100 + rank)
+        x, y = torch.randn(frames * 64, 64), torch.randn(frames * 64, 27)
+        bucket_bytes = 256 << 10
+
+        def one_step(g):
+            opt.zero_grad(set_to_none=True)
+            loss = ((model(x) - y) ** 2).mean()
+            red = sharding.overlapped_reducer(model, bucket_bytes=bucket_bytes, group=g) if g is not None else None
+            if red is not None:
+                red.arm()
+            loss.backward()
+            if red is not None:
+                red.finalize()
+            opt.step()
+            return loss.detach()
+        sync = lambda: None
+        net = model
+        what = "STAND-IN (3-layer torch MLP on CPU tensors): exercises the launch / exchange / report path only"
+    else:
+        from pvn3d_amd import train_step as ts
+        torch.manual_seed(1)
+        model = ts.PointVoteNet().to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        batch = ts.synthetic_batch(frames, 12288, dev, seed_base=7500 + 1000 * rank, n_obj=3072)
+        one_step = lambda g: ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16, group=g,
+                                           bucket_bytes=bucket_bytes)
+        sync = lambda: torch.cuda.synchronize(dev)
+        net = model
+        what = ("Pointnet2MSG + offset heads, forward + vote loss + backward + Adam step, bf16 autocast, SA/FP SharedMLP "
+                "on csrc/mlp_train.hip; %d frames of N=12288 per GPU per step" % frames)
+    sharding.broadcast_parameters(net, group=group)          # every rank starts from rank 0's weights (DataParallel's replication)
+
+    def timed(g):
+        for _ in range(warm):
+            one_step(g)
+        sync()
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        losses = [one_step(g) for _ in range(steps)]
+        sync()
+        dist.barrier()
+        sync()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if not standin else "cpu")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()) / steps * 1e3, [float(l) for l in losses]
+
+    ms_x, losses = timed(group)
+    red = getattr(net, "_pvn3d_grad_reducer", None)
+    n_buckets = len(red.buckets) if red is not None else 0
+    bytes_buckets = [int(sum(p.numel() * p.element_size() for p in b)) for b in red.buckets] if red is not None else []
+    during = red.launched_during_backward if red is not None else 0
+    # weights identical on every rank after the exchanged steps (the whole point of the all-reduce)
+    chk = torch.cat([p.detach().reshape(-1)[:64].float().cpu() for p in net.parameters()])
+    lo, hi = chk.clone(), chk.clone()
+    if not standin:
+        lo, hi = lo.to(dev), hi.to(dev)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    in_sync = bool(torch.equal(lo, hi))
+    ms_0, _ = timed(None)                                    # the same steps, no exchange
+    return dict(name="train_step", n_gpus=world, scaling="weak", frames_per_gpu_per_step=frames,
+                workload="config 5 at %d ranks: %s; gradients bucketed (%.1f MiB) and all-reduced from inside backward "
+                         "(RCCL over xGMI), one process per GPU" % (world, what, bucket_bytes / 2 ** 20),
+                ms_per_step=ms_x, frames_per_s=world * frames * 1e3 / ms_x,
+                ms_per_step_without_exchange=ms_0, exposed_allreduce_ms=max(0.0, ms_x - ms_0),
+                gradient_buckets=n_buckets, gradient_bytes_per_step=int(sum(bytes_buckets)), bucket_bytes=bytes_buckets,
+                buckets_issued_inside_backward_total=int(during), steps=steps, warmup=warm,
+                weights_identical_across_ranks_after_steps=in_sync, loss_first=losses[0], loss_last=losses[-1],
+                backend=dist.get_backend())
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: re-execute this command line as N ranks (one per GPU) under
     torch.distributed.run on 127.0.0.1 with a free port, stream rank 0's JSON line through, return the exit code.
@@ -630,6 +721,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="--frames is the TOTAL per step, split over the ranks (BASELINE config 4: 64 frames sharded)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `configs` array (N=1 only)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="N > 1: only BASELINE config 5 (distributed_train_entry), one JSON line with that entry")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch + init_process_group + one all-reduce, then exit (checks the N > 1 launch path)")
     args = ap.parse_args()
@@ -661,6 +754,21 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        return
+    standin = os.environ.get("PVN3D_BENCH_TRAIN_STANDIN") == "1"      # CPU test of the config-5 launch / exchange path
+    if args.train_only:
+        if world < 2:
+            raise SystemExit("bench.py --train-only measures config 5 at N > 1 (the N = 1 step is in `configs` of the default run)")
+        if not standin:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+            torch.cuda.set_device(local_rank)
+        entry = distributed_train_entry(torch.device("cuda", local_rank) if not standin else torch.device("cpu"), rank, world,
+                                        steps=args.steps, warm=args.warmup, standin=standin)
+        if rank == 0:
+            print(json.dumps({"metric": "config 5 training step, %d ranks" % world, "n_gpus": world, "configs": [entry]}))
+        dist.barrier()
+        dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
@@ -772,6 +880,12 @@ def main():
     pose_err = float(max(np.abs(pose0[:, :3] - f0["R"]).max(), np.abs(pose0[:, 3] - f0["t"]).max()))
     iters = res["iters"].cpu().numpy()
 
+    # BASELINE config 5 at N > 1: every rank takes part (gradient all-reduce); reported by rank 0 in `configs`
+    train_dist = None
+    if world > 1 and not args.no_extra_configs and args.n_pts == 12288 and net is not None:
+        del keep, gathered
+        torch.cuda.empty_cache()
+        train_dist = distributed_train_entry(dev, rank, world)
     if rank == 0:
         total_frames = frames_total * args.steps
         stage_ms = timer.totals_ms()
@@ -786,23 +900,26 @@ def main():
                 rooflines[name] = dict(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
                                        frac=gbs / PEAK_HBM_GBS, traffic=None, ms_per_step=op_step[name],
                                        algorithmic_bytes_per_frame=alg[name])
-        # the pair-scanning ops move kilobytes: their bound is VALU issue.  `achieved` counts the REFERENCE's
-        # pair evaluations (what a brute-force kernel must do); the grid / cell kernels skip most of them exactly,
-        # which is why a fraction can exceed what the CUs they occupy could issue
+        # The pair-scanning ops move kilobytes: what bounds them is VALU issue / latency.  The grid (ball query, three_nn)
+        # and cell-culled (FPS) kernels EXECUTE a few per cent of the reference's brute-force pair evaluations (the rest is
+        # excluded exactly), so a ratio of the reference's pair count to an issue-rate peak is not a roofline fraction
+        # (it exceeded 1 in round 4): `achieved` is stated in reference pairs per second as a speed, `frac` is null, and
+        # the HBM view above (algorithmic bytes / time) is the only fraction reported for them.
         pairs = pair_evals_per_frame(args.n_pts)
         for name in ("fps", "three_nn", "ball_query"):
             if name in op_step and op_step[name] > 0:
                 gp = pairs[name] * F / (op_step[name] * 1e-3) / 1e9
                 peak = VALU_LANE_INSTR_PER_S / VALU_INSTR_PER_PAIR[name] / 1e9
-                entry = dict(bound="valu", achieved=gp, peak=peak, unit="Gpair/s", frac=gp / peak, traffic=None,
-                             ms_per_step=op_step[name], pair_evals_per_frame=pairs[name],
-                             valu_instr_per_pair=VALU_INSTR_PER_PAIR[name], hbm_view=rooflines.get(name))
+                entry = dict(bound="valu", bound_note="VALU issue / latency; exact culling: most reference pairs are never "
+                             "evaluated, so no fraction of a brute-force bound is claimed", achieved=gp,
+                             peak=None, unit="G reference-pairs/s", frac=None, traffic=None, ms_per_step=op_step[name],
+                             pair_evals_per_frame_reference=pairs[name], valu_instr_per_pair=VALU_INSTR_PER_PAIR[name],
+                             brute_force_issue_bound_gpairs=peak, speed_over_brute_force_issue_bound=gp / peak,
+                             hbm_view=rooflines.get(name))
                 if name == "fps":
-                    # one wave per cloud (csrc/fps_cells.hip): F of the chip's 1024 SIMDs are in use
-                    entry["simds_in_use"] = F
-                    entry["frac_of_simds_in_use"] = gp / (peak * F / 1024.0)
-                    entry["note"] = ("serial in the samples: one wave per cloud; exact spatial culling evaluates ~3 % of "
-                                     "the reference's pairs, so the fraction of the occupied SIMDs' issue rate exceeds 1")
+                    entry["simds_in_use"] = F       # one wave per cloud (csrc/fps_cells.hip): F of the chip's 1024 SIMDs
+                    entry["note"] = ("serial in the samples: one wave per cloud, 0.75 us per sampling round; the cell test "
+                                     "touches ~2 of 64 cells per round (DESIGN 4.1)")
                 rooflines[name] = entry
         if net is not None:
             sa_fl, fp_fl = mlp_flops_per_frame(net, scale)
@@ -903,6 +1020,19 @@ def main():
             "meanshift_iters": {"min": int(iters.min()), "max": int(iters.max()), "mean": float(iters.mean())},
             "pose_err_vs_ground_truth": pose_err,
         }
+        # the same vote -> cluster -> pose call with the reference's stop rule run to its end (no winner stop): the
+        # iteration counts the reference would run on THESE frames, and that the poses are the same bits
+        from pvn3d_amd.lib.utils import _vote_engine as _ve
+        saved_k = _ve.DEFAULT_KERNEL
+        _ve.DEFAULT_KERNEL = "nowin" if not saved_k else saved_k + "+nowin"
+        try:
+            res_full = run_postproc(inp, timer_off, args.poll_every)
+        finally:
+            _ve.DEFAULT_KERNEL = saved_k
+        itf = res_full["iters"].cpu().numpy()
+        out["meanshift_iters_reference_stop_rule"] = {"min": int(itf.min()), "max": int(itf.max()), "mean": float(itf.mean())}
+        out["poses_identical_to_reference_stop_rule"] = bool(torch.equal(res["poses"], res_full["poses"])
+                                                             and torch.equal(res["cls_kps"], res_full["cls_kps"]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f0)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
@@ -921,6 +1051,8 @@ def main():
                 if c.get("name") == "heavy_tail_votes":
                     out["value_heavy_tail"] = dict(value=c["frames_per_s"], unit="frames/s (vote -> cluster -> pose only)",
                                                    ms_per_frame=c["ms_per_frame"], meanshift_iters=c["meanshift_iters"])
+        if train_dist is not None:
+            out["configs"] = [train_dist]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -70,17 +70,30 @@ struct S3Args {
   int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
   int bias_off, bias_all;
   float* out; int point_major, ld_out, coff;
-  int dbg;                                      // PVN3D_S3_DBG (tuning): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
+  int dbg;                                      // tuning builds only (-DPVN3D_S3_TUNING, env PVN3D_S3_DBG): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
 };
+
+// The tuning probes change results (synthetic gather values / indices) and write a global buffer: they exist only in a
+// build with -DPVN3D_S3_TUNING (tools/build_probe_lib.sh); the shipped library reads no environment variable and
+// S3_DBG() is a compile-time false.
+#ifdef PVN3D_S3_TUNING
+#define S3_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define S3_DBG(a, bit) false
+#endif
 
 // tuning probe (PVN3D_S3_DBG & 64): cycle stamps of workgroup 0 -- [0..63] MFMA wave 0 (8 stamps per column block),
 // [64..127] loader wave 0 (one stamp per chunk it staged, before / after)
+#ifdef PVN3D_S3_TUNING
 __device__ unsigned long long g_s3_prof[256];
 #define S3_STAMP(IDX)                                                                                   \
   do {                                                                                                  \
     if ((a.dbg & 64) && blockIdx.x == 0 && (IDX) < 128 && (threadIdx.x & 63) == 0)                       \
       g_s3_prof[(IDX)] = __builtin_readcyclecounter();                                                  \
   } while (0)
+#else
+#define S3_STAMP(IDX) do { } while (0)
+#endif
 
 // LDS control words (static): sequence numbers, all monotone
 struct S3Ctl {
@@ -160,7 +173,7 @@ __device__ __forceinline__ void loader_cols(const S3Args& a, LoaderCols<IS_SA>& 
   for (int i = 0; i < 8; ++i) {
     const int gc = min(col0 + cq + 8 * i, a.cols_total - 1);
     if (IS_SA) {
-      lcx.id[i][0] = (a.dbg & 2) ? gc % a.rowsA : a.idx[(size_t)bi * a.cols_total + gc];
+      lcx.id[i][0] = S3_DBG(a, 2) ? gc % a.rowsA : a.idx[(size_t)bi * a.cols_total + gc];
       lcx.w[i][0] = 1.f;
     } else {
       const size_t o = ((size_t)bi * a.cols_total + gc) * 3;
@@ -184,7 +197,7 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<I
     float4 v[8];
     if (IS_SA || !fromA) {
       // one source row per column: SA neighbour index / FP the unknown point itself
-      if (a.dbg & 1) {
+      if (S3_DBG(a, 1)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = make_float4(0.25f * lcx.id[i][0], 1.f, 2.f, 3.f);
       } else {
@@ -598,7 +611,7 @@ struct S3Consumer {
     f32x16 acc[NMAX][2];
     uint4 R[4][NMAX][3];           // weight-fragment ring of the layers >= 1 (layer 0 has its own)
     int boff = 0;
-    const int pb = wave == 0 ? blk_no * 8 : 1 << 20;
+    [[maybe_unused]] const int pb = wave == 0 ? blk_no * 8 : 1 << 20;
     S3_STAMP(pb + 0);
     {
       const int lane = fresh_lane();
@@ -783,7 +796,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
       if (a.ring_off == 0 && blocks_done > 0) lds_wait_ge(&ctl.blk, blocks_done);
       // first local chunk with (base + lc) % 4 == j
       for (int lc = (int)((j - base) & (S3_RING - 1)); lc < n_chunks; lc += S3_RING) {
-        const int pl = j == 0 ? 64 + 3 * (int)uses : 1 << 20;
+        [[maybe_unused]] const int pl = j == 0 ? 64 + 3 * (int)uses : 1 << 20;
         S3_STAMP(pl);
         lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
         S3_STAMP(pl + 1);
@@ -859,10 +872,13 @@ bool s3_plan(S3Args& a) {
 
 int s3_launch(S3Args& a, int sig, hipStream_t st) {
   if (!s3_plan(a)) return -1;
+  a.dbg = 0;
+#ifdef PVN3D_S3_TUNING
   {
     const char* e = getenv("PVN3D_S3_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
+#endif
   const size_t lds = (size_t)a.bias_off + (size_t)a.bias_all * 4;
   a.bpf = pvn3d_ceil_div(a.cols_total, S3_COLS);
   a.n_blocks = a.bpf * a.n_frames;
@@ -906,9 +922,11 @@ bool s3_fill(S3Args* a, int n_layers, const int* dims, const void* const* w, con
 
 }  // namespace
 
+#ifdef PVN3D_S3_TUNING
 extern "C" int pvn3d_debug_s3_prof_read(unsigned long long* host256) {
   return (int)hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_s3_prof), sizeof(unsigned long long) * 256);
 }
+#endif
 
 // 1: the split-bf16 family takes this shape; 0: use pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp (fp32 MFMA).
 // c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.

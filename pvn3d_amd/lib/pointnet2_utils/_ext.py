@@ -584,8 +584,9 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
         pre, wa = packed.precontracted(C2)
         if lib.pvn3d_mlp_split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
             cache = getattr(packed, "_pre_s16", None)
-            if cache is None:
-                cache = packed._pre_s16 = _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2))
+            if cache is None or cache[0] != C2:            # keyed on the split point like PackedMLP.precontracted()
+                cache = packed._pre_s16 = (C2, _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2)))
+            cache = cache[1]
             S, n_out = _fused_mlp._slabs(C2), cache.size(0)
             xs = torch.empty((B * m * S * 96,), dtype=torch.uint8, device=known_feats.device)
             z = torch.empty((B, m, n_out), dtype=torch.float32, device=known_feats.device)

@@ -75,7 +75,7 @@ class GraphedFramePoses(object):
     frame per call (test_mini_batch_size = 1, pvn3d/common.py:41), where the ~100 launches and three host polls of the
     call, not the GPU, set its latency.
 
-        g = GraphedFramePoses("ycb", pcld, mask, ctr_of, pred_kp_of, n_cls=22)        # batched tensors (F, N, ...)
+        g = GraphedFramePoses("ycb", pcld, mask, ctr_of, pred_kp_of, n_cls=22)        # tensors (1, N, ...): ONE YCB frame ("lm": F frames)
         res = g(pcld, mask, ctr_of, pred_kp_of)                                      # the engine dict, like cal_batch_poses
 
     The captured sequence enqueues at most `async_limit` MeanShift iterations per fit batch and no host poll; fits that
@@ -86,6 +86,11 @@ class GraphedFramePoses(object):
     def __init__(self, kind, pclds, masks, ctr_ofs, pred_kp_ofs, n_cls, use_ctr=True, use_ctr_clus_flter=None, obj_id=None,
                  async_limit=8, warmup=2):
         assert kind in ("lm", "ycb") and pclds.is_cuda
+        if kind == "ycb" and pclds.dim() == 3 and pclds.size(0) != 1:
+            # several YCB frames take their instance list from the masks through a host read (torch.nonzero in
+            # frames_pose_multi_class): not capturable, and a replay would keep the capture's list.  One frame instantiates
+            # every class slot instead, which is a fixed launch sequence.
+            raise ValueError("GraphedFramePoses('ycb', ...) captures ONE frame per call (got %d)" % pclds.size(0))
         self.kind, self.n_cls, self.use_ctr, self.obj_id = kind, n_cls, use_ctr, obj_id
         self.flt = (kind == "ycb") if use_ctr_clus_flter is None else use_ctr_clus_flter
         self.async_limit = async_limit

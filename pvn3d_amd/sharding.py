@@ -104,11 +104,17 @@ class OverlappedGradientReducer(object):
     this step, which therefore never completed -- waits, averages and writes the results back into ``.grad``.
 
         red = OverlappedGradientReducer(model.parameters(), group=group)     # once
-        loss.backward(); red.finalize(); optimizer.step()                     # every step
+        red.arm(); loss.backward(); red.finalize(); optimizer.step()          # every step
+
+    The hooks stay on the parameters but only act between ``arm()`` and ``finalize()``: a backward outside a training
+    step (eval-time gradients, a loop that exchanges with ``all_reduce_gradients``) issues no collective, so ranks
+    cannot be left with unmatched all-reduces.  A second backward inside one armed window (gradient accumulation) is
+    supported: a bucket whose all-reduce had already been issued when more gradient arrived is exchanged again from
+    the accumulated ``.grad`` at ``finalize()`` (the early copy is waited for and dropped).
     """
 
     def __init__(self, parameters, bucket_bytes=64 << 20, group=None, average=True):
-        self.group, self.average = group, average
+        self.group, self.average, self.bucket_bytes = group, average, bucket_bytes
         params = [p for p in parameters if p.requires_grad]
         params.reverse()
         self.buckets, cur, cur_bytes = [], [], 0
@@ -127,13 +133,21 @@ class OverlappedGradientReducer(object):
                 self._bucket_of[id(p)] = bi
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self.launched_during_backward = 0
+        self._armed = False
         self._reset()
 
     def _reset(self):
         self._ready = [0] * len(self.buckets)
         self._issued = [False] * len(self.buckets)
-        self._pending = []                  # (work, flat, params with a gradient)
+        self._dirty = [False] * len(self.buckets)
+        self._pending = []                  # (work, flat, params with a gradient, bucket index)
         self._in_backward = True
+
+    def arm(self):
+        """The next backward() exchanges its buckets as they complete; ``finalize()`` ends the window."""
+        self._reset()
+        self._armed = True
+        return self
 
     def _issue(self, bi):
         self._issued[bi] = True
@@ -142,27 +156,38 @@ class OverlappedGradientReducer(object):
             return
         flat = torch.cat([p.grad.reshape(-1) for p in bk])
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, flat, bk))
+        self._pending.append((work, flat, bk, bi))
         if self._in_backward:
             self.launched_during_backward += 1
 
     def _on_grad(self, p):
+        if not self._armed:
+            return
         bi = self._bucket_of[id(p)]
         self._ready[bi] += 1
-        if self._ready[bi] == len(self.buckets[bi]) and not self._issued[bi]:
+        if self._issued[bi]:
+            self._dirty[bi] = True          # more gradient arrived after the bucket's copy was sent (accumulation)
+        elif self._ready[bi] == len(self.buckets[bi]):
             self._issue(bi)
 
     def finalize(self):
         """Call after backward(): issue the remaining buckets, wait for all, average, write back.  Returns the number
         of buckets that were exchanged."""
+        if not self._armed:
+            raise RuntimeError("OverlappedGradientReducer.finalize() without arm(): no backward was watched")
         self._in_backward = False
+        self._armed = False
         for bi in range(len(self.buckets)):
             if not self._issued[bi]:
                 self._issue(bi)
         ws = dist.get_world_size(self.group)
         n = len(self._pending)
-        for work, flat, bk in self._pending:
+        for work, flat, bk, bi in self._pending:
             work.wait()
+            if self._dirty[bi]:             # the copy predates the last accumulation: exchange the accumulated gradient
+                bk = [p for p in self.buckets[bi] if p.grad is not None]
+                flat = torch.cat([p.grad.reshape(-1) for p in bk])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 flat.div_(ws)
             off = 0
@@ -177,15 +202,17 @@ class OverlappedGradientReducer(object):
         for h in self._handles:
             h.remove()
         self._handles = []
+        self._armed = False
 
 
 def overlapped_reducer(model, bucket_bytes=64 << 20, group=None, skip_single=True):
-    """The model's OverlappedGradientReducer (created on first use, kept on the model), or None when there is no
-    process group / a group of one (nothing to exchange)."""
+    """The model's OverlappedGradientReducer (created on first use, kept on the model; rebuilt when the group or the
+    bucket size changes), or None when there is no process group / a group of one (nothing to exchange).  The caller
+    arms it for one backward: ``red.arm(); loss.backward(); red.finalize()``."""
     if _single(group, skip_single):
         return None
     red = getattr(model, "_pvn3d_grad_reducer", None)
-    if red is None or red.group is not group:
+    if red is None or red.group is not group or red.bucket_bytes != bucket_bytes:
         if red is not None:
             red.remove()
         red = OverlappedGradientReducer(model.parameters(), bucket_bytes=bucket_bytes, group=group)

@@ -95,7 +95,14 @@ def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_
     # gradient buckets are all-reduced from inside backward (post-accumulate-grad hooks): the late layers' buckets are
     # on the wire while the early layers' gradients are still being computed (None: a single process, nothing to do)
     reducer = sharding.overlapped_reducer(net, bucket_bytes=bucket_bytes, group=group)
-    loss.backward()
+    if reducer is not None:
+        reducer.arm()                    # the hooks act for this backward only
+    try:
+        loss.backward()
+    except BaseException:
+        if reducer is not None:
+            reducer._armed = False       # no collective may be issued by a later, unrelated backward
+        raise
     if reducer is not None:
         reducer.finalize()
     optimizer.step()

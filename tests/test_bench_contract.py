@@ -65,6 +65,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r.get("traffic_measured_in_run") is False          # PMC traffic is pasted from a separate profile, and says so
     for name, rr in d["rooflines"].items():
         assert rr["bound"] in ("hbm", "mfma", "valu", "valu_fp32"), name
+        # a roofline fraction is achieved / peak and cannot exceed 1 (round 4 divided the reference's brute-force pair
+        # count by time for kernels that skip most pairs: 2.28); kernels without a defensible peak carry frac = None
+        if os.path.basename(lines[-1]) >= "r05" and rr.get("frac") is not None:
+            assert 0.0 < rr["frac"] <= 1.0, (name, rr["frac"])
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     names = {c["name"] for c in d["configs"]}
@@ -89,6 +93,33 @@ def test_bench_self_launches_its_ranks_when_asked_for_more_than_one_gpu():
     r = subprocess.run([sys.executable, py, "--gpus", "2", "--rendezvous-only"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (r.stderr + r.stdout)
+
+
+def test_bench_config5_train_entry_at_two_ranks_over_gloo():
+    """BASELINE config 5 at N > 1 is launchable: `python bench.py --gpus 2 --train-only` starts its ranks, runs
+    distributed_train_entry on both (gradient buckets all-reduced from inside backward, timing bracketed by barriers, MAX
+    over ranks, the same steps again without the exchange) and rank 0 prints the entry.  Here on CPU over gloo with the
+    stand-in model (the real model has no CPU path); on the GPU box the same command runs the bf16 training step over
+    RCCL.  Replaces train_linemod_pvn3d.py:480 (nn.DataParallel)."""
+    import json
+    import subprocess
+    py = os.path.join(os.path.dirname(bench.__file__), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PVN3D_BENCH_DIST_BACKEND"] = "gloo"
+    env["PVN3D_BENCH_TRAIN_STANDIN"] = "1"
+    r = subprocess.run([sys.executable, py, "--gpus", "2", "--train-only", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    e = d["configs"][0]
+    assert d["n_gpus"] == 2 and e["name"] == "train_step" and e["n_gpus"] == 2 and e["scaling"] == "weak"
+    assert e["backend"] == "gloo" and "STAND-IN" in e["workload"]
+    assert e["gradient_buckets"] >= 2 and e["gradient_bytes_per_step"] == sum(e["bucket_bytes"])
+    assert e["buckets_issued_inside_backward_total"] >= e["steps"]            # at least one bucket per step left during backward
+    assert e["weights_identical_across_ranks_after_steps"] is True
+    assert e["ms_per_step"] > 0 and e["ms_per_step_without_exchange"] > 0 and e["exposed_allreduce_ms"] >= 0
+    assert e["frames_per_s"] == 2 * e["frames_per_gpu_per_step"] * 1e3 / e["ms_per_step"]
 
 
 def test_train_step_algorithmic_work():

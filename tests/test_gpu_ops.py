@@ -1314,3 +1314,69 @@ def test_three_nn_weights_kernel_matches_the_torch_formula(dev, ext):
     want = rec / torch.sum(rec, dim=2, keepdim=True)
     assert torch.allclose(got, want, rtol=2e-6, atol=1e-9)
     assert abs(float(got[0, 0].sum()) - 1.0) < 1e-6 and float(got[0, 0, 0]) > 0.999
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The row-owner movers at the bench batch size (64 frames, XCD frame map, hand-placed vmcnt waits over divergent gathers
+# under store traffic): every backbone level's shape, bit-exact against an independent evaluation of the reference's
+# kernels (group_points_gpu.cu:8-28, interpolate_gpu.cu:72-101) -- torch indexing for all 64 frames, the C oracle on the
+# first and the last frame -- and bit-identical between two runs.
+# ------------------------------------------------------------------------------------------------------------------
+_SA_LEVELS = [(12288, 2048, 6, 0.0175, 0.025), (2048, 1024, 96, 0.025, 0.05), (1024, 512, 256, 0.05, 0.1),
+              (512, 128, 512, 0.1, 0.2)]                       # (n, npoint, C_in, r0, r1), lib/pvn3d.py:67-111
+_FP_LEVELS = [(1024, 128, 512), (512, 512, 1024), (512, 1024, 2048), (256, 2048, 12288)]   # (C2, m known, n unknown), :114-118
+
+
+def _bench_batch_xyz(n, dev, B=64):
+    base = clouds(500 + n, 8, n, 0.1)
+    return T(np.tile(base, (B // 8, 1, 1)), dev)
+
+
+@pytest.mark.parametrize("n,m,c,r0,r1", _SA_LEVELS)
+def test_group_ops_bit_exact_at_the_bench_batch_size(ext, orc, dev, n, m, c, r0, r1):
+    B = 64
+    xyz = _bench_batch_xyz(n, dev)
+    new_xyz = xyz[:, :m].contiguous()
+    torch.manual_seed(n)
+    feats = torch.randn(B, c, n, device=dev)
+    i0, i1 = ext.ball_query_pair(new_xyz, xyz, r0, 16, r1, 32)
+    g0, g1 = ext.group_xyz_features_pair(xyz, new_xyz, feats, i0, i1)
+    h0, h1 = ext.group_xyz_features_pair(xyz, new_xyz, feats, i0, i1)
+    assert torch.equal(g0, h0) and torch.equal(g1, h1)                       # two runs, identical bits
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    for idx, got in ((i0, g0), (i1, g1)):
+        ns = idx.size(2)
+        flat = idx.long().reshape(B, 1, m * ns)
+        want_f = torch.gather(feats, 2, flat.expand(-1, c, -1)).reshape(B, c, m, ns)
+        want_x = torch.gather(xyz_t, 2, flat.expand(-1, 3, -1)).reshape(B, 3, m, ns) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        assert torch.equal(got[:, 3:], want_f) and torch.equal(got[:, :3], want_x), "ns = %d" % ns
+        # the plain operator on the same index list (the reference's own call, pointnet2_utils.py:193-241)
+        plain = ext.group_points(feats, idx)
+        assert torch.equal(plain, want_f) and torch.equal(plain, ext.group_points(feats, idx))
+        for f in (0, B - 1):                                                 # anchored on the C oracle
+            o = orc.group_points(feats[f:f + 1].cpu().numpy(), idx[f:f + 1].cpu().numpy())
+            assert np.array_equal(plain[f:f + 1].cpu().numpy(), o)
+        del want_f, want_x, plain
+
+
+@pytest.mark.parametrize("c2,m,n", _FP_LEVELS)
+def test_three_interpolate_bit_exact_at_the_bench_batch_size(ext, orc, dev, c2, m, n):
+    B = 64
+    unknown = _bench_batch_xyz(n, dev)
+    known = unknown[:, :m].contiguous()
+    torch.manual_seed(m)
+    pts = torch.randn(B, c2, m, device=dev)
+    d2, idx = ext.three_nn(unknown, known)
+    w = ext.three_nn_weights(d2)
+    got = ext.three_interpolate(pts, idx, w)
+    assert torch.equal(got, ext.three_interpolate(pts, idx, w))              # two runs, identical bits
+    # interpolate_gpu.cu:72-101: p[i0] * w0 + p[i1] * w1 + p[i2] * w2, one rounding per operation, in this order
+    li = idx.long()
+    want = None
+    for t in range(3):
+        g = torch.gather(pts, 2, li[:, :, t].unsqueeze(1).expand(-1, c2, -1)) * w[:, :, t].unsqueeze(1)
+        want = g if want is None else want + g
+    assert torch.equal(got, want)
+    for f in (0, B - 1):
+        o = orc.three_interpolate(pts[f:f + 1].cpu().numpy(), idx[f:f + 1].cpu().numpy(), w[f:f + 1].cpu().numpy())
+        assert np.array_equal(got[f:f + 1].cpu().numpy(), o)

@@ -178,17 +178,34 @@ def _overlap_worker(rank, ws, port, q):
     red = OverlappedGradientReducer(params, bucket_bytes=6000)  # several buckets
     in_flight = []
     h = net[0].weight.register_hook(lambda g: in_flight.append(red.launched_during_backward))   # first layer: last gradient
+    backward()                                                  # not armed: the hooks must not issue anything
+    idle = red.launched_during_backward == 0 and not red._pending
+    red.arm()
     backward()
     h.remove()
     during = red.launched_during_backward
     n = red.finalize()
     got = [p.grad.clone() for p in net.parameters()]
     same = all(torch.equal(a, b) for a, b in zip(got, want))    # same buckets, same summation: identical bits
+    red.arm()
     backward()                                                  # a second step reuses the reducer
     n2 = red.finalize()
     same2 = all(torch.equal(p.grad, b) for p, b in zip(net.parameters(), want))
-    q.put((rank, same and same2, len(red.buckets), n, n2, during, in_flight[0] if in_flight else -1,
-           unused.grad is None))
+    # gradient accumulation inside one armed window: two backward passes, then ONE exchange of the accumulated gradient
+    for p in params:
+        p.grad = None
+    red.arm()
+    ((net(x) - y) ** 2).mean().backward()
+    ((net(x) - y) ** 2).mean().backward()
+    red.finalize()
+    acc_ok = all(torch.allclose(p.grad, 2 * b, rtol=1e-6, atol=1e-7) for p, b in zip(net.parameters(), want))
+    try:
+        red.finalize()
+        unarmed_raises = False
+    except RuntimeError:
+        unarmed_raises = True
+    q.put((rank, same and same2 and idle and acc_ok and unarmed_raises, len(red.buckets), n, n2, during,
+           in_flight[-1] if in_flight else -1, unused.grad is None))
     dist.barrier()
     dist.destroy_process_group()
 

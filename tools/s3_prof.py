@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase timeline of workgroup 0 of the split-bf16 SA level-2 kernel (PVN3D_S3_DBG & 64 stamps, csrc/sa_mlp_split.hip)."""
+"""Phase timeline of workgroup 0 of the split-bf16 SA level-2 kernel (PVN3D_S3_DBG & 64 stamps, csrc/sa_mlp_split.hip).
+Needs the tuning build: tools/build_probe_lib.sh, then PVN3D_HIP_LIB=tools/libpvn3d_probe.so python tools/s3_prof.py"""
 import ctypes
 import os
 import sys
