@@ -342,7 +342,7 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
         assert c["pvn3d_fp_interp_mlp_split"] == 2 and c["pvn3d_fp_interp_mlp"] == 0
         assert c["pvn3d_split_gemm"] == 2 + 1 + 3 + 3 and c["pvn3d_split_rows"] == 2 + 1 + 2 + 2
         assert not any(k.startswith("pvn3d_sb_") for k in spy_sb.calls)
-    worst = {}
+    worst, worst_proj, proj_by_level = {}, 0.0, {}
     for name in LEVELS:
         t = feats[name].double()                                              # (B, C, n)
         cols = torch.from_numpy(z["%s_cols" % name].astype(np.int64)).to(dev)
@@ -357,15 +357,21 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
             for got, proj, terms in ((tc[i], "chan", t.shape[2]), (tp[i], "pt", t.shape[1])):
                 want = z["%s_%s_sum" % (name, proj)][f].astype(np.float64)
                 mass = z["%s_%s_abs" % (name, proj)][f].astype(np.float64)
-                # element errors <= 1e-5 of the scale adding up like a random walk + 1e-6 of the summed magnitude (the
-                # reference's own fp32-vs-fp64 distance; the point sums are stored as float32: 6e-8 of theirs)
-                bound = 1e-5 * scale * np.sqrt(terms) + 1.2e-6 * mass
-                assert np.all(np.abs(got - want) <= bound), "%s frame %d %s-sum projection" % (name, i, proj)
+                # Every element enters one channel sum and one point sum, so a wrong element anywhere shows.  Bound:
+                # element errors <= 1e-5 of the scale adding up like a random walk, plus 5e-6 of the summed magnitude
+                # for the part of the fp32 rounding that does NOT average out over a sum (the reference's own fp32 run
+                # is 1e-6 of it from its fp64 run; the three-piece bf16 products drop terms of one sign, < 2^-24 of
+                # each product; measured here: up to 3e-6 on the split-bf16 levels) -- a single element off by 1e-2 of the scale is ten bounds away.
+                bound = 1e-5 * scale * np.sqrt(terms) + 5e-6 * mass
+                ratio = float((np.abs(got - want) / bound).max())
+                worst_proj = max(worst_proj, ratio)
+                proj_by_level[name] = max(proj_by_level.get(name, 0.0), ratio)
+                assert ratio <= 1.0, "%s frame %d %s-sum projection: %.2f bounds" % (name, i, proj, ratio)
         assert e32 <= 1e-4, "%s: %.3g of the output scale vs the reference fp32 run" % (name, e32)
         assert e64 <= 1e-5, "%s: %.3g of the output scale vs the reference code in float64" % (name, e64)
         worst[name] = (e32, e64)
     print("B = %d Pointnet2MSG vs reference module code, rel. max err per level (vs fp32 run, vs fp64 run):" % B,
-          {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()})
+          {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in worst.items()}, "worst projection / bound: %.2f" % worst_proj, {k: "%.2f" % v for k, v in proj_by_level.items()})
 
     # --- the whole forward a second time: every level identical bits (gathers under store traffic, loader waves,
     #     split-GEMM epilogues: any timing-dependent fault shows here; DESIGN 4.7c has the one that was found)
