@@ -255,16 +255,23 @@ def mlp_chain_table(net, scale, frames=64):
     def add(stage, name, dims, cols, is_sa, c_a, c_b, ns):
         from pvn3d_amd.lib.pointnet2_utils import _ext
         arr = (ctypes.c_int * len(dims))(*dims)
-        split = _fused_mlp.MLP_ARITH == "bf16x3" and bool(lib.pvn3d_mlp_split_ok(1 if is_sa else 0, c_a, c_b, ns, len(dims) - 1, arr))
+        args = (1 if is_sa else 0, c_a, c_b, ns, len(dims) - 1, arr)
+        split2 = (_fused_mlp.MLP_ARITH == "fp16x2" and (_ext.SPLIT2_NARROW or dims[1] >= 128)
+                  and bool(lib.pvn3d_mlp_split2_ok(*args)))
+        split = not split2 and _fused_mlp.split_arith() and bool(lib.pvn3d_mlp_split_ok(*args))
         # FP levels 2-3: layer by layer on the split GEMM (csrc/split_gemm.hip).  flops_per_frame stays the
         # reference's formulation (conv over [interp; skip] on the unknown points); the launches execute fewer (the
         # first conv's interpolated half runs over the known points)
-        layerwise = not split and not is_sa and _ext.fp_layerwise_shape_ok(cols * frames, c_b, dims)
+        layerwise = not split and not split2 and not is_sa and _ext.fp_layerwise_shape_ok(cols * frames, c_b, dims)
         fl = 2.0 * sum(a * b for a, b in zip(dims[:-1], dims[1:])) * cols
-        kind = ("bf16x3 split on v_mfma_f32_32x32x16_bf16" + (", layer by layer" if layerwise else "")) if (split or layerwise) \
-            else "fp32 on v_mfma_f32_32x32x2_f32"
-        rows.append(dict(stage=stage, chain=name, dims=list(dims), flops_per_frame=fl, arithmetic=kind,
-                         peak_tflops=PEAK_BF16_MFMA_TFLOPS / 6.0 if (split or layerwise) else PEAK_FP32_MFMA_TFLOPS))
+        if split2:
+            kind, peak = "fp16x2 split on v_mfma_f32_32x32x16_f16 (3 partial products per multiply)", PEAK_BF16_MFMA_TFLOPS / 3.0
+        elif split or layerwise:
+            kind = "bf16x3 split on v_mfma_f32_32x32x16_bf16 (6 partial products)" + (", layer by layer" if layerwise else "")
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        else:
+            kind, peak = "fp32 on v_mfma_f32_32x32x2_f32", PEAK_FP32_MFMA_TFLOPS
+        rows.append(dict(stage=stage, chain=name, dims=list(dims), flops_per_frame=fl, arithmetic=kind, peak_tflops=peak))
 
     for li, mod in enumerate(net.SA_modules):
         m = int(mod.npoint * scale)
@@ -996,9 +1003,11 @@ def main():
         else:
             island = ("Pointnet2MSG forward (4 SA-MSG + 4 FP levels, random-init weights, eval): FPS, gather, "
                       "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP; "
-                      "fp32 operands and results throughout, the contraction on fp32 MFMA (SA levels 0-1) or -- SA levels 2-3, every "
-                      "FP level -- as six exact bf16 x bf16 partial products per multiply on bf16 MFMA (fp32 accuracy: every bit "
-                      "of both operands enters the product; tests pin both to 2e-5 of an fp64 evaluation)")
+                      "fp32 operands and results throughout; the contraction runs on fp32 MFMA (SA level 0), as three exact "
+                      "fp16 x fp16 partial products per multiply on fp16 MFMA with two fp16 pieces per operand (SA levels 1-3, FP "
+                      "levels 0-1; power-of-two range scaling from device-side bounds) or as six bf16 x bf16 partial products "
+                      "with three bf16 pieces (FP levels 2-3 and the pre-contractions, layer by layer); all three are as close "
+                      "to an fp64 evaluation as the fp32 FMA chain (tests: 2e-5 of the output scale, measured 5e-7 - 1e-6)")
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

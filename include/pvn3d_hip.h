@@ -232,6 +232,40 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
                               const float* const* bias_padded, float* out, int out_point_major, int ld_out,
                               void* stream);
 
+/* The two fused chains on the fp16 matrix pipe with TWO pieces per fp32 operand (round 5; csrc/sa_mlp_split.hip, AR = 1):
+ * x s = h + l, h = fp16(x s), l = fp16(x s - h), three partial products wh.xh + wh.xl + wl.xh per multiply accumulated
+ * in fp32 by v_mfma_f32_32x32x16_f16 -- half the matrix-pipe time of the three-piece bf16 form.  A product of two fp16
+ * numbers is exact in fp32; the pieces carry >= 20 bits of each operand and the dropped wl.xl is below 2^-20 of the
+ * product; measured against fp64 (tools/mfma_fp16x2_bench.hip) the results are as close as the fp32 FMA chain's
+ * (5.5e-7 vs 6.2e-7 of the output scale at K = 512): what remains is the fp32 accumulation's rounding, not the operands'.
+ * fp16's 5 exponent bits are handled by exact power-of-two scales: the weights' (host, sw below), the layer-0 input's
+ * from a bound on |input| that the kernel reads from DEVICE memory, the hidden layers' from the rigorous bound
+ * B' = ||W||_inf B + max|b|; every scale is undone exactly where accumulators leave a layer.
+ * Arguments as the _split entry points, except
+ *   w_split2[l]   DEVICE int16[ceil(K/16)][ceil(M/32)][2][64][8]: piece 0 = fp16(sw_l W'), piece 1 = fp16(sw_l W' - piece 0)
+ *                 (round to nearest), same (slab, mt, piece, lane, j) order as w_split;
+ *   layer_meta    HOST float[3 * n_layers]: per layer sw_l (a power of two with max|sw_l W'| in [2^13, 2^14]),
+ *                 ||W'||_inf (largest row sum of |W'|, true weights), max|bias|;
+ *   *_absmax      DEVICE float: a bound on |x| over the row table it names (pvn3d_absmax); SA: xyz_absmax bounds the
+ *                 coordinates of `xyz` (the relative coordinates are then within twice that); FP: unknown_absmax may be
+ *                 NULL when c1 == 0.  The bounds must hold: a larger value costs nothing measurable, a smaller one
+ *                 saturates operands at 65504 / scale.
+ * pvn3d_mlp_split2_ok answers pvn3d_mlp_split_ok's question for these kernels (smaller LDS footprint; one more chain
+ * shape: SA level 1).  pvn3d_absmax: *out_max = max(*out_max, max |src[r][ch]|, r < rows, ch < c) as an atomic max on
+ * the bit pattern -- set *out_max to 0 (or to a previous bound) before the call. */
+int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);
+int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                                const float* features_pm, int ld_feat, const int* idx, int n_layers,
+                                const int* dims_host, const void* const* w_split2, const float* const* bias_padded,
+                                const float* layer_meta, const float* features_absmax, const float* xyz_absmax,
+                                float* out_pm, int ld_out, int out_coff, void* stream);
+int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                               const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                               int n_layers, const int* dims_host, const void* const* w_split2,
+                               const float* const* bias_padded, const float* layer_meta, const float* known_absmax,
+                               const float* unknown_absmax, float* out, int out_point_major, int ld_out, void* stream);
+int pvn3d_absmax(long long rows, int c, const float* src, int ld_src, float* out_max, void* stream);
+
 /* Layer-by-layer split-bf16 SharedMLP for chains whose hidden layer is too wide for the fused kernel (FP levels 2-3 of
  * PVN3D's backbone, lib/pvn3d.py:114-118; the module code is pointnet2_modules.py:188-206) -- csrc/split_gemm.hip.
  * "s16" layout of a matrix [rows][K]: rows x slabs (= 16 k each) x 3 pieces x 16 bf16, i.e. entry (r, k, piece) at

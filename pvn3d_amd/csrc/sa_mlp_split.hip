@@ -34,12 +34,31 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
+
+// Arithmetic of a chain kernel (template parameter AR):
+//   0  bf16 x 3: three bf16 pieces per fp32 operand, six partial products per 16-k slab (header comment above);
+//   1  fp16 x 2 (round 5): TWO fp16 pieces per operand, x s = h + l with h = fp16(x s) and l = fp16(x s - h) (both
+//      truncating; weights rounded to nearest on the host), THREE partial products wh.xh + wh.xl + wl.xh on
+//      v_mfma_f32_32x32x16_f16 -- half the matrix-pipe time and two thirds of the LDS bytes of (0).  An fp16 x fp16
+//      product is exact in fp32 (11 + 11 significant bits), the two pieces carry >= 20 bits of the operand and the
+//      dropped wl.xl is below 2^-20 of the product; measured (tools/mfma_fp16x2_bench.hip, 256 tiles, K = 512 / 1536,
+//      against fp64): max error 5.5e-7 / 9.2e-7 of the output scale vs 6.2e-7 / 1.0e-6 for the fp32 FMA chain and
+//      8.6e-7 / 1.7e-6 for (0) -- the error of all three is the fp32 ACCUMULATION's, not the operands'.
+//      fp16 has 5 exponent bits, so every operand is scaled by a power of two (exact) into its range: weights by a
+//      per-layer sw (host), the layer-0 input by s_0 = 2^14 / 2^ceil(log2 B_0) with B_0 a bound on |input| read from
+//      device memory (abs-max of the feature tables, written by pvn3d_absmax), hidden layers by the rigorous bound
+//      B_{l+1} = ||W_l||_inf B_l + max|b_l| (host constants).  A loose bound costs nothing that matters: values far
+//      below the bound lose low-piece bits against an ABSOLUTE floor of 2^-38 of the bound.  Scales are undone exactly
+//      (powers of two) where a layer's accumulators leave: results differ from (0) only in rounding.
 
 constexpr int S3_COLS = 64;
 constexpr int S3_KC = 32;                       // input channels per layer-0 chunk (two 16-k slabs)
 constexpr int S3_CS = 80;                       // bytes per column of a chunk buffer (64 + 16: 16 x odd)
 constexpr int S3_CPS = S3_COLS * S3_CS;         // bytes per piece plane of a chunk buffer
-constexpr int S3_CHUNK = 3 * S3_CPS;            // 15360 bytes
+constexpr int s3_np(int ar) { return ar == 1 ? 2 : 3; }                 // pieces per operand
+constexpr int s3_chunk(int ar) { return s3_np(ar) * S3_CPS; }           // bytes of one chunk buffer (15360 / 10240)
 constexpr int S3_RING = 4;                      // chunk buffers = loader waves
 constexpr int S3_NWC = 4;                       // MFMA (consumer) waves
 constexpr int S3_NWL = 4;                       // loader waves
@@ -70,6 +89,10 @@ struct S3Args {
   int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
   int bias_off, bias_all;
   float* out; int point_major, ld_out, coff;
+  // fp16 x 2 only: per-layer weight scale (power of two), ||W_l||_inf and max|b_l| of the true (folded) weights, and the
+  // device-side bounds of the layer-0 input: B_0 = max(*bound_a, mul_b * *bound_b, 1e-30)
+  float sw[S3_MAX_LAYERS], wnorm[S3_MAX_LAYERS], bmax[S3_MAX_LAYERS];
+  const float* bound_a; const float* bound_b; float mul_b;
   int dbg;                                      // tuning builds only (-DPVN3D_S3_TUNING, env PVN3D_S3_DBG): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
 };
 
@@ -140,6 +163,64 @@ __device__ __forceinline__ void s3_block_map(const S3Args& a, int q, int& bi, in
   }
 }
 
+__device__ __forceinline__ void split4(const float (&x)[4], uint2& h, uint2& m, uint2& l);
+
+// ---- fp16 x 2: the power-of-two scales of a chain, computed by every thread from the device-side input bound ----------
+struct S3Scales {
+  float s_in[S3_MAX_LAYERS];      // scale of layer l's input (activations)
+  float bias_mul[S3_MAX_LAYERS];  // sw_l * s_in[l]: what the layer's accumulators carry
+  float next_mul[S3_MAX_LAYERS];  // s_in[l + 1] / bias_mul[l]: accumulator -> next layer's input (last layer: 1 / bias_mul)
+};
+__device__ __forceinline__ float s3_pow2_scale(float bound) {      // largest power of two s with bound * s <= 2^14
+  int e;
+  (void)frexpf(fmaxf(bound, 1e-30f), &e);                          // bound = m 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 14 - e);
+}
+__device__ __forceinline__ S3Scales s3_scales(const S3Args& a) {
+  S3Scales sc;
+  float B = a.bound_a ? *a.bound_a : 1.f;
+  if (a.bound_b) B = fmaxf(B, a.mul_b * *a.bound_b);
+#pragma unroll
+  for (int l = 0; l < S3_MAX_LAYERS; ++l) {
+    if (l < a.n_layers) {
+      sc.s_in[l] = s3_pow2_scale(B);
+      sc.bias_mul[l] = a.sw[l] * sc.s_in[l];
+      B = (a.wnorm[l] * B + a.bmax[l]) * 1.01f;                    // |y| <= ||W||_inf max|x| + max|b| (+ rounding slack)
+    } else {
+      sc.s_in[l] = 1.f; sc.bias_mul[l] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < S3_MAX_LAYERS; ++l)
+    sc.next_mul[l] = l + 1 < a.n_layers ? sc.s_in[l + 1] / sc.bias_mul[l] : 1.f / sc.bias_mul[l];
+  return sc;
+}
+// two truncated fp16 pieces of four (already scaled) fp32 values: h = rtz(x), l = rtz(x - h)
+__device__ __forceinline__ void split4h(const float (&x)[4], uint2& h, uint2& l) {
+  const fp16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]), h23 = __builtin_amdgcn_cvt_pkrtz(x[2], x[3]);
+  const fp16x2_t l01 = __builtin_amdgcn_cvt_pkrtz(x[0] - (float)h01[0], x[1] - (float)h01[1]);
+  const fp16x2_t l23 = __builtin_amdgcn_cvt_pkrtz(x[2] - (float)h23[0], x[3] - (float)h23[1]);
+  h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
+  l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+}
+// store four consecutive-k values as pieces: planes `plane` bytes apart
+template <int AR>
+__device__ __forceinline__ void s3_put4(char* d, size_t plane, const float (&x)[4], float mul) {
+  if (AR == 1) {
+    const float y[4] = {x[0] * mul, x[1] * mul, x[2] * mul, x[3] * mul};
+    uint2 h, l;
+    split4h(y, h, l);
+    *reinterpret_cast<uint2*>(d) = h;
+    *reinterpret_cast<uint2*>(d + plane) = l;
+  } else {
+    uint2 h, m, l;
+    split4(x, h, m, l);
+    *reinterpret_cast<uint2*>(d) = h;
+    *reinterpret_cast<uint2*>(d + plane) = m;
+    *reinterpret_cast<uint2*>(d + 2 * plane) = l;
+  }
+}
+
 // ---- exact 3-way split of four fp32 values (consecutive k) into three packed bf16x4 ---------------------------------
 __device__ __forceinline__ void split4(const float (&x)[4], uint2& h, uint2& m, uint2& l) {
   unsigned hb[4], mb[4], lb[4];
@@ -183,9 +264,9 @@ __device__ __forceinline__ void loader_cols(const S3Args& a, LoaderCols<IS_SA>& 
   }
 }
 
-template <bool IS_SA>
+template <bool IS_SA, int AR>
 __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<IS_SA>& lcx, char* slot, int bi, int col0,
-                                             int lc /*local chunk*/, int lane) {
+                                             int lc /*local chunk*/, int lane, float s0) {
   const int g = lane & 7, cq = lane >> 3;
   const int n_full = a.nA + a.nB;
   if (lc < n_full) {
@@ -230,12 +311,7 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<I
       const int c = cq + 8 * i;
       const bool ok = col0 + c < a.cols_total;
       const float x[4] = {ok ? v[i].x : 0.f, ok ? v[i].y : 0.f, ok ? v[i].z : 0.f, ok ? v[i].w : 0.f};
-      uint2 h, m, l;
-      split4(x, h, m, l);
-      char* d = slot + c * S3_CS + 8 * g;
-      *reinterpret_cast<uint2*>(d) = h;
-      *reinterpret_cast<uint2*>(d + S3_CPS) = m;
-      *reinterpret_cast<uint2*>(d + 2 * S3_CPS) = l;
+      s3_put4<AR>(slot + c * S3_CS + 8 * g, S3_CPS, x, s0);
     }
   } else {
     // tail chunk: one 16-k slab, channels [0, tail_w) real, the rest zero.  lane -> column lane, rows 0..15
@@ -259,12 +335,7 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<I
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float y[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-      uint2 h, m, l;
-      split4(y, h, m, l);
-      char* d = slot + lane * S3_CS + 8 * q;
-      *reinterpret_cast<uint2*>(d) = h;
-      *reinterpret_cast<uint2*>(d + S3_CPS) = m;
-      *reinterpret_cast<uint2*>(d + 2 * S3_CPS) = l;
+      s3_put4<AR>(slot + lane * S3_CS + 8 * q, S3_CPS, y, s0);
     }
   }
 }
@@ -282,26 +353,26 @@ struct WSrc {
   int last;                 // last slab
 };
 
-// B fragments of one slab: base = plane 0, this lane's column (+ column tile for CS), k offset of the slab
-template <bool CS>
-__device__ __forceinline__ void b_load(bf16x8 (&b)[CS ? 1 : 2][3], const char* base, int ps, int ct_bytes) {
-#pragma unroll
-  for (int c = 0; c < (CS ? 1 : 2); ++c)
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-      b[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (size_t)pc * ps + (size_t)c * ct_bytes));
-}
-
-// the six partial products of one slab, smallest terms first; consecutive MFMAs hit different accumulators
-template <int NTC, int NT, bool CS, int NR>
-__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][3],
-                                        const bf16x8 (&b)[CS ? 1 : 2][3]) {
+// the partial products of one slab (six bf16 / three fp16), smallest terms first; consecutive MFMAs hit different
+// accumulators.  Fragments travel as uint4 (eight 16-bit pieces of consecutive k).
+template <int AR, int NTC, int NT, int NR>
+__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][s3_np(AR)], const uint4 (&b)[2][s3_np(AR)]) {
+  if (AR == 1) {
 #define S3_MM(PA, PB)                                                                                                  \
-  _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < (CS ? 1 : 2); ++c)             \
-      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t][PA]), b[c][PB], acc[t][c], 0, 0, 0)
-  S3_MM(0, 2); S3_MM(2, 0); S3_MM(1, 1);
-  S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
+  _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
+      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t][PA]),                          \
+                                                         __builtin_bit_cast(f16x8, b[c][PB]), acc[t][c], 0, 0, 0)
+    S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
 #undef S3_MM
+  } else {
+#define S3_MM(PA, PB)                                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
+      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t][PA]),                        \
+                                                          __builtin_bit_cast(bf16x8, b[c][PB]), acc[t][c], 0, 0, 0)
+    S3_MM(0, 2); S3_MM(2, 0); S3_MM(1, 1);
+    S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
+#undef S3_MM
+  }
 }
 
 __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ sb, int half) {
@@ -317,8 +388,10 @@ __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ 
 // PASSES: the last layer's row tiles are worked off in PASSES rounds of 4 * NLAST tiles (512-wide last layers: the
 // accumulators of all 16 tiles would not fit); its input P is only read, so the rounds need no barrier between them,
 // and their max-pool runs on DPP lane shifts instead of LDS patches (P is still being read by the other waves).
-template <bool IS_SA, int N0, int N1, int N2, int PASSES>
+template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR>
 struct S3Consumer {
+  static constexpr int NP = s3_np(AR);
+  static constexpr int CHUNK = s3_chunk(AR);
   static constexpr int NMAX = N0 > N1 ? (N0 > N2 ? N0 : N2) : (N1 > N2 ? N1 : N2);
   static constexpr int NL = N2 > 0 ? 3 : 2;
   const S3Args& a;
@@ -326,6 +399,7 @@ struct S3Consumer {
   char* ring;
   const float* s_bias;
   S3Ctl* ctl;
+  S3Scales sc;             // fp16 x 2: power-of-two scales (all 1 for bf16 x 3)
   int lane_, wave;
   unsigned phase;          // barrier arrivals expected so far
   unsigned chunk_no;       // chunks of this workgroup consumed so far (all blocks)
@@ -336,39 +410,39 @@ struct S3Consumer {
     const int mt_total = (a.M[l] + 31) >> 5;
     WSrc<NTC> w;
     w.sbase = reinterpret_cast<const char*>(a.W[l]);
-    w.sstride = (unsigned)mt_total * 3u * 64u * 16u;
+    w.sstride = (unsigned)mt_total * (unsigned)NP * 64u * 16u;
     w.last = slabs - 1;
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
-      w.voff[t] = ((unsigned)min(tile_base + wave + S3_NWC * t, mt_total - 1) * 192u + (unsigned)lane) * 16u;
+      w.voff[t] = ((unsigned)min(tile_base + wave + S3_NWC * t, mt_total - 1) * (unsigned)(NP * 64) + (unsigned)lane) * 16u;
     return w;
   }
   template <int NTC, int NR>
-  __device__ __forceinline__ void a_load(uint4 (&r)[NR][3], const WSrc<NTC>& w, int slab) const {
+  __device__ __forceinline__ void a_load(uint4 (&r)[NR][NP], const WSrc<NTC>& w, int slab) const {
     const char* sb = w.sbase + (size_t)((unsigned)min(slab, w.last) * w.sstride);      // scalar
 #pragma unroll
     for (int t = 0; t < NTC; ++t)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) r[t][pc] = *reinterpret_cast<const uint4*>(sb + w.voff[t] + pc * 1024);
+      for (int pc = 0; pc < NP; ++pc) r[t][pc] = *reinterpret_cast<const uint4*>(sb + w.voff[t] + pc * 1024);
   }
   // LDS byte addresses of this lane's B fragments: [column tile][piece]; a slab is + 32 bytes (an instruction offset)
   struct BSrc {
-    const char* p[2][3];
+    const char* p[2][NP];
   };
   __device__ __forceinline__ BSrc bsrc(const char* base, int ps, int ct_bytes) const {
     BSrc b;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) b.p[c][pc] = base + (size_t)c * ct_bytes + (size_t)pc * ps;
+      for (int pc = 0; pc < NP; ++pc) b.p[c][pc] = base + (size_t)c * ct_bytes + (size_t)pc * ps;
     return b;
   }
   template <int OFF>
-  __device__ __forceinline__ void b_ld(bf16x8 (&b)[2][3], const BSrc& src) const {
+  __device__ __forceinline__ void b_ld(uint4 (&b)[2][NP], const BSrc& src) const {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) b[c][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(src.p[c][pc] + OFF));
+      for (int pc = 0; pc < NP; ++pc) b[c][pc] = *reinterpret_cast<const uint4*>(src.p[c][pc] + OFF);
   }
   __device__ __forceinline__ void tiles_bias(int l, int (&tile)[NMAX], int n) const {
     const int mt_total = (a.M[l] + 31) >> 5;
@@ -398,17 +472,17 @@ struct S3Consumer {
     const int slabs = 2 * n_full + (tail ? 1 : 0);
     const WSrc<NTC> w = wsrc<NTC>(0, slabs, lane);
     init_acc<NTC>(acc, 0, 0, half);
-    uint4 ringA[4][NTC][3];
+    uint4 ringA[4][NTC][NP];
     a_load<NTC, NTC>(ringA[0], w, 0);
     a_load<NTC, NTC>(ringA[1], w, 1);
     a_load<NTC, NTC>(ringA[2], w, 2);
-    // this lane's fragment addresses in ring slot 0; slot k is + k * S3_CHUNK
+    // this lane's fragment addresses in ring slot 0; slot k is + k * CHUNK
     const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
     const int n_chunks = n_full + (tail ? 1 : 0);
     // Software pipeline over the chunks: the fragments of a chunk's first slab are requested during the previous
     // chunk (after its first slab's MFMAs have been issued, so the ready poll and the LDS round trip run under MFMAs
     // that are already in the pipe); a chunk step therefore starts with b0 in registers.
-    bf16x8 bA[2][3], bB[2][3];            // first-slab fragments of the current / next chunk, second-slab fragments
+    uint4 bA[2][NP], bB[2][NP];           // first-slab fragments of the current / next chunk, second-slab fragments
     {
       const int slot = chunk_no & (S3_RING - 1);
       lds_wait_ge(&ctl->rdy[slot], chunk_no + 1);
@@ -416,7 +490,7 @@ struct S3Consumer {
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * S3_CHUNK;
+        for (int p2 = 0; p2 < NP; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * CHUNK;
       b_ld<0>(bA, bs);
     }
     // one full chunk C = slabs 2C (weight slot U0) and 2C + 1 (slot U0 + 1); NEXT: there is a chunk C + 1 in this block
@@ -425,24 +499,24 @@ struct S3Consumer {
     const unsigned cn_ = chunk_no + (C);                                                               \
     const int slot_ = cn_ & (S3_RING - 1);                                                             \
     BSrc bs_;                                                                                          \
-    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)  \
-        bs_.p[c_][p_] = bs0.p[c_][p_] + slot_ * S3_CHUNK;                                              \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) \
+        bs_.p[c_][p_] = bs0.p[c_][p_] + slot_ * CHUNK;                                                 \
     a_load<NTC, NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
     b_ld<32>(bB, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U0)], bA);                                                   \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0)], bA);                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     a_load<NTC, NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
     if ((C) + 1 < n_chunks) {                                                                          \
       const int slotn_ = (cn_ + 1) & (S3_RING - 1);                                                    \
       lds_wait_ge(&ctl->rdy[slotn_], cn_ + 2);                                                         \
       BSrc bn_;                                                                                        \
-      _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) \
-          bn_.p[c_][p_] = bs0.p[c_][p_] + slotn_ * S3_CHUNK;                                           \
+      _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) _Pragma("unroll") for (int p_ = 0; p_ < NP; ++p_) \
+          bn_.p[c_][p_] = bs0.p[c_][p_] + slotn_ * CHUNK;                                              \
       b_ld<0>(bA, bn_);                                                                                \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, ringA[(U0) + 1], bB);                                               \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0) + 1], bB);                                               \
     lds_signal_add(&ctl->fin[slot_], lane);                                                            \
   } while (0)
     int c = 0;
@@ -457,8 +531,8 @@ struct S3Consumer {
       // the tail chunk's single slab: its fragments are already in bA
       const unsigned cn = chunk_no + n_full;
       const int slot = cn & (S3_RING - 1);
-      if (odd) mm_slab<NTC, NMAX, false>(acc, ringA[2], bA);
-      else mm_slab<NTC, NMAX, false>(acc, ringA[0], bA);
+      if (odd) mm_slab<AR, NTC, NMAX>(acc, ringA[2], bA);
+      else mm_slab<AR, NTC, NMAX>(acc, ringA[0], bA);
       lds_signal_add(&ctl->fin[slot], lane);
     }
     chunk_no += n_full + (tail ? 1 : 0);
@@ -470,7 +544,7 @@ struct S3Consumer {
   // (the ring registers are free then): the ~2k-cycle L2 round trip runs under the store phase instead of heading the
   // layer (short layers -- 8 slabs -- spent a quarter of their time there).
   template <int NTC>
-  __device__ __forceinline__ void preloadA(uint4 (&R)[4][NMAX][3], int l, int lane, int tile_base = 0) const {
+  __device__ __forceinline__ void preloadA(uint4 (&R)[4][NMAX][NP], int l, int lane, int tile_base = 0) const {
     constexpr int RD = NTC >= 3 ? 2 : 4;
     const int slabs = (a.K[l] + 15) >> 4;
     const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
@@ -478,7 +552,7 @@ struct S3Consumer {
     for (int u = 0; u < RD - 1; ++u) a_load<NTC, NMAX>(R[u], w, u);
   }
   template <int NTC>
-  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], uint4 (&R)[4][NMAX][3], int l, int boff, int lane,
+  __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], uint4 (&R)[4][NMAX][NP], int l, int boff, int lane,
                                          int tile_base = 0) {
     const int half = lane >> 5, col = lane & 31;
     const int slabs = (a.K[l] + 15) >> 4;
@@ -486,7 +560,7 @@ struct S3Consumer {
     init_acc<NTC>(acc, l, boff, half, tile_base);
     BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);
     constexpr int RD = NTC >= 3 ? 2 : 4;
-    bf16x8 b[2][2][3];
+    uint4 b[2][2][NP];
     b_ld<0>(b[0], bs);
     // slab S (weight slot U): fragments of slab S + 1 are requested at the offset OFFN from the current bases
 #define S3_SLAB_STEP(S, U, OFFN)                                                                       \
@@ -494,7 +568,7 @@ struct S3Consumer {
     a_load<NTC, NMAX>(R[((U) + RD - 1) % RD], w, (S) + RD - 1);                                        \
     b_ld<(OFFN)>(b[((U) + 1) & 1], bs);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<NTC, NMAX, false>(acc, R[(U) % RD], b[(U) & 1]);                                           \
+    mm_slab<AR, NTC, NMAX>(acc, R[(U) % RD], b[(U) & 1]);                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
     // (the layer's slab count is padded: P holds zero rows up to a multiple of 32 k, and the fragment reads of the
@@ -508,7 +582,7 @@ struct S3Consumer {
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-        for (int p2 = 0; p2 < 3; ++p2) bs.p[c2][p2] += 128;
+        for (int p2 = 0; p2 < NP; ++p2) bs.p[c2][p2] += 128;
     }
     if (s < slabs) S3_SLAB_STEP(s, 0, 32);
     if (s + 1 < slabs) S3_SLAB_STEP(s + 1, 1, 64);
@@ -518,19 +592,14 @@ struct S3Consumer {
 
   // relu(tile) -> three bf16 planes of P: register group g of a tile holds rows mt*32 + 8g + 4*half + 0..3 of the lane's
   // column = four consecutive k of the next layer = one 8-byte store per plane
-  __device__ __forceinline__ void store_tile(const f32x16& acc, int mt, int colx, int lane) {
+  __device__ __forceinline__ void store_tile(const f32x16& acc, int mt, int colx, int lane, float mul) {
     const int half = lane >> 5;
     char* d0 = P + (size_t)colx * a.rs + 64 * mt + 8 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float x[4] = {fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f), fmaxf(acc[4 * g + 2], 0.f),
                           fmaxf(acc[4 * g + 3], 0.f)};
-      uint2 h, m, l;
-      split4(x, h, m, l);
-      char* d = d0 + 16 * g;
-      *reinterpret_cast<uint2*>(d) = h;
-      *reinterpret_cast<uint2*>(d + a.ps) = m;
-      *reinterpret_cast<uint2*>(d + 2 * (size_t)a.ps) = l;
+      s3_put4<AR>(d0 + 16 * g, (size_t)a.ps, x, mul);
     }
   }
   template <int NTC>
@@ -541,8 +610,8 @@ struct S3Consumer {
     for (int t = 0; t < NTC; ++t) {
       const int mt = wave + S3_NWC * t;
       if (mt < mt_total) {
-        store_tile(acc[t][0], mt, col, lane);
-        store_tile(acc[t][1], mt, 32 + col, lane);
+        store_tile(acc[t][0], mt, col, lane, sc.next_mul[l]);
+        store_tile(acc[t][1], mt, 32 + col, lane, sc.next_mul[l]);
       }
     }
   }
@@ -557,6 +626,7 @@ struct S3Consumer {
   __device__ __forceinline__ void pool_dpp_t(const f32x16 (&acc)[2], int mt, int bi, int col0, int lane) {
     const int half = lane >> 5, col = lane & 31;
     const int M = a.M[NL - 1];
+    const float om = AR == 1 ? sc.next_mul[NL - 1] : 1.f;        // accumulator -> output (exact power of two)
     const bool writer = NS == 16 ? (lane & 15) == 15 : (lane & 31) == 31;
 #pragma unroll
     for (int ct = 0; ct < (NS == 64 ? 1 : 2); ++ct) {
@@ -584,11 +654,11 @@ struct S3Consumer {
         for (int g = 0; g < 4; ++g) {
           const int row = mt * 32 + 8 * g + 4 * half;
           if (row + 3 < M) {
-            *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g] * om, v[4 * g + 1] * om, v[4 * g + 2] * om, v[4 * g + 3] * om);
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (row + k < M) o[8 * g + k] = v[4 * g + k];
+              if (row + k < M) o[8 * g + k] = v[4 * g + k] * om;
           }
         }
       }
@@ -609,7 +679,7 @@ struct S3Consumer {
 
   __device__ __forceinline__ void run_block(int bi, int col0) {
     f32x16 acc[NMAX][2];
-    uint4 R[4][NMAX][3];           // weight-fragment ring of the layers >= 1 (layer 0 has its own)
+    uint4 R[4][NMAX][NP];          // weight-fragment ring of the layers >= 1 (layer 0 has its own)
     int boff = 0;
     [[maybe_unused]] const int pb = wave == 0 ? blk_no * 8 : 1 << 20;
     S3_STAMP(pb + 0);
@@ -671,6 +741,7 @@ struct S3Consumer {
     // ---- epilogue on the last layer's accumulators (rows wave + 4 t, both column tiles)
     const int lane = fresh_lane();
     const int half = lane >> 5, col = lane & 31;
+    const float om = AR == 1 ? sc.next_mul[NL - 1] : 1.f;          // accumulator -> output (exact power of two)
     if (IS_SA) {
       // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip;
       // measured against the DPP form of the multi-round kernels: 4.0k vs 7.6k cycles for two tiles)
@@ -715,12 +786,12 @@ struct S3Consumer {
           if (row < M && (ns < 64 || half == 0)) {
             float* o = out + ((size_t)bi * a.m + jbase) * a.ld_out + a.coff + row;
             if (nout <= 2) {
-              if (jbase < a.m) o[0] = __int_as_float(v[0]);
-              if (nout == 2 && jbase + 1 < a.m) o[a.ld_out] = __int_as_float(v[1]);
+              if (jbase < a.m) o[0] = __int_as_float(v[0]) * om;
+              if (nout == 2 && jbase + 1 < a.m) o[a.ld_out] = __int_as_float(v[1]) * om;
             } else {
 #pragma unroll
               for (int q = 0; q < 32; ++q)
-                if (q < nout && jbase + q < a.m) o[(size_t)q * a.ld_out] = __int_as_float(v[q]);
+                if (q < nout && jbase + q < a.m) o[(size_t)q * a.ld_out] = __int_as_float(v[q]) * om;
             }
           }
         }
@@ -737,7 +808,7 @@ struct S3Consumer {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (row + k < M) {
-                const float v0 = fmaxf(acc[t][0][4 * g + k], 0.f), v1 = fmaxf(acc[t][1][4 * g + k], 0.f);
+                const float v0 = fmaxf(acc[t][0][4 * g + k], 0.f) * om, v1 = fmaxf(acc[t][1][4 * g + k], 0.f) * om;
                 if (a.point_major) {
                   if (g0 < a.cols_total) out[((size_t)bi * a.cols_total + g0) * a.ld_out + a.coff + row + k] = v0;
                   if (g1 < a.cols_total) out[((size_t)bi * a.cols_total + g1) * a.ld_out + a.coff + row + k] = v1;
@@ -755,7 +826,7 @@ struct S3Consumer {
   }
 };
 
-template <bool IS_SA, int N0, int N1, int N2, int PASSES>
+template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR>
 __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   // 16-byte aligned dynamic LDS (every fragment read is a ds_read_b128: a base that is only 8-byte aligned -- what a
   // static __shared__ object in front of it produces -- turns each of them into a slow misaligned access); the control
@@ -769,12 +840,23 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < (int)(sizeof(S3Ctl) / 4)) reinterpret_cast<unsigned*>(&ctl)[tid] = 0u;
-  {   // all biases of the chain -> LDS, once per (persistent) workgroup
+  S3Scales sc;
+  if (AR == 1) {
+    sc = s3_scales(a);
+  } else {
+#pragma unroll
+    for (int l = 0; l < S3_MAX_LAYERS; ++l) sc.s_in[l] = sc.bias_mul[l] = sc.next_mul[l] = 1.f;
+  }
+  {   // all biases of the chain -> LDS, once per (persistent) workgroup (fp16 x 2: in the accumulators' scale, exact)
     int off = 0;
-    for (int l = 0; l < a.n_layers; ++l) {
-      const int mp = ((a.M[l] + 31) >> 5) << 5;
-      for (int i = tid; i < mp; i += S3_THREADS) s_bias[off + i] = a.bias[l][i];
-      off += mp;
+#pragma unroll
+    for (int l = 0; l < S3_MAX_LAYERS; ++l) {          // (constant trip count: the scales stay in registers)
+      if (l < a.n_layers) {
+        const int mp = ((a.M[l] + 31) >> 5) << 5;
+        const float bm = sc.bias_mul[l];
+        for (int i = tid; i < mp; i += S3_THREADS) s_bias[off + i] = a.bias[l][i] * bm;
+        off += mp;
+      }
     }
   }
   __syncthreads();          // the only s_barrier: from here on the two roles only meet through LDS words
@@ -783,7 +865,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   if (wave >= S3_NWC) {
     // ------------------------------------------------ loader wave j: slot j, chunks j, j + 4, ...
     const int j = wave - S3_NWC;
-    char* slot = ring + (size_t)j * S3_CHUNK;
+    char* slot = ring + (size_t)j * s3_chunk(AR);
     unsigned uses = 0;                   // how often the slot has been filled
     unsigned base = 0;                   // chunk number of the current block's first chunk
     unsigned blocks_done = 0;
@@ -800,7 +882,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
         S3_STAMP(pl);
         lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
         S3_STAMP(pl + 1);
-        loader_chunk<IS_SA>(a, lcx, slot, bi, bx * S3_COLS, lc, lane);
+        loader_chunk<IS_SA, AR>(a, lcx, slot, bi, bx * S3_COLS, lc, lane, sc.s_in[0]);
         S3_STAMP(pl + 2);
         ++uses;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -810,7 +892,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2, PASSES> c{a, P, ring, s_bias, &ctl, lane, wave, 0u, 0u, 0};
+  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, &ctl, sc, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -829,12 +911,13 @@ bool vec_ok(const float* p, int ld) { return p != nullptr && (ld & 3) == 0 && (r
 // shapes of PVN3D's backbone that gain: SA level 2 (259 -> 128 -> 196 -> 256), SA level 3 (515 -> 256 -> 256 | 384 ->
 // 512: the 16 tiles of the last layer in two rounds), FP level 0 (262 -> 128 -> 128), FP level 1 (608 -> 256 -> 256).
 // -1: no kernel for this chain (the caller keeps the fp32-MFMA kernels of sa_mlp.hip).
-int s3_signature(int is_sa, int n_layers, const int* dims, int nsample) {
+int s3_signature(int is_sa, int n_layers, const int* dims, int nsample, int arith = 0) {
   int n[3] = {0, 0, 0};
   if (n_layers < 2 || n_layers > 3) return -1;
   for (int l = 0; l < n_layers; ++l) n[l] = pvn3d_ceil_div(pvn3d_ceil_div(dims[l + 1], 32), S3_NWC);
   const int sig = n[0] * 100 + n[1] * 10 + n[2];
   if (is_sa) {
+    if (sig == 111 && arith == 1) return sig;       // SA level 1 (99 -> 64 -> 64 | 96 -> 128): pays with fp16 x 2 only
     if (sig == 122) return sig;
     if ((sig == 224 || sig == 234) && nsample >= 16) return sig;      // DPP pooling: whole 16-lane rows per centre
     return -1;
@@ -843,7 +926,7 @@ int s3_signature(int is_sa, int n_layers, const int* dims, int nsample) {
 }
 
 // LDS plan; false when the chain does not fit
-bool s3_plan(S3Args& a) {
+bool s3_plan(S3Args& a, int arith = 0) {
   int kcap = 32, bias_all = 0;
   for (int l = 0; l < a.n_layers; ++l) {
     const int mp = ((a.M[l] + 31) / 32) * 32;
@@ -852,9 +935,9 @@ bool s3_plan(S3Args& a) {
   }
   a.rs = 2 * kcap + 16;                                    // 16 x odd (kcap is a multiple of 32)
   a.ps = S3_COLS * a.rs;
-  size_t p_bytes = (size_t)3 * a.ps;
+  size_t p_bytes = (size_t)s3_np(arith) * a.ps;
   if (a.is_sa) p_bytes = max(p_bytes, (size_t)S3_NWC * 32 * S3_EPAD * 4);
-  const size_t ring_bytes = (size_t)S3_RING * S3_CHUNK;
+  const size_t ring_bytes = (size_t)S3_RING * s3_chunk(arith);
   const size_t bias_bytes = (size_t)bias_all * 4;
   const size_t budget = 160 * 1024 - 256;
   if (p_bytes + ring_bytes + bias_bytes <= budget) {
@@ -870,8 +953,8 @@ bool s3_plan(S3Args& a) {
   return true;
 }
 
-int s3_launch(S3Args& a, int sig, hipStream_t st) {
-  if (!s3_plan(a)) return -1;
+int s3_launch(S3Args& a, int sig, hipStream_t st, int arith = 0) {
+  if (!s3_plan(a, arith)) return -1;
   a.dbg = 0;
 #ifdef PVN3D_S3_TUNING
   {
@@ -889,20 +972,30 @@ int s3_launch(S3Args& a, int sig, hipStream_t st) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  int grid = min(a.n_blocks, cus);
+  // (the narrow fp16 x 2 chain -- signature 111, 122 registers per wave -- fits twice on a CU: two workgroups cover each
+  // other's store / barrier / epilogue phases, which the one-workgroup shape leaves exposed)
+  const int wg_per_cu = (arith == 1 && sig == 111 && 2 * (lds + 512) <= 160 * 1024) ? 2 : 1;
+  int grid = min(a.n_blocks, cus * wg_per_cu);
   if (grid >= 8) grid &= ~7;
+#define S3_GO1(SA, A0, A1, A2, PS, AR)                                                                            \
+  do {                                                                                                            \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR>));            \
+    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR>), dim3(grid), dim3(S3_THREADS), lds, st, a);  \
+  } while (0)
 #define S3_GO(SA, A0, A1, A2, PS)                                                                                 \
   do {                                                                                                            \
-    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2, PS>));                \
-    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2, PS>), dim3(grid), dim3(S3_THREADS), lds, st, a);      \
+    if (arith == 1) S3_GO1(SA, A0, A1, A2, PS, 1);                                                                \
+    else S3_GO1(SA, A0, A1, A2, PS, 0);                                                                           \
   } while (0)
-  if (a.is_sa && sig == 122) S3_GO(true, 1, 2, 2, 1);
+  if (a.is_sa && sig == 111 && arith == 1) S3_GO1(true, 1, 1, 1, 1, 1);
+  else if (a.is_sa && sig == 122) S3_GO(true, 1, 2, 2, 1);
   else if (a.is_sa && sig == 224) S3_GO(true, 2, 2, 2, 2);
   else if (a.is_sa && sig == 234) S3_GO(true, 2, 3, 2, 2);
   else if (!a.is_sa && sig == 110) S3_GO(false, 1, 1, 0, 1);
   else if (!a.is_sa && sig == 220) S3_GO(false, 2, 2, 0, 1);
   else return -1;
 #undef S3_GO
+#undef S3_GO1
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
@@ -930,7 +1023,7 @@ extern "C" int pvn3d_debug_s3_prof_read(unsigned long long* host256) {
 
 // 1: the split-bf16 family takes this shape; 0: use pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp (fp32 MFMA).
 // c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.
-extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host) {
+static int s3_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int arith) {
   if (!dims_host || n_layers < 2 || n_layers > 3) return 0;
   if (c_a <= 0 || (c_a % S3_KC) != 0) return 0;                       // whole 32-channel row-gather chunks
   if (is_sa) {
@@ -938,27 +1031,48 @@ extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int 
   } else if ((c_b % S3_KC) > 8) {
     return 0;                                                         // the tail chunk holds <= 8 channels
   }
-  if (s3_signature(is_sa, n_layers, dims_host, nsample) < 0) return 0;
+  if (s3_signature(is_sa, n_layers, dims_host, nsample, arith) < 0) return 0;
   S3Args a = {};
   a.n_layers = n_layers;
   a.is_sa = is_sa;
   for (int l = 0; l < n_layers; ++l) a.M[l] = dims_host[l + 1];
-  return s3_plan(a) ? 1 : 0;
+  return s3_plan(a, arith) ? 1 : 0;
+}
+extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host) {
+  return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 0);
+}
+// the same question for the fp16 x 2 kernels (two pieces: smaller LDS footprint, one more chain signature)
+extern "C" int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host) {
+  return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 1);
 }
 
-extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz,
-                                          const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
-                                          int n_layers, const int* dims_host, const void* const* w_split,
-                                          const float* const* bias_padded, float* out_pm, int ld_out, int out_coff,
-                                          void* stream) {
+// fp16 x 2: per-layer (sw, ||W||_inf, max|b|) triples + the device-side input bounds -> S3Args; false when malformed
+static bool s3_fill_scales(S3Args* a, int n_layers, const float* layer_meta, const float* bound_a, const float* bound_b,
+                           float mul_b) {
+  if (!layer_meta || !bound_a) return false;
+  for (int l = 0; l < n_layers; ++l) {
+    a->sw[l] = layer_meta[3 * l]; a->wnorm[l] = layer_meta[3 * l + 1]; a->bmax[l] = layer_meta[3 * l + 2];
+    int e = 0;
+    if (!(a->sw[l] > 0.f) || frexpf(a->sw[l], &e) != 0.5f || !(a->wnorm[l] >= 0.f) || !(a->bmax[l] >= 0.f)) return false;
+  }
+  a->bound_a = bound_a; a->bound_b = bound_b; a->mul_b = mul_b;
+  return true;
+}
+
+static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
+                       const float* features_pm, int ld_feat, const int* idx, int n_layers, const int* dims_host,
+                       const void* const* w_split, const float* const* bias_padded, const float* layer_meta,
+                       const float* bound_a, const float* bound_b, float mul_b, float* out_pm, int ld_out, int out_coff,
+                       void* stream) {
   if (b <= 0 || m <= 0) return 0;
   if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
     return (int)hipErrorInvalidValue;
-  if (!pvn3d_mlp_split_ok(1, c, 0, nsample, n_layers, dims_host) || dims_host[0] != c + 3 || !vec_ok(features_pm, ld_feat) ||
+  if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith) || dims_host[0] != c + 3 || !vec_ok(features_pm, ld_feat) ||
       ld_feat < c || out_coff < 0 || ld_out < out_coff + dims_host[n_layers])
     return (int)hipErrorInvalidValue;
   S3Args a = {};
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
+  if (arith == 1 && !s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, mul_b)) return (int)hipErrorInvalidValue;
   a.is_sa = 1;
   a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
   a.idx = idx;
@@ -967,24 +1081,44 @@ extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsampl
   a.cols_total = m * nsample;
   a.n_frames = b;
   a.out = out_pm; a.point_major = 1; a.ld_out = ld_out; a.coff = out_coff;
-  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host, nsample), (hipStream_t)stream);
+  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host, nsample, arith), (hipStream_t)stream, arith);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
+extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz,
+                                          const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
+                                          int n_layers, const int* dims_host, const void* const* w_split,
+                                          const float* const* bias_padded, float* out_pm, int ld_out, int out_coff,
+                                          void* stream) {
+  return s3_sa_entry(0, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split,
+                     bias_padded, nullptr, nullptr, nullptr, 0.f, out_pm, ld_out, out_coff, stream);
+}
+extern "C" int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz,
+                                           const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
+                                           int n_layers, const int* dims_host, const void* const* w_split2,
+                                           const float* const* bias_padded, const float* layer_meta,
+                                           const float* features_absmax, const float* xyz_absmax, float* out_pm,
+                                           int ld_out, int out_coff, void* stream) {
+  // |p - c| <= 2 max|xyz| bounds the relative coordinates whatever the index list holds
+  return s3_sa_entry(1, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split2,
+                     bias_padded, layer_meta, features_absmax, xyz_absmax, 2.f, out_pm, ld_out, out_coff, stream);
+}
 
-extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
-                                         const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
-                                         int n_layers, const int* dims_host, const void* const* w_split,
-                                         const float* const* bias_padded, float* out, int out_point_major, int ld_out,
-                                         void* stream) {
+static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                       const float* unknown_pm, int ld_unknown, const int* idx, const float* weight, int n_layers,
+                       const int* dims_host, const void* const* w_split, const float* const* bias_padded,
+                       const float* layer_meta, const float* bound_a, const float* bound_b, float* out,
+                       int out_point_major, int ld_out, void* stream) {
   if (b <= 0 || n <= 0) return 0;
   if (!known_pm || !idx || !weight || !out || !dims_host || !w_split || !bias_padded || (c1 > 0 && !unknown_pm))
     return (int)hipErrorInvalidValue;
-  if (!pvn3d_mlp_split_ok(0, c2, c1, 0, n_layers, dims_host) || dims_host[0] != c2 + c1 || !vec_ok(known_pm, ld_known) ||
+  if (!s3_ok(0, c2, c1, 0, n_layers, dims_host, arith) || dims_host[0] != c2 + c1 || !vec_ok(known_pm, ld_known) ||
       ld_known < c2 || (c1 > 0 && ld_unknown < c1) || (c1 >= S3_KC && !vec_ok(unknown_pm, ld_unknown)) ||
       (out_point_major && ld_out < dims_host[n_layers]))
     return (int)hipErrorInvalidValue;
   S3Args a = {};
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
+  if (arith == 1 && (!s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, 1.f) || (c1 > 0 && !bound_b)))
+    return (int)hipErrorInvalidValue;
   a.is_sa = 0;
   a.idx = idx; a.weight = weight;
   a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
@@ -993,6 +1127,66 @@ extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, co
   a.cols_total = n;
   a.n_frames = b;
   a.out = out; a.point_major = out_point_major ? 1 : 0; a.ld_out = ld_out; a.coff = 0;
-  const int rc = s3_launch(a, s3_signature(0, n_layers, dims_host, 0), (hipStream_t)stream);
+  const int rc = s3_launch(a, s3_signature(0, n_layers, dims_host, 0, arith), (hipStream_t)stream, arith);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
+}
+extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                                         const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                                         int n_layers, const int* dims_host, const void* const* w_split,
+                                         const float* const* bias_padded, float* out, int out_point_major, int ld_out,
+                                         void* stream) {
+  return s3_fp_entry(0, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
+                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, stream);
+}
+extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                                          const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                                          int n_layers, const int* dims_host, const void* const* w_split2,
+                                          const float* const* bias_padded, const float* layer_meta,
+                                          const float* known_absmax, const float* unknown_absmax, float* out,
+                                          int out_point_major, int ld_out, void* stream) {
+  // interpolation weights are non-negative and sum to 1: |interp(known)| <= max|known|
+  return s3_fp_entry(1, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
+                     w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, stream);
+}
+
+// max |x| over a point-major table [rows][ld] (channels [0, c)) -> *out (device float), as an atomic max on the bit
+// pattern (non-negative floats order like unsigned integers).  *out must hold a value <= the result (0) beforehand.
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(long long rows, int c, const float* __restrict__ src, int ld,
+                                                      unsigned* __restrict__ out) {
+  const int c4 = c >> 2;
+  float m = 0.f;
+  if ((ld & 3) == 0 && c4 > 0) {
+    const long long n4 = rows * c4;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long long)gridDim.x * 256) {
+      const long long r = t / c4;
+      const int q = (int)(t - r * c4);
+      const float4 v = *reinterpret_cast<const float4*>(src + r * ld + 4 * q);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    const int rest = c - 4 * c4;
+    if (rest) {
+      for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256)
+        for (int k = 0; k < rest; ++k) m = fmaxf(m, fabsf(src[r * ld + 4 * c4 + k]));
+    }
+  } else {
+    const long long n = rows * c;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+      const long long r = t / c;
+      m = fmaxf(m, fabsf(src[r * ld + (int)(t - r * c)]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+}  // namespace
+extern "C" int pvn3d_absmax(long long rows, int c, const float* src, int ld_src, float* out_max, void* stream) {
+  if (rows <= 0 || c <= 0) return 0;
+  if (!src || !out_max || ld_src < c) return (int)hipErrorInvalidValue;
+  const long long work = rows * ((c + 3) / 4);
+  const unsigned blocks = (unsigned)(work < 256LL * 2048 ? (work + 255) / 256 : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, c, src, ld_src, (unsigned*)out_max);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
 }

@@ -409,6 +409,29 @@ def _point_major(t):
     return out, ld
 
 
+# fp16 x 2 also for chains whose first hidden layer is narrower than 128 channels (SA level 1 of the backbone); False keeps
+# those on the fp32-MFMA kernels (A/B switch)
+SPLIT2_NARROW = True
+
+
+def table_absmax(base, rows, c, ld):
+    """Device float32[1] holding max|x| over the point-major table (rows, c) at `base` (row stride ld): the input bound
+    the fp16 x 2 kernels scale by (include/pvn3d_hip.h).  One reduction per table: the result is cached on the tensor
+    object (the fused levels hand the SAME view object to every consumer of a level's output)."""
+    key = (base.data_ptr(), int(rows), int(c), int(ld), base._version)
+    cache = getattr(base, "_pvn3d_absmax", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    out = torch.zeros(1, dtype=torch.float32, device=base.device)
+    with on_device(base.device):
+        check(lib.pvn3d_absmax(int(rows), int(c), base.data_ptr(), int(ld), out.data_ptr(), _stream(base)), "absmax")
+    try:
+        base._pvn3d_absmax = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
 def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, out_coff=0):
     """Fused group -> SharedMLP (BN folded, fp32 MFMA) -> max over nsample, inference only.
     packed: _fused_mlp.PackedMLP built with n_xyz_first=3 when use_xyz.  features: (B, C, n) in
@@ -436,8 +459,19 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
         out_pm = torch.empty((B, m, (M + 3) // 4 * 4), dtype=torch.float32, device=xyz.device)
         out_coff = 0
     ld_out = out_pm.size(2)
-    if (use_xyz and feat is not None and _fused_mlp.MLP_ARITH == "bf16x3" and ld_feat % 4 == 0
-            and feat.data_ptr() % 16 == 0 and lib.pvn3d_mlp_split_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
+    vec = use_xyz and feat is not None and ld_feat % 4 == 0 and feat.data_ptr() % 16 == 0
+    if (vec and _fused_mlp.MLP_ARITH == "fp16x2" and (SPLIT2_NARROW or packed.dims[1] >= 128)
+            and lib.pvn3d_mlp_split2_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
+        w2, meta = packed.split2()
+        fa, xa = table_absmax(feat, B * N, C, ld_feat), table_absmax(xyz, B * N, 3, 3)
+        with on_device(xyz.device):
+            check(lib.pvn3d_sa_mlp_maxpool_split2(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),
+                                                  ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c,
+                                                  meta, fa.data_ptr(), xa.data_ptr(), out_pm.data_ptr(), ld_out, out_coff,
+                                                  _stream(xyz)), "sa_mlp_maxpool_split2")
+        return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
+    if (vec and _fused_mlp.split_arith()
+            and lib.pvn3d_mlp_split_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
         with on_device(xyz.device):
             check(lib.pvn3d_sa_mlp_maxpool_split(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),
                                                  ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, packed.split(),
@@ -464,7 +498,7 @@ def sa_precontract(features, packs, nsamples):
     """-> [(features' (B, M0, n) view, PackedMLP') per scale] or None when the level does not qualify.
     pointnet2_modules.py:57-69 / pointnet2_utils.py:293-330 regrouped; the fp32 rounding sequence of layer 0 changes
     (the identity part of the new layer 0 is exact), accuracy against fp64 does not (tests/test_gpu_ops.py)."""
-    if not (SA_PRECONTRACT and _fused_mlp.MLP_ARITH == "bf16x3") or features is None or not features.is_cuda:
+    if not (SA_PRECONTRACT and _fused_mlp.split_arith()) or features is None or not features.is_cuda:
         return None
     B, C, n = features.shape
     if C < 128 or B * n < 4096 or features.dtype != torch.float32:
@@ -474,7 +508,8 @@ def sa_precontract(features, packs, nsamples):
         if p.n_layers != 3 or p.dims[0] != C + 3 or p.dims[1] % 32 != 0 or 2 * p.dims[1] > C:
             return None
         pre, wf = p.precontracted(C)
-        if not lib.pvn3d_mlp_split_ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c):
+        ok = lib.pvn3d_mlp_split2_ok if _fused_mlp.MLP_ARITH == "fp16x2" else lib.pvn3d_mlp_split_ok
+        if not ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c):
             return None
         pres.append((pre, wf))
     feat, ld = _point_major(features)
@@ -514,7 +549,7 @@ def fp_layerwise_shape_ok(n_points, c1, dims):
     """The shape half of the dispatch test of fp_interp_mlp (bench.py prices a chain by the pipe it runs on): a
     two-layer chain with skip features whose layers are at least 256 wide, on at least 4096 points, that the fused
     split kernel does not take."""
-    return (_fused_mlp.MLP_ARITH == "bf16x3" and FP_LAYERWISE_SPLIT and len(dims) == 3 and c1 > 0
+    return (_fused_mlp.split_arith() and FP_LAYERWISE_SPLIT and len(dims) == 3 and c1 > 0
             and min(dims[1], dims[2]) >= 256 and n_points >= 4096)
 
 
@@ -578,11 +613,12 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     # FP level 0 (12288 <- 2048 points, 256 -> 128): the interpolated half of the first conv per KNOWN point ahead of the
     # interpolation (six times fewer points, and the chain then gathers 128 instead of 256 channels per neighbour) --
     # the regrouping of _fp_layerwise_split with the fused kernel behind it
-    if (FP_PRECONTRACT and _fused_mlp.MLP_ARITH == "bf16x3" and packed.n_layers == 2 and C1 > 0 and C2 >= 256
+    split_ok = lib.pvn3d_mlp_split2_ok if _fused_mlp.MLP_ARITH == "fp16x2" else lib.pvn3d_mlp_split_ok
+    if (FP_PRECONTRACT and _fused_mlp.split_arith() and packed.n_layers == 2 and C1 > 0 and C2 >= 256
             and packed.dims[1] % 32 == 0 and 2 * packed.dims[1] <= C2 and n >= 4 * m and B * m >= 4096
             and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0):
         pre, wa = packed.precontracted(C2)
-        if lib.pvn3d_mlp_split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
+        if split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
             cache = getattr(packed, "_pre_s16", None)
             if cache is None or cache[0] != C2:            # keyed on the split point like PackedMLP.precontracted()
                 cache = packed._pre_s16 = (C2, _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2)))
@@ -595,8 +631,21 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                 check(lib.pvn3d_split_gemm(B * m, n_out, S, xs.data_ptr(), cache.data_ptr(), None, 0, None, 0, 0, 0, None,
                                            None, z.data_ptr(), n_out, None, 0, _stream(known_feats)), "split_gemm")
             kf, ld_k, C2, packed = z, n_out, pre.dims[1], pre
-    if (_fused_mlp.MLP_ARITH == "bf16x3" and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0
-            and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
+    vec = ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
+    if (vec and _fused_mlp.MLP_ARITH == "fp16x2"
+            and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
+        w2, meta = packed.split2()
+        ka = table_absmax(kf, B * m, C2, ld_k)
+        ua = table_absmax(uf, B * n, C1, ld_u) if uf is not None else None
+        with on_device(known_feats.device):
+            check(lib.pvn3d_fp_interp_mlp_split2(B, n, m, C2, C1, kf.data_ptr(), ld_k,
+                                                 uf.data_ptr() if uf is not None else None, ld_u, idx.data_ptr(),
+                                                 weight.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c, meta,
+                                                 ka.data_ptr(), ua.data_ptr() if ua is not None else None, out.data_ptr(),
+                                                 1 if point_major_out else 0, ld_out, _stream(known_feats)),
+                  "fp_interp_mlp_split2")
+        return out[:, :, :M].transpose(1, 2) if point_major_out else out
+    if (vec and _fused_mlp.split_arith()
             and lib.pvn3d_mlp_split_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
         with on_device(known_feats.device):
             check(lib.pvn3d_fp_interp_mlp_split(B, n, m, C2, C1, kf.data_ptr(), ld_k,

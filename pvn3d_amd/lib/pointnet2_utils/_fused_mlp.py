@@ -7,6 +7,7 @@ A layer is eligible when it is exactly [1x1 Conv2d] -> [BatchNorm2d in eval mode
 None and the caller keeps the unfused torch path.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -31,7 +32,15 @@ def invalidate_packed():
 #             fp32 on the bf16 matrix pipe -- fp32 accuracy (the dropped terms are below fp32's own rounding step) at
 #             6/16 of the fp32-MFMA cost;
 #   "fp32":   v_mfma_f32_32x32x2_f32 everywhere (csrc/sa_mlp.hip).
-MLP_ARITH = os.environ.get("PVN3D_MLP_ARITH", "bf16x3")
+#   "fp16x2": (round 5, default) two fp16 pieces per operand, three partial products on the fp16 matrix pipe, operands
+#             scaled by exact powers of two into fp16's range -- as close to fp64 as the fp32 FMA chain (measured), half the
+#             matrix-pipe time of "bf16x3"; chains the fp16 x 2 kernels do not take fall back to "bf16x3" behaviour.
+MLP_ARITH = os.environ.get("PVN3D_MLP_ARITH", "fp16x2")
+
+
+def split_arith():
+    """True when a split (bf16 x 3 or fp16 x 2) arithmetic is selected, i.e. everything but "fp32"."""
+    return MLP_ARITH in ("bf16x3", "fp16x2")
 
 
 class PackedMLP(object):
@@ -87,6 +96,23 @@ class PackedMLP(object):
         self._s16 = (c_first, d)
         return d
 
+    def split2(self):
+        """-> (ctypes array of the fp16 x 2 weight buffers, ctypes float[3 * n_layers] layer_meta) for
+        pvn3d_*_split2 (csrc/sa_mlp_split.hip, AR = 1), built on first use: per layer a power-of-two weight scale sw
+        with max|sw W'| in [2^13, 2^14], the two fp16 pieces of sw W' (round to nearest), ||W'||_inf and max|bias|."""
+        if getattr(self, "_split2", None) is None:
+            ws, meta = [], []
+            for W, b in zip(self._folded, self.b):
+                wmax = float(W.abs().max())
+                sw = 2.0 ** (14 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0
+                while wmax * sw > 16384.0:
+                    sw *= 0.5
+                ws.append(_pack_weight_split2(W * sw))
+                meta += [sw, float(W.abs().sum(1).max()), float(b.abs().max())]
+            self._split2 = (ws, (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in ws]),
+                            (ctypes.c_float * len(meta))(*meta))
+        return self._split2[1], self._split2[2]
+
     def split(self):
         """-> ctypes array of the split-bf16 weight buffers (csrc/sa_mlp_split.hip), built on first use."""
         if self._split is None:
@@ -112,6 +138,20 @@ def _pack_weight_split(W):
     # (piece, mt, r, s, half, j) -> (s, mt, piece, half, r, j)
     out = pieces.view(3, MT, 32, S, 2, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
     return out.view(torch.int16).view(S, MT, 3, 64, 8)
+
+
+def _pack_weight_split2(W):
+    """W (M, K) float32, already scaled into fp16's range -> int16 [ceil(K/16)][ceil(M/32)][2 pieces][64 lanes][8]:
+    hi = fp16(W), lo = fp16(W - hi), both rounded to nearest; fragment order as _pack_weight_split."""
+    M, K = W.shape
+    MT, S = (M + 31) // 32, (K + 15) // 16
+    Wp = torch.zeros((MT * 32, S * 16), dtype=torch.float32, device=W.device)
+    Wp[:M, :K] = W
+    hi = Wp.to(torch.float16)
+    lo = (Wp - hi.float()).to(torch.float16)
+    pieces = torch.stack([hi, lo], 0)                           # (2, MT*32, S*16)
+    out = pieces.view(2, MT, 32, S, 2, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
+    return out.view(torch.int16).view(S, MT, 2, 64, 8)
 
 
 def _slabs(k):

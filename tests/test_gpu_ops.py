@@ -13,6 +13,10 @@ def cloud(seed, n, wrap=0.0):
     return synth.synth_cloud(np.random.default_rng(seed), n, wrap_pad=wrap)[0]
 
 
+from pvn3d_amd.lib.pointnet2_utils import _fused_mlp as _fm0  # noqa: E402
+_DEFAULT_ARITH = _fm0.MLP_ARITH          # the library's default arithmetic of the fused chains ("fp16x2")
+
+
 def clouds(seed, b, n, wrap=0.0):
     return np.stack([cloud(seed + i, n, wrap) for i in range(b)], 0)
 
@@ -1070,13 +1074,13 @@ def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns,
     few = _small_batch.MAX_FUSED_WGS
     _small_batch.MAX_FUSED_WGS = 0              # small column counts too go through the fused chains under test
     try:
-        for arith in ("bf16x3", "fp32"):
+        for arith in ("fp16x2", "bf16x3", "fp32"):
             _fused_mlp.MLP_ARITH = arith
             try:
                 with torch.no_grad():
                     new_xyz, out = sa(T(xyz_np, dev), feats)
             finally:
-                _fused_mlp.MLP_ARITH = "bf16x3"
+                _fused_mlp.MLP_ARITH = _DEFAULT_ARITH
             outs[arith] = out.cpu().double().numpy()
     finally:
         _ext.sa_precontract = orig_pre
@@ -1084,10 +1088,11 @@ def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns,
     # wide levels on full batches run their first conv's feature half per source point, ahead of the gather
     # (_ext.sa_precontract: SA levels 2-3 of the backbone); everything else gathers the raw features
     want_pre = c_in >= 128 and b * n >= 4096 and 2 * mlp[1] <= c_in and mlp[1] % 32 == 0
-    assert any(taken) == want_pre and taken.count(True) <= 1, (taken, want_pre)      # never under "fp32"
+    assert taken.count(True) == (2 if want_pre else 0), (taken, want_pre)      # both split arithmetics, never "fp32"
     packed = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
     from pvn3d_amd._lib import lib
-    assert lib.pvn3d_mlp_split_ok(1, c_in, 0, ns, packed.n_layers, packed.dims_c) == 1      # the split kernel really ran
+    assert lib.pvn3d_mlp_split_ok(1, c_in, 0, ns, packed.n_layers, packed.dims_c) == 1      # the split kernels really ran
+    assert lib.pvn3d_mlp_split2_ok(1, c_in, 0, ns, packed.n_layers, packed.dims_c) == 1
     new_xyz_np = new_xyz.cpu().numpy()
     idx = orc.ball_query(new_xyz_np, xyz_np, 0.08, ns)
     b_ix = np.arange(b)[:, None, None]
@@ -1103,10 +1108,13 @@ def test_split_bf16_sa_chain_matches_fp32_mfma_and_fp64(dev, orc, c_in, mlp, ns,
     want = np.transpose(h.max(axis=2), (0, 2, 1))
     scale = max(1.0, np.abs(want).max())
     e_split, e_fp32 = np.abs(outs["bf16x3"] - want).max() / scale, np.abs(outs["fp32"] - want).max() / scale
-    print("SA chain %s: max err / scale vs fp64: split %.2e, fp32 mfma %.2e" % (mlp, e_split, e_fp32))
-    assert not np.array_equal(outs["bf16x3"], outs["fp32"])            # two different kernels produced these
-    assert e_split < 2e-5 and e_fp32 < 2e-5
+    e_h2 = np.abs(outs["fp16x2"] - want).max() / scale
+    print("SA chain %s: max err / scale vs fp64: fp16x2 %.2e, bf16x3 %.2e, fp32 mfma %.2e" % (mlp, e_h2, e_split, e_fp32))
+    assert not np.array_equal(outs["bf16x3"], outs["fp32"])            # three different kernels produced these
+    assert not np.array_equal(outs["fp16x2"], outs["fp32"]) and not np.array_equal(outs["fp16x2"], outs["bf16x3"])
+    assert e_split < 2e-5 and e_fp32 < 2e-5 and e_h2 < 2e-5
     assert np.abs(outs["bf16x3"] - outs["fp32"]).max() / scale < 2e-6
+    assert np.abs(outs["fp16x2"] - outs["fp32"]).max() / scale < 2e-6
 
 
 @pytest.mark.parametrize("c2,c1,mlp,n,m,b,pm_out", [
@@ -1135,13 +1143,13 @@ def test_split_bf16_fp_chain_matches_fp32_mfma(dev, c2, c1, mlp, n, m, b, pm_out
     few = _small_batch.MAX_FUSED_WGS
     _small_batch.MAX_FUSED_WGS = 0              # small point counts too go through the fused chains under test
     try:
-        for arith in ("bf16x3", "fp32"):
+        for arith in ("fp16x2", "bf16x3", "fp32"):
             _fused_mlp.MLP_ARITH = arith
             try:
                 with torch.no_grad():
                     outs[arith] = fp(unknown, known, uf, kf).clone()
             finally:
-                _fused_mlp.MLP_ARITH = "bf16x3"
+                _fused_mlp.MLP_ARITH = _DEFAULT_ARITH
     finally:
         _small_batch.MAX_FUSED_WGS = few
     packed = _fused_mlp.pack_shared_mlp(fp.mlp)
@@ -1154,12 +1162,15 @@ def test_split_bf16_fp_chain_matches_fp32_mfma(dev, c2, c1, mlp, n, m, b, pm_out
     finally:
         pm.FUSED_INFERENCE = True
     scale = max(1.0, ref.abs().max().item())
-    assert outs["bf16x3"].shape == ref.shape == (b, mlp[-1], n)
-    d = (outs["bf16x3"] - outs["fp32"]).abs().max().item() / scale
-    print("FP chain %s: split vs fp32 chain %.2e of the output scale" % (mlp, d))
-    # (the pre-contracted form of the last case sums layer 0 in another order than the fp32 chain: 4e-6 instead of 2e-6)
-    assert d < (4e-6 if b * m >= 4096 else 2e-6)
-    assert (outs["bf16x3"] - ref).abs().max().item() / scale < 1e-4
+    assert outs["bf16x3"].shape == outs["fp16x2"].shape == ref.shape == (b, mlp[-1], n)
+    assert lib.pvn3d_mlp_split2_ok(0, c2, c1, 0, packed.n_layers, packed.dims_c) == 1
+    assert not torch.equal(outs["fp16x2"], outs["fp32"]) and not torch.equal(outs["fp16x2"], outs["bf16x3"])
+    for arith in ("bf16x3", "fp16x2"):
+        d = (outs[arith] - outs["fp32"]).abs().max().item() / scale
+        print("FP chain %s: %s vs fp32 chain %.2e of the output scale" % (mlp, arith, d))
+        # (the pre-contracted form of the last case sums layer 0 in another order than the fp32 chain: 4e-6 instead of 2e-6)
+        assert d < (4e-6 if b * m >= 4096 else 2e-6)
+        assert (outs[arith] - ref).abs().max().item() / scale < 1e-4
 
 
 @pytest.mark.parametrize("c2,c1,mlp,n,m,b", [
@@ -1194,7 +1205,7 @@ def test_layerwise_split_fp_chain_against_fp64_and_fp32_chain(dev, c2, c1, mlp, 
             _fused_mlp.MLP_ARITH = "fp32"
             chain = fp(unknown, known, uf, kf, neighbours=nb).clone()
     finally:
-        _fused_mlp.MLP_ARITH = "bf16x3"
+        _fused_mlp.MLP_ARITH = _DEFAULT_ARITH
         _ext._fp_layerwise_split = orig
     assert len(calls) == 2                                   # the layer-wise path really ran (and not under "fp32")
     assert torch.equal(got, again)
@@ -1237,17 +1248,18 @@ def test_split_chains_at_the_bench_batch_size_repeat_bit_for_bit(dev):
         nb0 = fp0.neighbours(unk, unk[:, :2048].contiguous())
         nb2 = fp2.neighbours(unk[:, :1024].contiguous(), unk[:, :512].contiguous())
         runs = []
-        for arith in ("bf16x3", "bf16x3", "fp32"):
+        for arith in ("fp16x2", "fp16x2", "fp32", "bf16x3", "bf16x3"):
             _fused_mlp.MLP_ARITH = arith
             try:
                 runs.append([sa(xyz, feats, geometry=geo)[1].clone(),
                              fp0(unk, unk[:, :2048].contiguous(), uf0, kf0, neighbours=nb0).clone(),
                              fp2(unk[:, :1024].contiguous(), unk[:, :512].contiguous(), uf2, kf2, neighbours=nb2).clone()])
             finally:
-                _fused_mlp.MLP_ARITH = "bf16x3"
-    for a, b, c in zip(*runs):
-        assert torch.equal(a, b) and not torch.equal(a, c)
+                _fused_mlp.MLP_ARITH = _DEFAULT_ARITH
+    for a, b, c, d, e in zip(*runs):
+        assert torch.equal(a, b) and torch.equal(d, e) and not torch.equal(a, c) and not torch.equal(d, c)
         assert (a - c).abs().max().item() / max(1.0, c.abs().max().item()) < 4e-6
+        assert (d - c).abs().max().item() / max(1.0, c.abs().max().item()) < 4e-6
 
 
 def test_split_gemm_c_abi(dev):

@@ -327,3 +327,34 @@ def test_pmc_mfma_groups_the_launches_of_a_forward_by_chain():
     plain = ["mlp_chain_cols_kernel<true, 1>", "mlp_chain_cols_kernel<true, 2>"] + ["mlp_chain_kernel<true, false>"] * 6 + \
         ["mlp_chain_wide_kernel<false, false>"] * 2 + ["mlp_chain_kernel<false, false>"] * 2
     assert [len(g) for g in mod.group_launches(list(enumerate(plain)))] == [1] * 12
+
+
+def test_fp16x2_weight_packing_and_layer_meta():
+    """_fused_mlp.PackedMLP.split2 (include/pvn3d_hip.h, w_split2 / layer_meta): per layer a power-of-two scale that puts
+    the largest weight in [2^13, 2^14], two fp16 pieces whose sum is the scaled weight to 2^-22, in the fragment order of
+    the three-piece packing; ||W||_inf and max|bias| of the TRUE weights."""
+    import math
+    import torch
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp, pointnet2_modules as pm
+    torch.manual_seed(0)
+    sa = pm.PointnetSAModule(mlp=[61, 40, 70], npoint=8, radius=0.1, nsample=8).eval()
+    for layer in sa.mlps[0].children():
+        layer.normlayer.bn.running_var.uniform_(0.5, 2.0)
+        layer.normlayer.bn.running_mean.normal_()
+    pk = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
+    wptr, meta = pk.split2()
+    ws = pk._split2[0]
+    assert len(ws) == pk.n_layers and len(meta) == 3 * pk.n_layers
+    for l, (W, b) in enumerate(zip(pk._folded, pk.b)):
+        sw, wnorm, bmax = meta[3 * l], meta[3 * l + 1], meta[3 * l + 2]
+        assert math.frexp(sw)[0] == 0.5 and 8192.0 <= float(W.abs().max()) * sw <= 16384.0
+        assert abs(wnorm - float(W.abs().sum(1).max())) <= 1e-6 * wnorm and abs(bmax - float(b.abs().max())) <= 1e-6 * max(bmax, 1e-9)
+        M, K = W.shape
+        MT, S = (M + 31) // 32, (K + 15) // 16
+        t = ws[l]
+        assert tuple(t.shape) == (S, MT, 2, 64, 8) and t.dtype == torch.int16
+        # (s, mt, piece, half * 32 + r, j) -> value of row mt*32 + r, k = 16 s + 8 half + j
+        v = t.view(torch.float16).double().view(S, MT, 2, 2, 32, 8).permute(2, 1, 4, 0, 3, 5).reshape(2, MT * 32, S * 16)
+        rec = (v[0] + v[1])[:M, :K] / sw
+        assert float((rec - W.double()).abs().max()) <= 2.0 ** -21 * float(W.abs().max())
+        assert float(v[:, M:].abs().max() if M < MT * 32 else 0.0) == 0.0 and float(v[:, :, K:].abs().max() if K < S * 16 else 0.0) == 0.0

@@ -31,6 +31,15 @@ def main():
     torch.manual_seed(0)
     xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
     cases = []
+    # SA level 1: 2048 -> 1024 centres, C = 96, ns 16 / 32 (fp16 x 2 only: chain signature 111)
+    xyz1 = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=2048, n_obj=256)["pcld"] for i in range(B)])).to(dev)
+    for ns, radius, mlp in ((16, 0.025, [96, 64, 64, 128]), (32, 0.05, [96, 64, 96, 128])):
+        sa = pm.PointnetSAModule(mlp=list(mlp), npoint=1024, radius=radius, nsample=ns).to(dev).eval()
+        feats = torch.randn(B, 2048, 96, device=dev).transpose(1, 2)
+        with torch.no_grad():
+            geo = sa.sample_and_query(xyz1)
+        cases.append(("SA1 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz1, feats, geometry=geo),
+                      2.0 * (99 * mlp[1] + mlp[1] * mlp[2] + mlp[2] * mlp[3]) * 1024 * ns * B))
     # SA level 2: 1024 -> 512 centres, C = 256, ns 16 / 32
     for ns, radius in ((16, 0.05), (32, 0.1)):
         sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=radius, nsample=ns).to(dev).eval()
@@ -63,7 +72,7 @@ def main():
             if name in ("FP2", "FP3"):
                 _fused_mlp.MLP_ARITH = "fp32"
                 want = fp(unk, kn, uf, kf, neighbours=nb)
-                _fused_mlp.MLP_ARITH = "bf16x3"
+                _fused_mlp.MLP_ARITH = "fp16x2"
                 got = fp(unk, kn, uf, kf, neighbours=nb)
                 print(name, "split GEMM vs fp32 chain: max |diff| / scale = %.2e" % (
                     float((got - want).abs().max()) / max(1.0, float(want.abs().max()))))
@@ -71,13 +80,20 @@ def main():
                       2.0 * sum(a * b for a, b in zip(mlp[:-1], mlp[1:])) * n * B))
     for name, fn, flops in cases:
         res = {}
-        for arith in ("fp32", "bf16x3"):
+        outs = {}
+        for arith in ("fp32", "bf16x3", "fp16x2"):
             _fused_mlp.MLP_ARITH = arith
             with torch.no_grad():
                 res[arith] = ms_of(fn)
-        print("%-9s fp32 mfma %7.3f ms (%6.1f TF/s)   split bf16 %7.3f ms (%6.1f TF/s fp32-equivalent)   dbg=%s" % (
-            name, res["fp32"], flops / res["fp32"] / 1e9, res["bf16x3"], flops / res["bf16x3"] / 1e9,
-            os.environ.get("PVN3D_S3_DBG", "0")))
+                o = fn()
+                outs[arith] = (o[1] if isinstance(o, tuple) else o).clone()
+        sc = max(1.0, float(outs["fp32"].abs().max()))
+        print("%-9s fp32 mfma %7.3f ms (%6.1f TF/s)   bf16x3 %7.3f ms (%6.1f)   fp16x2 %7.3f ms (%6.1f TF/s fp32-equivalent)   "
+              "max|diff|/scale vs fp32 chain: bf16x3 %.1e fp16x2 %.1e   dbg=%s" % (
+                  name, res["fp32"], flops / res["fp32"] / 1e9, res["bf16x3"], flops / res["bf16x3"] / 1e9,
+                  res["fp16x2"], flops / res["fp16x2"] / 1e9, float((outs["bf16x3"] - outs["fp32"]).abs().max()) / sc,
+                  float((outs["fp16x2"] - outs["fp32"]).abs().max()) / sc, os.environ.get("PVN3D_S3_DBG", "0")))
+    _fused_mlp.MLP_ARITH = "fp16x2"
 
 
 if __name__ == "__main__":
