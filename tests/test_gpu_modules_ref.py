@@ -268,7 +268,7 @@ def test_batch_fixture_inputs_are_reproducible(golden):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [8, 64])
 def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
-    """(i) the 64-frame forward goes through the pre-contractions, the split-bf16 chains and the layer-wise split-GEMM FP
+    """(i) the 64-frame forward goes through the pre-contractions, the fp16 x 2 chains and the layer-wise split-GEMM FP
     levels (asserted on the C-ABI calls); (ii) every level's FPS / ball-query / three_nn indices are the reference's
     (bit-exact; ball query and three_nn by SHA-256 per frame), every level's features within 1e-4 of the reference's
     float32 run and 1e-5 of its float64 run (of the level's output scale) on seeded columns, and two projections that
@@ -335,11 +335,11 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
     print("B = %d C-ABI calls:" % B, dict((k, v) for k, v in sorted(c.items()) if "mlp" in k or "split" in k),
           "small-batch:", dict(spy_sb.calls))
     if B == 64:
-        # SA0-1 two fp32-MFMA chains each; SA2-3 pre-contracted (one split GEMM per level) + two split chains each;
-        # FP0 pre-contracted (one split GEMM) + split chain, FP1 split chain; FP2-3 layer by layer (three split GEMMs
-        # and two row splits each); nothing on the small-batch route
-        assert c["pvn3d_sa_mlp_maxpool"] == 4 and c["pvn3d_sa_mlp_maxpool_split"] == 4
-        assert c["pvn3d_fp_interp_mlp_split"] == 2 and c["pvn3d_fp_interp_mlp"] == 0
+        # SA0: two fp32-MFMA chains; SA1: two fp16 x 2 chains; SA2-3 pre-contracted (one split GEMM per level) + two
+        # fp16 x 2 chains each; FP0 pre-contracted (one split GEMM) + fp16 x 2 chain, FP1 fp16 x 2 chain; FP2-3 layer by
+        # layer (three split GEMMs and two row splits each); nothing on the small-batch route, nothing on bf16 x 3 chains
+        assert c["pvn3d_sa_mlp_maxpool"] == 2 and c["pvn3d_sa_mlp_maxpool_split2"] == 6 and c["pvn3d_sa_mlp_maxpool_split"] == 0
+        assert c["pvn3d_fp_interp_mlp_split2"] == 2 and c["pvn3d_fp_interp_mlp"] == 0 and c["pvn3d_fp_interp_mlp_split"] == 0
         assert c["pvn3d_split_gemm"] == 2 + 1 + 3 + 3 and c["pvn3d_split_rows"] == 2 + 1 + 2 + 2
         assert not any(k.startswith("pvn3d_sb_") for k in spy_sb.calls)
     worst, worst_proj, proj_by_level = {}, 0.0, {}

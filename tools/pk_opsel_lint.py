@@ -69,7 +69,7 @@ def lint_file(path):
 
 def main(argv):
     from concurrent.futures import ThreadPoolExecutor
-    files = argv or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    files = [os.path.abspath(f) for f in argv] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     bad = 0
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         results = list(ex.map(lint_file, files))
