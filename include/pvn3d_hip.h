@@ -287,6 +287,25 @@ int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* x_s16, cons
                      int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
                      void* out_s16, int slabs_out, void* stream);
 
+/* The layer-by-layer GEMM in the fp16 x 2 arithmetic of pvn3d_*_split2 (round 5).  "h16" layout of a matrix [rows][K]:
+ * rows x slabs x 2 pieces x 16 fp16, entry (r, k, piece) at byte ((r * slabs + k / 16) * 2 + piece) * 32 + 2 * (k % 16),
+ * holding s * x split as piece 0 = fp16(s x), piece 1 = fp16(s x - piece 0), where s is the power of two that puts a
+ * bound B on |x| at 2^14 -- B is a DEVICE float the caller names (pvn3d_absmax of the source, a GEMM's out_absmax, or
+ * pvn3d_bound_affine of such bounds); the same pointer must be passed where the matrix is written and where it is read.
+ *   pvn3d_split_rows2: fp32 rows -> h16 (scale from *src_bound).
+ *   pvn3d_split_gemm2: pvn3d_split_gemm on h16 operands; w_h16 holds w_scale * W (w_scale a power of two, host);
+ *       out_absmax (optional): atomic max of |out_f32| -- set it to 0 before; out_bound: the bound the h16 output is
+ *       written with (required with out_h16).  Three partial products per multiply on v_mfma_f32_32x32x16_f16.
+ *   pvn3d_bound_affine: *out = 1.01 (ca * *a + cb * *b + c0) (b may be NULL): the rigorous bound |W x + ...| <=
+ *       ||W||_inf max|x| + ... of a layer's output from the bounds of its inputs. */
+int pvn3d_split_rows2(long long rows, int c, const float* src, int ld_src, const float* src_bound, void* dst_h16, int slabs,
+                      void* stream);
+int pvn3d_split_gemm2(int n_points, int n_out, int slabs, const void* x_h16, const float* x_bound, const void* w_h16,
+                      float w_scale, const float* bias_padded, int relu, const float* z, int ldz, int z_points_per_frame,
+                      int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
+                      float* out_absmax, void* out_h16, int slabs_out, const float* out_bound, void* stream);
+int pvn3d_bound_affine(float* out, const float* a, float ca, const float* b, float cb, float c0, void* stream);
+
 /* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */
 int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out, int ld_out,
                                void* stream);

@@ -31,11 +31,24 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 sg_h2;
+typedef __attribute__((ext_vector_type(2))) float sg_f2;
 
+// Arithmetic (template parameter AR), as in sa_mlp_split.hip:
+//   0  bf16 x 3 ("s16" matrices: rows x slabs x 3 pieces x 16 bf16 = 96 B per slab), six partial products;
+//   1  fp16 x 2 ("h16" matrices: rows x slabs x 2 pieces x 16 fp16 = 64 B per slab), three partial products on
+//      v_mfma_f32_32x32x16_f16; every h16 matrix holds x * s with s the power of two that puts a bound B on |x| (a DEVICE
+//      float the caller names: pvn3d_absmax of the source, or pvn3d_bound_affine of such bounds) at 2^14; the weights carry
+//      a host-side power-of-two scale; both are undone exactly on the accumulators.  Two thirds of the operand bytes
+//      (the kernel is bound by L2 -> LDS traffic) and half of the MFMAs of (0).
 constexpr int SG_T = 128;                 // tile edge
-constexpr int SG_ROWB = 208;              // LDS bytes per tile row: 2 slabs x 96 B + 16 B pad
-constexpr int SG_OPB = SG_T * SG_ROWB;    // one operand's chunk
+constexpr int sg_np(int ar) { return ar == 1 ? 2 : 3; }
+constexpr int sg_slab(int ar) { return sg_np(ar) * 32; }            // bytes per 16-k slab of a row: 96 / 64
+constexpr int sg_rowb(int ar) { return 2 * sg_slab(ar) + 16; }      // LDS bytes per tile row (32 k): 208 / 144 = 16 x odd
+constexpr int sg_parts(int ar) { return 2 * sg_slab(ar) / 16; }     // 16-byte parts per row and chunk: 12 / 8
+constexpr int sg_opb(int ar) { return SG_T * sg_rowb(ar); }         // one operand's chunk in LDS
 
 struct SgArgs {
   int P, N, S;                 // points, real output channels, 16-k slabs of the contraction (even)
@@ -49,7 +62,27 @@ struct SgArgs {
   const float* wgt;            // [P][3]
   float* out_f; int ld_out;    // fp32 [P][ld_out], channels < N
   char* out_s; int S_out;      // s16 [P][S_out]: every channel < 16 * S_out is written (pad channels are exact zeros)
+  // fp16 x 2 only
+  const float* x_bound;        // device: bound on |X| (the scale X was written with)
+  float w_scale;               // host: power-of-two scale of W
+  const float* out_bound;      // device: bound on |out| for the h16 output (nullptr without out_s)
+  unsigned* out_absmax;        // device or nullptr: atomic max of |out_f| (bit pattern), for the consumer's bound
 };
+
+__device__ __forceinline__ float sg_pow2_scale(float bound) {      // largest power of two s with bound * s <= 2^14
+  int e;
+  (void)frexpf(fmaxf(bound, 1e-30f), &e);
+  return ldexpf(1.f, 14 - e);
+}
+// two fp16 pieces (round to nearest) of four scaled values
+__device__ __forceinline__ void sg_split4h(const float (&x)[4], uint2& h, uint2& l) {
+  const sg_f2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
+  const sg_h2 h01 = __builtin_convertvector(x01, sg_h2), h23 = __builtin_convertvector(x23, sg_h2);
+  const sg_h2 l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, sg_f2), sg_h2);
+  const sg_h2 l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, sg_f2), sg_h2);
+  h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
+  l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+}
 
 // exact 3-way split of four fp32 values (consecutive channels) into three packed bf16x4
 __device__ __forceinline__ void sg_split4(const float (&x)[4], uint2& h, uint2& m, uint2& l) {
@@ -67,10 +100,13 @@ __device__ __forceinline__ void sg_split4(const float (&x)[4], uint2& h, uint2& 
 }
 
 // grid (channel tiles, point tiles), remapped per XCD below.
+template <int AR>
 __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * SG_OPB];
+  constexpr int NP = sg_np(AR), SLAB = sg_slab(AR), ROWB = sg_rowb(AR), PARTS = sg_parts(AR), OPB = sg_opb(AR);
+  constexpr int LD = SG_T * PARTS / 256;             // 16-byte chunk loads per thread and operand: 6 / 4
+  __shared__ __attribute__((aligned(16))) char smem[2 * OPB];
   char* sW = smem;
-  char* sX = smem + SG_OPB;
+  char* sX = smem + OPB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 1, wc = wave >> 1;           // 64-channel / 64-point quadrant of this wave
@@ -86,25 +122,25 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
     pt = (int)(q / gridDim.x) * 8 + (int)(lin & 7);
   }
   const int c0 = ct * SG_T, p0 = pt * SG_T;
-  const size_t rowb = (size_t)a.S * 96;              // bytes per s16 row
+  const size_t rowb = (size_t)a.S * SLAB;            // bytes per s16 / h16 row
   const int nch = a.S >> 1;
 
-  // chunk loads: 12 x 16 B per row and operand; thread -> (row, part) = ((tid + 256 j) / 12, (tid + 256 j) % 12)
-  const char* gW[6];
-  const char* gX[6];
-  int lofs[6];
+  // chunk loads: PARTS x 16 B per row and operand; thread -> (row, part) = ((tid + 256 j) / PARTS, (tid + 256 j) % PARTS)
+  const char* gW[LD];
+  const char* gX[LD];
+  int lofs[LD];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int id = tid + 256 * j, row = id / 12, part = id - row * 12;
+  for (int j = 0; j < LD; ++j) {
+    const int id = tid + 256 * j, row = id / PARTS, part = id - row * PARTS;
     gW[j] = a.W + (size_t)(c0 + row) * rowb + part * 16;
     gX[j] = a.X + (size_t)min(p0 + row, a.P - 1) * rowb + part * 16;
-    lofs[j] = row * SG_ROWB + part * 16;
+    lofs[j] = row * ROWB + part * 16;
   }
-  u32x4 rW[6], rX[6];
-#define SG_GLOAD(C)                                                        \
-  _Pragma("unroll") for (int j = 0; j < 6; ++j) {                          \
-    rW[j] = *reinterpret_cast<const u32x4*>(gW[j] + (size_t)(C) * 192);    \
-    rX[j] = *reinterpret_cast<const u32x4*>(gX[j] + (size_t)(C) * 192);    \
+  u32x4 rW[LD], rX[LD];
+#define SG_GLOAD(C)                                                             \
+  _Pragma("unroll") for (int j = 0; j < LD; ++j) {                              \
+    rW[j] = *reinterpret_cast<const u32x4*>(gW[j] + (size_t)(C) * (2 * SLAB));  \
+    rX[j] = *reinterpret_cast<const u32x4*>(gX[j] + (size_t)(C) * (2 * SLAB));  \
   }
 
   f32x16 acc[2][2];
@@ -115,15 +151,15 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment addresses: row (lane & 31) of a 32-row block, k half (lane >> 5); + slab * 96 + piece * 32
-  const char* fW = sW + (wr * 64 + (lane & 31)) * SG_ROWB + (lane >> 5) * 16;
-  const char* fX = sX + (wc * 64 + (lane & 31)) * SG_ROWB + (lane >> 5) * 16;
+  // fragment addresses: row (lane & 31) of a 32-row block, k half (lane >> 5); + slab * SLAB + piece * 32
+  const char* fW = sW + (wr * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const char* fX = sX + (wc * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
 
   SG_GLOAD(0)
   for (int c = 0; c < nch; ++c) {
     __syncthreads();                                  // the previous chunk's fragment reads are done
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < LD; ++j) {
       *reinterpret_cast<u32x4*>(sW + lofs[j]) = rW[j];
       *reinterpret_cast<u32x4*>(sX + lofs[j]) = rX[j];
     }
@@ -131,20 +167,30 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
     if (c + 1 < nch) { SG_GLOAD(c + 1) }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[2][3], fb[2][3];
+      u32x4 fa[2][NP], fb[2][NP];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          fa[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(fW + i * 32 * SG_ROWB + s * 96 + p * 32));
-          fb[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(fX + i * 32 * SG_ROWB + s * 96 + p * 32));
+        for (int p = 0; p < NP; ++p) {
+          fa[i][p] = *reinterpret_cast<const u32x4*>(fW + i * 32 * ROWB + s * SLAB + p * 32);
+          fb[i][p] = *reinterpret_cast<const u32x4*>(fX + i * 32 * ROWB + s * SLAB + p * 32);
         }
+      if (AR == 1) {
 #define SG_MM(PA, PB)                                                                              \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0)
-      SG_MM(0, 2); SG_MM(2, 0); SG_MM(1, 1);
-      SG_MM(0, 1); SG_MM(1, 0); SG_MM(0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][PA]),     \
+                                                         __builtin_bit_cast(f16x8, fb[j][PB]), acc[i][j], 0, 0, 0)
+        SG_MM(0, 1); SG_MM(1, 0); SG_MM(0, 0);
 #undef SG_MM
+      } else {
+#define SG_MM(PA, PB)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA]),   \
+                                                          __builtin_bit_cast(bf16x8, fb[j][PB]), acc[i][j], 0, 0, 0)
+        SG_MM(0, 2); SG_MM(2, 0); SG_MM(1, 1);
+        SG_MM(0, 1); SG_MM(1, 0); SG_MM(0, 0);
+#undef SG_MM
+      }
     }
   }
 #undef SG_GLOAD
@@ -156,6 +202,18 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
   // last 16 lanes of a wave, timing dependent; the same loads behind an explicit s_waitcnt vmcnt(0) were always
   // right.  Root cause not established; tools/sg_check.py exercises the case at the failing size.)
   const int half = lane >> 5;
+  float s_out = 1.f, amax = 0.f;
+  if (AR == 1) {
+    // accumulators carry w_scale * s_x: undo (an exact power of two) before anything is added
+    const float inv = 1.f / (a.w_scale * sg_pow2_scale(*a.x_bound));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    if (a.out_s) s_out = sg_pow2_scale(*a.out_bound);
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int p = p0 + wc * 64 + j * 32 + (lane & 31);
@@ -216,28 +274,43 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
           float* o = a.out_f + (size_t)p * a.ld_out + ch;
           if (ch + 3 < a.N) {
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (ch + e < a.N) o[e] = v[e];
+              if (ch + e < a.N) { o[e] = v[e]; amax = fmaxf(amax, fabsf(v[e])); }
           }
         }
         if (a.out_s && ch < 16 * a.S_out) {
-          uint2 h, m, l;
-          sg_split4(v, h, m, l);
-          char* o = a.out_s + ((size_t)p * a.S_out + (ch >> 4)) * 96 + (ch & 15) * 2;
-          *reinterpret_cast<uint2*>(o) = h;
-          *reinterpret_cast<uint2*>(o + 32) = m;
-          *reinterpret_cast<uint2*>(o + 64) = l;
+          char* o = a.out_s + ((size_t)p * a.S_out + (ch >> 4)) * SLAB + (ch & 15) * 2;
+          if (AR == 1) {
+            const float y[4] = {v[0] * s_out, v[1] * s_out, v[2] * s_out, v[3] * s_out};
+            uint2 h, l;
+            sg_split4h(y, h, l);
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + 32) = l;
+          } else {
+            uint2 h, m, l;
+            sg_split4(v, h, m, l);
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + 32) = m;
+            *reinterpret_cast<uint2*>(o + 64) = l;
+          }
         }
       }
+  }
+  if (a.out_absmax) {           // the consumer's bound on |out_f| (pvn3d_absmax without a second pass over the table)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0 && amax > 0.f) atomicMax(a.out_absmax, __float_as_uint(amax));
   }
 }
 
 // fp32 rows [rows][ld] (channels [0, c)) -> s16 [rows][S] by truncation split; channels >= c are zeros.
 // One thread per (row, 4 channels).
+template <int AR>
 __global__ __launch_bounds__(256) void sg_split_rows_kernel(long long rows, int c, const float* __restrict__ src, int ld,
-                                                            char* __restrict__ dst, int S) {
+                                                            char* __restrict__ dst, int S, const float* __restrict__ bound) {
   const int q_per_row = S * 4;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= rows * q_per_row) return;
@@ -253,49 +326,104 @@ __global__ __launch_bounds__(256) void sg_split_rows_kernel(long long rows, int 
     for (int e = 0; e < 4; ++e)
       if (ch + e < c) x[e] = s[e];
   }
-  uint2 h, m, l;
-  sg_split4(x, h, m, l);
-  char* o = dst + ((size_t)row * S + (ch >> 4)) * 96 + (ch & 15) * 2;
-  *reinterpret_cast<uint2*>(o) = h;
-  *reinterpret_cast<uint2*>(o + 32) = m;
-  *reinterpret_cast<uint2*>(o + 64) = l;
+  char* o = dst + ((size_t)row * S + (ch >> 4)) * sg_slab(AR) + (ch & 15) * 2;
+  if (AR == 1) {
+    const float s = sg_pow2_scale(*bound);
+    const float y[4] = {x[0] * s, x[1] * s, x[2] * s, x[3] * s};
+    uint2 h, l;
+    sg_split4h(y, h, l);
+    *reinterpret_cast<uint2*>(o) = h;
+    *reinterpret_cast<uint2*>(o + 32) = l;
+  } else {
+    uint2 h, m, l;
+    sg_split4(x, h, m, l);
+    *reinterpret_cast<uint2*>(o) = h;
+    *reinterpret_cast<uint2*>(o + 32) = m;
+    *reinterpret_cast<uint2*>(o + 64) = l;
+  }
+}
+
+// out = ca * *a + cb * *b + c0 (b may be null): the rigorous bound of a layer's output from the bounds of its inputs
+__global__ void sg_bound_affine_kernel(float* out, const float* a, float ca, const float* b, float cb, float c0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = (ca * *a + (b ? cb * *b : 0.f) + c0) * 1.01f;
 }
 
 }  // namespace
 
-extern "C" int pvn3d_split_rows(long long rows, int c, const float* src, int ld_src, void* dst_s16, int slabs,
-                                void* stream) {
+static int sg_split_rows_any(int ar, long long rows, int c, const float* src, int ld_src, void* dst, int slabs,
+                             const float* bound, void* stream) {
   if (rows <= 0) return 0;
-  if (!src || !dst_s16 || c <= 0 || slabs <= 0 || c > 16 * slabs || ld_src < c ||
-      ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst_s16 & 15) != 0)
+  if (!src || !dst || c <= 0 || slabs <= 0 || c > 16 * slabs || ld_src < c || (ar == 1 && !bound) ||
+      ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0)
     return (int)hipErrorInvalidValue;
   const long long n = rows * (long long)slabs * 4;
   if (n > 0x7fffffffLL * 256) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sg_split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, c,
-                     src, ld_src, (char*)dst_s16, slabs);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (ar == 1)
+    hipLaunchKernelGGL(sg_split_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, rows, c, src, ld_src, (char*)dst, slabs, bound);
+  else
+    hipLaunchKernelGGL(sg_split_rows_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, rows, c, src, ld_src, (char*)dst, slabs, bound);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pvn3d_split_rows(long long rows, int c, const float* src, int ld_src, void* dst_s16, int slabs,
+                                void* stream) {
+  return sg_split_rows_any(0, rows, c, src, ld_src, dst_s16, slabs, nullptr, stream);
+}
+extern "C" int pvn3d_split_rows2(long long rows, int c, const float* src, int ld_src, const float* src_bound, void* dst_h16,
+                                 int slabs, void* stream) {
+  return sg_split_rows_any(1, rows, c, src, ld_src, dst_h16, slabs, src_bound, stream);
+}
+
+extern "C" int pvn3d_bound_affine(float* out, const float* a, float ca, const float* b, float cb, float c0, void* stream) {
+  if (!out || !a || !(ca >= 0.f) || !(cb >= 0.f) || !(c0 >= 0.f)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sg_bound_affine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, a, ca, b, cb, c0);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
 
+static int sg_gemm_any(int ar, int n_points, int n_out, int slabs, const void* x, const void* w, const float* bias_padded,
+                       int relu, const float* z, int ldz, int z_points_per_frame, int z_rows_per_frame, const int* idx,
+                       const float* weight, float* out_f32, int ld_out, void* out_s, int slabs_out, const float* x_bound,
+                       float w_scale, const float* out_bound, float* out_absmax, void* stream) {
+  if (n_points <= 0 || n_out <= 0) return 0;
+  if (!x || !w || slabs <= 0 || (slabs & 1) || (!out_f32 && !out_s) || (out_f32 && ld_out < n_out) ||
+      (out_s && (slabs_out <= 0 || 16 * slabs_out > pvn3d_ceil_div(n_out, SG_T) * SG_T)) ||
+      (z && (!idx || !weight || (ldz & 3) || ldz < pvn3d_ceil_div(n_out, SG_T) * SG_T || z_points_per_frame <= 0 ||
+             z_rows_per_frame <= 0 || ((uintptr_t)z & 15) != 0)) ||
+      ((uintptr_t)x & 15) != 0 || ((uintptr_t)w & 15) != 0 || (out_f32 && (((uintptr_t)out_f32 & 15) != 0 || (ld_out & 3))) ||
+      (out_s && ((uintptr_t)out_s & 15) != 0) || (bias_padded && ((uintptr_t)bias_padded & 15) != 0))
+    return (int)hipErrorInvalidValue;
+  if (ar == 1) {
+    int e = 0;
+    if (!x_bound || !(w_scale > 0.f) || frexpf(w_scale, &e) != 0.5f || (out_s && !out_bound)) return (int)hipErrorInvalidValue;
+  } else if (out_absmax) {
+    return (int)hipErrorInvalidValue;
+  }
+  SgArgs a = {};
+  a.P = n_points; a.N = n_out; a.S = slabs;
+  a.X = (const char*)x; a.W = (const char*)w; a.bias = bias_padded; a.relu = relu;
+  a.Z = z; a.ldz = ldz; a.zn = z_points_per_frame; a.zm = z_rows_per_frame; a.idx = idx; a.wgt = weight;
+  a.out_f = out_f32; a.ld_out = ld_out; a.out_s = (char*)out_s; a.S_out = slabs_out;
+  a.x_bound = x_bound; a.w_scale = w_scale; a.out_bound = out_bound; a.out_absmax = (unsigned*)out_absmax;
+  const dim3 grid(pvn3d_ceil_div(n_out, SG_T), pvn3d_ceil_div(n_points, SG_T));
+  if (ar == 1) hipLaunchKernelGGL(sg_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(sg_gemm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* x_s16, const void* w_s16,
                                 const float* bias_padded, int relu, const float* z, int ldz, int z_points_per_frame,
                                 int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
                                 void* out_s16, int slabs_out, void* stream) {
-  if (n_points <= 0 || n_out <= 0) return 0;
-  if (!x_s16 || !w_s16 || slabs <= 0 || (slabs & 1) || (!out_f32 && !out_s16) || (out_f32 && ld_out < n_out) ||
-      (out_s16 && (slabs_out <= 0 || 16 * slabs_out > pvn3d_ceil_div(n_out, SG_T) * SG_T)) ||
-      (z && (!idx || !weight || (ldz & 3) || ldz < pvn3d_ceil_div(n_out, SG_T) * SG_T || z_points_per_frame <= 0 ||
-             z_rows_per_frame <= 0 || ((uintptr_t)z & 15) != 0)) ||
-      ((uintptr_t)x_s16 & 15) != 0 || ((uintptr_t)w_s16 & 15) != 0 || (out_f32 && (((uintptr_t)out_f32 & 15) != 0 || (ld_out & 3))) ||
-      (out_s16 && ((uintptr_t)out_s16 & 15) != 0) || (bias_padded && ((uintptr_t)bias_padded & 15) != 0))
-    return (int)hipErrorInvalidValue;
-  SgArgs a = {};
-  a.P = n_points; a.N = n_out; a.S = slabs;
-  a.X = (const char*)x_s16; a.W = (const char*)w_s16; a.bias = bias_padded; a.relu = relu;
-  a.Z = z; a.ldz = ldz; a.zn = z_points_per_frame; a.zm = z_rows_per_frame; a.idx = idx; a.wgt = weight;
-  a.out_f = out_f32; a.ld_out = ld_out; a.out_s = (char*)out_s16; a.S_out = slabs_out;
-  const dim3 grid(pvn3d_ceil_div(n_out, SG_T), pvn3d_ceil_div(n_points, SG_T));
-  hipLaunchKernelGGL(sg_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-  PVN3D_LAUNCH_CHECK();
-  return 0;
+  return sg_gemm_any(0, n_points, n_out, slabs, x_s16, w_s16, bias_padded, relu, z, ldz, z_points_per_frame, z_rows_per_frame,
+                     idx, weight, out_f32, ld_out, out_s16, slabs_out, nullptr, 1.f, nullptr, nullptr, stream);
+}
+extern "C" int pvn3d_split_gemm2(int n_points, int n_out, int slabs, const void* x_h16, const float* x_bound,
+                                 const void* w_h16, float w_scale, const float* bias_padded, int relu, const float* z,
+                                 int ldz, int z_points_per_frame, int z_rows_per_frame, const int* idx, const float* weight,
+                                 float* out_f32, int ld_out, float* out_absmax, void* out_h16, int slabs_out,
+                                 const float* out_bound, void* stream) {
+  return sg_gemm_any(1, n_points, n_out, slabs, x_h16, w_h16, bias_padded, relu, z, ldz, z_points_per_frame, z_rows_per_frame,
+                     idx, weight, out_f32, ld_out, out_h16, slabs_out, x_bound, w_scale, out_bound, out_absmax, stream);
 }

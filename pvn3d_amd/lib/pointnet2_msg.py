@@ -211,8 +211,16 @@ class Pointnet2MSG(nn.Module):
                         t.record_stream(cur)       # produced on the geometry stream, consumed on THIS stream
         else:
             sa_geo, fp_geo = self._geometry_ahead(xyz)
+        # fp16 x 2 chains scale their operands by device-side bounds: one abs-max of the cloud bounds every level's
+        # centres (they are points of the cloud), so the levels inherit it instead of reducing their own xyz
+        xyz_bound = None
+        from .pointnet2_utils import _ext, _fused_mlp
+        if _fused_mlp.MLP_ARITH == "fp16x2":
+            xyz_bound = _ext.table_absmax(xyz, xyz.size(0) * xyz.size(1), 3, 3)
         for sa, (geom, ev) in zip(self.SA_modules, sa_geo):
             cur.wait_event(ev)
+            if xyz_bound is not None:
+                geom[0]._pvn3d_bound = xyz_bound
             li_xyz, li_features = sa(l_xyz[-1], l_features[-1], geometry=geom)
             l_xyz.append(li_xyz)
             l_features.append(li_features)

@@ -418,6 +418,9 @@ def table_absmax(base, rows, c, ld):
     """Device float32[1] holding max|x| over the point-major table (rows, c) at `base` (row stride ld): the input bound
     the fp16 x 2 kernels scale by (include/pvn3d_hip.h).  One reduction per table: the result is cached on the tensor
     object (the fused levels hand the SAME view object to every consumer of a level's output)."""
+    inherited = getattr(base, "_pvn3d_bound", None)       # a bound that holds for every table inside this tensor's data
+    if inherited is not None:
+        return inherited
     key = (base.data_ptr(), int(rows), int(c), int(ld), base._version)
     cache = getattr(base, "_pvn3d_absmax", None)
     if cache is not None and cache[0] == key:
@@ -430,6 +433,13 @@ def table_absmax(base, rows, c, ld):
     except AttributeError:
         pass
     return out
+
+
+def seed_absmax(view, rows, c, ld, bound):
+    """Attach `bound` (device float32[1], already known -- e.g. a GEMM's out_absmax) to `view` as the cached result of
+    table_absmax(view, rows, c, ld)."""
+    view._pvn3d_absmax = ((view.data_ptr(), int(rows), int(c), int(ld), view._version), bound)
+    return view
 
 
 def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, out_coff=0):
@@ -515,26 +525,43 @@ def sa_precontract(features, packs, nsamples):
     feat, ld = _point_major(features)
     if ld % 4 != 0 or feat.data_ptr() % 16 != 0:
         return None
-    key = tuple(id(p) for p in packs)
+    h2 = _fused_mlp.MLP_ARITH == "fp16x2"
+    key = (tuple(id(p) for p in packs), h2)
     cache = getattr(packs[0], "_pre_cat", None)
     if cache is None or cache[0] != key:
         wcat = torch.cat([wf for _, wf in pres], 0)
-        cache = (key, _fused_mlp._pack_weight_s16(wcat, _fused_mlp._slabs(C)), list(packs))
+        sw = _fused_mlp._pow2_weight_scale(wcat) if h2 else 1.0
+        wp = _fused_mlp._pack_weight_h16(wcat * sw, _fused_mlp._slabs(C)) if h2 else \
+            _fused_mlp._pack_weight_s16(wcat, _fused_mlp._slabs(C))
+        cache = (key, wp, list(packs), sw)
         packs[0]._pre_cat = cache
-    ws = cache[1]
+    ws, sw = cache[1], cache[3]
     S, n_out = _fused_mlp._slabs(C), ws.size(0)
     dev = features.device
     st = _stream(features)
-    xs = torch.empty((B * n * S * 96,), dtype=torch.uint8, device=dev)
     y = torch.empty((B, n, n_out), dtype=torch.float32, device=dev)
-    with on_device(dev):
-        check(lib.pvn3d_split_rows(B * n, C, feat.data_ptr(), ld, xs.data_ptr(), S, st), "split_rows")
-        check(lib.pvn3d_split_gemm(B * n, n_out, S, xs.data_ptr(), ws.data_ptr(), None, 0, None, 0, 0, 0, None, None,
-                                   y.data_ptr(), n_out, None, 0, st), "split_gemm")
+    amax = None
+    if h2:
+        fa = table_absmax(feat, B * n, C, ld)
+        amax = torch.zeros(1, dtype=torch.float32, device=dev)
+        xs = torch.empty((B * n * S * 64,), dtype=torch.uint8, device=dev)
+        with on_device(dev):
+            check(lib.pvn3d_split_rows2(B * n, C, feat.data_ptr(), ld, fa.data_ptr(), xs.data_ptr(), S, st), "split_rows2")
+            check(lib.pvn3d_split_gemm2(B * n, n_out, S, xs.data_ptr(), fa.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0,
+                                        0, None, None, y.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st), "split_gemm2")
+    else:
+        xs = torch.empty((B * n * S * 96,), dtype=torch.uint8, device=dev)
+        with on_device(dev):
+            check(lib.pvn3d_split_rows(B * n, C, feat.data_ptr(), ld, xs.data_ptr(), S, st), "split_rows")
+            check(lib.pvn3d_split_gemm(B * n, n_out, S, xs.data_ptr(), ws.data_ptr(), None, 0, None, 0, 0, 0, None, None,
+                                       y.data_ptr(), n_out, None, 0, st), "split_gemm")
     out, off = [], 0
     for pre, _ in pres:
         m0 = pre.dims[1]
-        out.append((y[:, :, off:off + m0].transpose(1, 2), pre))
+        view = y[:, :, off:off + m0].transpose(1, 2)
+        if amax is not None:
+            seed_absmax(view, B * n, m0, n_out, amax)           # max|y| bounds every channel slice of y
+        out.append((view, pre))
         off += m0
     return out
 
@@ -559,10 +586,36 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
     conv pulled through the (linear) interpolation, so that it runs over the m known points.  Three launches of
     pvn3d_split_gemm + two row splits; every intermediate is a torch allocation (caching allocator)."""
     dev = kf.device
-    w = packed.s16(C2)
-    n1p = w["b1"].numel()
     st = _stream(kf)
     P, Pk = B * n, B * m
+    if _fused_mlp.MLP_ARITH == "fp16x2":
+        # the same three launches in the two-piece fp16 arithmetic (pvn3d_split_gemm2): operand scales from device-side
+        # bounds -- abs-max of the two inputs, the rigorous bound of H from them -- and the output's abs-max for its consumer
+        w = packed.h16(C2)
+        n1p = w["b1"].numel()
+        ka, ua = table_absmax(kf, Pk, C2, ld_k), table_absmax(uf, P, C1, ld_u)
+        xk = torch.empty((Pk * w["s_a"] * 64,), dtype=torch.uint8, device=dev)
+        xu = torch.empty((P * w["s_b"] * 64,), dtype=torch.uint8, device=dev)
+        z = torch.empty((Pk, n1p), dtype=torch.float32, device=dev)
+        h = torch.empty((P * w["s_h"] * 64,), dtype=torch.uint8, device=dev)
+        bnd = torch.zeros(2, dtype=torch.float32, device=dev)            # [0] bound of H, [1] abs-max of the output
+        with on_device(dev):
+            check(lib.pvn3d_split_rows2(Pk, C2, kf.data_ptr(), ld_k, ka.data_ptr(), xk.data_ptr(), w["s_a"], st), "split_rows2")
+            check(lib.pvn3d_split_rows2(P, C1, uf.data_ptr(), ld_u, ua.data_ptr(), xu.data_ptr(), w["s_b"], st), "split_rows2")
+            # |H| <= ||Wb||_inf max|skip| + ||Wa||_inf max|known| + max|b1|  (interpolation weights are >= 0 and sum to 1)
+            check(lib.pvn3d_bound_affine(bnd.data_ptr(), ua.data_ptr(), w["nb"], ka.data_ptr(), w["na"], w["b1max"], st),
+                  "bound_affine")
+            check(lib.pvn3d_split_gemm2(Pk, n1p, w["s_a"], xk.data_ptr(), ka.data_ptr(), w["wa"].data_ptr(), w["sw_a"], None, 0,
+                                        None, 0, 0, 0, None, None, z.data_ptr(), n1p, None, None, 0, None, st), "split_gemm2")
+            check(lib.pvn3d_split_gemm2(P, w["n1"], w["s_b"], xu.data_ptr(), ua.data_ptr(), w["wb"].data_ptr(), w["sw_b"],
+                                        w["b1"].data_ptr(), 1, z.data_ptr(), n1p, n, m, idx.data_ptr(), weight.data_ptr(),
+                                        None, 0, None, h.data_ptr(), w["s_h"], bnd.data_ptr(), st), "split_gemm2")
+            check(lib.pvn3d_split_gemm2(P, w["n2"], w["s_h"], h.data_ptr(), bnd.data_ptr(), w["w2"].data_ptr(), w["sw_2"],
+                                        w["b2"].data_ptr(), 1, None, 0, 0, 0, None, None, out.data_ptr(), ld_out,
+                                        bnd.data_ptr() + 4, None, 0, None, st), "split_gemm2")
+        return bnd[1:2]
+    w = packed.s16(C2)
+    n1p = w["b1"].numel()
     xk = torch.empty((Pk * w["s_a"] * 96,), dtype=torch.uint8, device=dev)
     xu = torch.empty((P * w["s_b"] * 96,), dtype=torch.uint8, device=dev)
     z = torch.empty((Pk, n1p), dtype=torch.float32, device=dev)
@@ -578,6 +631,7 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
                                    w["s_h"], st), "split_gemm")
         check(lib.pvn3d_split_gemm(P, w["n2"], w["s_h"], h.data_ptr(), w["w2"].data_ptr(), w["b2"].data_ptr(), 1,
                                    None, 0, 0, 0, None, None, out.data_ptr(), ld_out, None, 0, st), "split_gemm")
+    return None
 
 
 def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_out=False):
@@ -619,17 +673,33 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
             and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0):
         pre, wa = packed.precontracted(C2)
         if split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
+            h2 = _fused_mlp.MLP_ARITH == "fp16x2"
             cache = getattr(packed, "_pre_s16", None)
-            if cache is None or cache[0] != C2:            # keyed on the split point like PackedMLP.precontracted()
-                cache = packed._pre_s16 = (C2, _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2)))
-            cache = cache[1]
-            S, n_out = _fused_mlp._slabs(C2), cache.size(0)
-            xs = torch.empty((B * m * S * 96,), dtype=torch.uint8, device=known_feats.device)
-            z = torch.empty((B, m, n_out), dtype=torch.float32, device=known_feats.device)
-            with on_device(known_feats.device):
-                check(lib.pvn3d_split_rows(B * m, C2, kf.data_ptr(), ld_k, xs.data_ptr(), S, _stream(known_feats)), "split_rows")
-                check(lib.pvn3d_split_gemm(B * m, n_out, S, xs.data_ptr(), cache.data_ptr(), None, 0, None, 0, 0, 0, None,
-                                           None, z.data_ptr(), n_out, None, 0, _stream(known_feats)), "split_gemm")
+            if cache is None or cache[0] != (C2, h2):       # keyed on the split point like PackedMLP.precontracted()
+                sw = _fused_mlp._pow2_weight_scale(wa) if h2 else 1.0
+                wp = _fused_mlp._pack_weight_h16(wa * sw, _fused_mlp._slabs(C2)) if h2 else \
+                    _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2))
+                cache = packed._pre_s16 = ((C2, h2), wp, sw)
+            wp, sw = cache[1], cache[2]
+            S, n_out = _fused_mlp._slabs(C2), wp.size(0)
+            dev, st = known_feats.device, _stream(known_feats)
+            z = torch.empty((B, m, n_out), dtype=torch.float32, device=dev)
+            if h2:
+                ka = table_absmax(kf, B * m, C2, ld_k)
+                amax = torch.zeros(1, dtype=torch.float32, device=dev)
+                xs = torch.empty((B * m * S * 64,), dtype=torch.uint8, device=dev)
+                with on_device(dev):
+                    check(lib.pvn3d_split_rows2(B * m, C2, kf.data_ptr(), ld_k, ka.data_ptr(), xs.data_ptr(), S, st), "split_rows2")
+                    check(lib.pvn3d_split_gemm2(B * m, n_out, S, xs.data_ptr(), ka.data_ptr(), wp.data_ptr(), sw, None, 0, None,
+                                                0, 0, 0, None, None, z.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st),
+                          "split_gemm2")
+                seed_absmax(z, B * m, pre.dims[1], n_out, amax)
+            else:
+                xs = torch.empty((B * m * S * 96,), dtype=torch.uint8, device=dev)
+                with on_device(dev):
+                    check(lib.pvn3d_split_rows(B * m, C2, kf.data_ptr(), ld_k, xs.data_ptr(), S, st), "split_rows")
+                    check(lib.pvn3d_split_gemm(B * m, n_out, S, xs.data_ptr(), wp.data_ptr(), None, 0, None, 0, 0, 0, None,
+                                               None, z.data_ptr(), n_out, None, 0, st), "split_gemm")
             kf, ld_k, C2, packed = z, n_out, pre.dims[1], pre
     vec = ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
     if (vec and _fused_mlp.MLP_ARITH == "fp16x2"
@@ -656,8 +726,9 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
         return out[:, :, :M].transpose(1, 2) if point_major_out else out
     if (point_major_out and fp_layerwise_shape_ok(B * n, C1, packed.dims)
             and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and ld_u % 4 == 0 and uf.data_ptr() % 16 == 0):
-        _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out)
-        return out[:, :, :M].transpose(1, 2)
+        amax = _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out)
+        view = out[:, :, :M].transpose(1, 2)
+        return seed_absmax(view, B * n, M, ld_out, amax) if amax is not None else view
     with on_device(known_feats.device):
         check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                       uf.data_ptr() if uf is not None else None, ld_u,

@@ -96,6 +96,32 @@ class PackedMLP(object):
         self._s16 = (c_first, d)
         return d
 
+    def h16(self, c_first):
+        """The two-layer chain for csrc/split_gemm.hip in the fp16 x 2 arithmetic (pvn3d_split_gemm2), built on first
+        use: layer 0 split at input channel `c_first` (W = [Wa | Wb]), every matrix in the h16 layout with its own
+        power-of-two scale.  -> dict(wa, wb, w2 int16 buffers; sw_a, sw_b, sw_2 scales; na, nb = ||Wa||_inf, ||Wb||_inf,
+        b1max; b1, b2 fp32 biases padded to 128; n1, n2; s_a, s_b, s_h slab counts)."""
+        cache = getattr(self, "_h16", None)
+        if cache is not None and cache[0] == c_first:
+            return cache[1]
+        assert self.n_layers == 2
+        (W1, W2) = self._folded
+        n1, n2 = W1.shape[0], W2.shape[0]
+        s_a, s_b, s_h = _slabs(c_first), _slabs(W1.shape[1] - c_first), _slabs(n1)
+
+        def pad_bias(b, n):
+            out = torch.zeros(((n + 127) // 128) * 128, dtype=torch.float32, device=b.device)
+            out[:n] = b[:n]
+            return out
+        Wa, Wb = W1[:, :c_first], W1[:, c_first:]
+        sw_a, sw_b, sw_2 = _pow2_weight_scale(Wa), _pow2_weight_scale(Wb), _pow2_weight_scale(W2)
+        d = dict(wa=_pack_weight_h16(Wa * sw_a, s_a), wb=_pack_weight_h16(Wb * sw_b, s_b), w2=_pack_weight_h16(W2 * sw_2, s_h),
+                 sw_a=sw_a, sw_b=sw_b, sw_2=sw_2, na=float(Wa.abs().sum(1).max()), nb=float(Wb.abs().sum(1).max()),
+                 b1max=float(self.b[0].abs().max()), b1=pad_bias(self.b[0], n1), b2=pad_bias(self.b[1], n2),
+                 n1=n1, n2=n2, s_a=s_a, s_b=s_b, s_h=s_h)
+        self._h16 = (c_first, d)
+        return d
+
     def split2(self):
         """-> (ctypes array of the fp16 x 2 weight buffers, ctypes float[3 * n_layers] layer_meta) for
         pvn3d_*_split2 (csrc/sa_mlp_split.hip, AR = 1), built on first use: per layer a power-of-two weight scale sw
@@ -103,10 +129,7 @@ class PackedMLP(object):
         if getattr(self, "_split2", None) is None:
             ws, meta = [], []
             for W, b in zip(self._folded, self.b):
-                wmax = float(W.abs().max())
-                sw = 2.0 ** (14 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0
-                while wmax * sw > 16384.0:
-                    sw *= 0.5
+                sw = _pow2_weight_scale(W)
                 ws.append(_pack_weight_split2(W * sw))
                 meta += [sw, float(W.abs().sum(1).max()), float(b.abs().max())]
             self._split2 = (ws, (ctypes.c_void_p * self.n_layers)(*[t.data_ptr() for t in ws]),
@@ -138,6 +161,32 @@ def _pack_weight_split(W):
     # (piece, mt, r, s, half, j) -> (s, mt, piece, half, r, j)
     out = pieces.view(3, MT, 32, S, 2, 8).permute(3, 1, 0, 4, 2, 5).contiguous()
     return out.view(torch.int16).view(S, MT, 3, 64, 8)
+
+
+def _pow2_weight_scale(W):
+    """The power of two that puts max|W| into (2^13, 2^14] (1 for a zero matrix)."""
+    wmax = float(W.abs().max()) if W.numel() else 0.0
+    if not wmax > 0:
+        return 1.0
+    sw = 2.0 ** (14 - math.ceil(math.log2(wmax)))
+    while wmax * sw > 16384.0:
+        sw *= 0.5
+    return sw
+
+
+def _pack_weight_h16(W, slabs):
+    """W (M, K) float32, already scaled into fp16's range -> int16 [roundup128(M)][slabs][2 pieces][16]: the h16 layout of
+    include/pvn3d_hip.h (hi = fp16(W), lo = fp16(W - hi), round to nearest), zero outside M x K."""
+    M, K = W.shape
+    Mp = ((M + 127) // 128) * 128
+    assert K <= 16 * slabs
+    Wp = torch.zeros((Mp, slabs * 16), dtype=torch.float32, device=W.device)
+    Wp[:M, :K] = W
+    hi = Wp.to(torch.float16)
+    lo = (Wp - hi.float()).to(torch.float16)
+    pieces = torch.stack([hi, lo], 0)                            # (2, Mp, slabs*16)
+    out = pieces.view(2, Mp, slabs, 16).permute(1, 2, 0, 3).contiguous()
+    return out.view(torch.int16)
 
 
 def _pack_weight_split2(W):

@@ -1392,3 +1392,72 @@ def test_three_interpolate_bit_exact_at_the_bench_batch_size(ext, orc, dev, c2, 
     for f in (0, B - 1):
         o = orc.three_interpolate(pts[f:f + 1].cpu().numpy(), idx[f:f + 1].cpu().numpy(), w[f:f + 1].cpu().numpy())
         assert np.array_equal(got[f:f + 1].cpu().numpy(), o)
+
+
+def test_split_gemm2_c_abi(dev):
+    """pvn3d_split_rows2 / pvn3d_split_gemm2 / pvn3d_bound_affine / pvn3d_absmax through the C-ABI (fp16 x 2 arithmetic):
+    h16 rows carry the scaled values to 2^-22, a GEMM's fp32 output agrees with float64 like the three-piece GEMM's, its
+    h16 output is its fp32 output split under the named bound, out_absmax is the abs-max of the fp32 output, the
+    gathered-add epilogue equals three_interpolate of the table; bad arguments come back as an error code."""
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp as fm
+    st = torch.cuda.current_stream(dev).cuda_stream
+    torch.manual_seed(4)
+
+    def h16_to_float(buf, rows, S):
+        return buf.view(torch.float16).view(rows, S, 2, 16).double().sum(2).reshape(rows, S * 16)
+
+    for (P, K, N) in ((300, 72, 200), (1000, 512, 384)):
+        X = torch.randn(P, K, device=dev) * 37.0
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        S = fm._slabs(K)
+        xb = torch.zeros(1, device=dev)
+        assert lib.pvn3d_absmax(P, K, X.data_ptr(), K, xb.data_ptr(), st) == 0
+        assert float(xb) == float(X.abs().max())
+        xs = torch.empty(P * S * 64, dtype=torch.uint8, device=dev)
+        assert lib.pvn3d_split_rows2(P, K, X.data_ptr(), K, xb.data_ptr(), xs.data_ptr(), S, st) == 0
+        import math
+        sx = math.ldexp(1.0, 14 - math.frexp(float(xb))[1])
+        back = h16_to_float(xs, P, S)[:, :K] / sx
+        assert float((back - X.double()).abs().max()) <= 2.0 ** -21 * float(xb)
+        assert float(h16_to_float(xs, P, S)[:, K:].abs().max() if K < 16 * S else 0.0) == 0.0
+        sw = fm._pow2_weight_scale(W)
+        ws = fm._pack_weight_h16(W * sw, S)
+        Np = ws.size(0)
+        bp = torch.zeros(Np, device=dev); bp[:N] = b
+        out = torch.full((P, Np), float("nan"), device=dev)
+        Sout = fm._slabs(N)
+        outs = torch.empty(P * Sout * 64, dtype=torch.uint8, device=dev)
+        bounds = torch.zeros(2, device=dev)            # [0] bound of the output, [1] abs-max of the output
+        wn = float(W.abs().sum(1).max())
+        assert lib.pvn3d_bound_affine(bounds.data_ptr(), xb.data_ptr(), wn, None, 0.0, float(b.abs().max()), st) == 0
+        assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, bp.data_ptr(), 1, None, 0, 0, 0,
+                                     None, None, out.data_ptr(), Np, bounds.data_ptr() + 4, outs.data_ptr(), Sout,
+                                     bounds.data_ptr(), st) == 0
+        want = torch.relu(X.double() @ W.double().T + b.double())
+        got = out[:, :N].double()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) / scale < 2e-6
+        assert float(bounds[1]) == float(out[:, :N].abs().max()) and float(bounds[0]) >= float(bounds[1])
+        so = math.ldexp(1.0, 14 - math.frexp(float(bounds[0]))[1])
+        assert float((h16_to_float(outs, P, Sout)[:, :N] / so - got).abs().max()) <= 2.0 ** -21 * float(bounds[0])
+        # gathered add
+        Bf, n, m = 4, P // 4, 37
+        Z = torch.randn(Bf * m, Np, device=dev)
+        idx = torch.randint(0, m, (P, 3), device=dev, dtype=torch.int32)
+        wg = torch.rand(P, 3, device=dev)
+        out2 = torch.empty((P, Np), device=dev)
+        assert lib.pvn3d_split_gemm2(Bf * n, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, None, 0, Z.data_ptr(), Np, n, m,
+                                     idx.data_ptr(), wg.data_ptr(), out2.data_ptr(), Np, None, None, 0, None, st) == 0
+        f = (torch.arange(Bf * n, device=dev) // n).long()
+        zg = sum(Z.double()[f * m + idx[:Bf * n, t].long()] * wg[:Bf * n, t:t + 1].double() for t in range(3))
+        want2 = X[:Bf * n].double() @ W.double().T + zg[:, :N]
+        assert float((out2[:Bf * n, :N].double() - want2).abs().max()) / max(1.0, float(want2.abs().max())) < 2e-6
+        # error codes: odd slab count, no output, missing bound, a scale that is not a power of two, h16 output without its bound
+        assert lib.pvn3d_split_gemm2(P, N, 3, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0, 0, None, None, out.data_ptr(), Np, None, None, 0, None, st) != 0
+        assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0, 0, None, None, None, 0, None, None, 0, None, st) != 0
+        assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), None, ws.data_ptr(), sw, None, 0, None, 0, 0, 0, None, None, out.data_ptr(), Np, None, None, 0, None, st) != 0
+        assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), 3.0, None, 0, None, 0, 0, 0, None, None, out.data_ptr(), Np, None, None, 0, None, st) != 0
+        assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0, 0, None, None, None, 0, None, outs.data_ptr(), Sout, None, st) != 0
+        assert lib.pvn3d_split_rows2(P, K, X.data_ptr(), K, None, xs.data_ptr(), S, st) != 0
