@@ -1158,41 +1158,52 @@ extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, c
 // max |x| over a point-major table [rows][ld] (channels [0, c)) -> *out (device float), as an atomic max on the bit
 // pattern (non-negative floats order like unsigned integers).  *out must hold a value <= the result (0) beforehand.
 namespace {
+// thread -> (row slot ty, channel-group slot tx) with cx = 2^cx_log2 slots across a row: no division anywhere (a 64-bit
+// `t / c4` per element made the first version of this kernel 4x slower than its memory traffic)
 __global__ __launch_bounds__(256) void absmax_kernel(long long rows, int c, const float* __restrict__ src, int ld,
-                                                      unsigned* __restrict__ out) {
-  const int c4 = c >> 2;
+                                                      unsigned* __restrict__ out, int cx_log2, int vec) {
+  const int cx = 1 << cx_log2, tx = threadIdx.x & (cx - 1), ty = threadIdx.x >> cx_log2, rpb = 256 >> cx_log2;
   float m = 0.f;
-  if ((ld & 3) == 0 && c4 > 0) {
-    const long long n4 = rows * c4;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long long)gridDim.x * 256) {
-      const long long r = t / c4;
-      const int q = (int)(t - r * c4);
-      const float4 v = *reinterpret_cast<const float4*>(src + r * ld + 4 * q);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-    }
-    const int rest = c - 4 * c4;
-    if (rest) {
-      for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256)
-        for (int k = 0; k < rest; ++k) m = fmaxf(m, fabsf(src[r * ld + 4 * c4 + k]));
+  if (vec) {
+    const int c4 = c >> 2, rest = c & 3;
+    for (long long r = (long long)blockIdx.x * rpb + ty; r < rows; r += (long long)gridDim.x * rpb) {
+      const float* row = src + r * ld;
+      for (int q = tx; q < c4; q += cx) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+      if (tx < rest) m = fmaxf(m, fabsf(row[4 * c4 + tx]));
     }
   } else {
-    const long long n = rows * c;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
-      const long long r = t / c;
-      m = fmaxf(m, fabsf(src[r * ld + (int)(t - r * c)]));
+    for (long long r = (long long)blockIdx.x * rpb + ty; r < rows; r += (long long)gridDim.x * rpb) {
+      const float* row = src + r * ld;
+      for (int q = tx; q < c; q += cx) m = fmaxf(m, fabsf(row[q]));
     }
   }
+  // one atomic per workgroup (thousands of them on one address serialise at the L2: 12 ns each)
+  __shared__ float s_m[4];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));
+  }
 }
 }  // namespace
 extern "C" int pvn3d_absmax(long long rows, int c, const float* src, int ld_src, float* out_max, void* stream) {
   if (rows <= 0 || c <= 0) return 0;
   if (!src || !out_max || ld_src < c) return (int)hipErrorInvalidValue;
-  const long long work = rows * ((c + 3) / 4);
-  const unsigned blocks = (unsigned)(work < 256LL * 2048 ? (work + 255) / 256 : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, c, src, ld_src, (unsigned*)out_max);
+  const int vec = ((ld_src & 3) == 0 && ((uintptr_t)src & 15) == 0 && c >= 4) ? 1 : 0;
+  const int per_row = vec ? (c + 3) / 4 : c;                 // work items across a row
+  int cx_log2 = 0;
+  while ((1 << cx_log2) < per_row && cx_log2 < 6) ++cx_log2;  // 1 .. 64 slots across
+  const int rpb = 256 >> cx_log2;
+  const long long want = (rows + rpb - 1) / rpb;
+  const unsigned blocks = (unsigned)(want < 1024 ? want : 1024);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, c, src, ld_src, (unsigned*)out_max,
+                     cx_log2, vec);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }

@@ -302,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
   if (a.out_absmax) {           // the consumer's bound on |out_f| (pvn3d_absmax without a second pass over the table)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0 && amax > 0.f) atomicMax(a.out_absmax, __float_as_uint(amax));
+    // (a plain read first: once the running maximum is above this wave's, no atomic is issued -- thousands of atomics
+    // on one address serialise at the L2)
+    if (lane == 0 && amax > 0.f && __float_as_uint(amax) > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(a.out_absmax, __float_as_uint(amax));
   }
 }
 
