@@ -88,9 +88,14 @@ def main():
         # v_mfma_f32_32x32x16_bf16 (1024 flop/clk/SIMD); the fp32 chains v_mfma_f32_32x32x2_f32 (64 flop/clk/SIMD).
         # `tflops` stays the algorithmic (fp32-equivalent) rate; `tflops_peak_at_clock` is what the pipe the launch runs
         # on could deliver of THAT quantity at the measured clock (bf16 peak / 6 for the split chains).
+        # fp16 x 2 chains (round 5; template argument AR = 1 of mlp_chain_s3_kernel / sg_gemm_kernel): three fp16 partial
+        # products per multiply on v_mfma_f32_32x32x16_f16 -> bf16/fp16 peak / 3.
         split = "s3_kernel" in kern or "sg_gemm" in kern
-        per_clk = 1024.0 / 6.0 if split else 64.0
-        rows.append(dict(chain=name, kernel=kern, arithmetic="bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split
+        last = dur[g[-1]][1]
+        fp16 = split and (last.rstrip().endswith(", 1>") or "sg_gemm_kernel<1>" in last)
+        per_clk = 1024.0 / 3.0 if fp16 else 1024.0 / 6.0 if split else 64.0
+        rows.append(dict(chain=name, kernel=kern, arithmetic="fp16x2 split (3 fp16 MFMA products per fp32 multiply)" if fp16
+                         else "bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split
                          else "fp32 MFMA", duration_us=us, effective_clock_ghz=clk,
                          mfma_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui),
                          mfma_busy_vs_sq_busy=c["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * c["SQ_BUSY_CYCLES"]),

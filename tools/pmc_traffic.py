@@ -50,7 +50,8 @@ def run_pass(counter, outdir, extra=()):
         stage_after[i] = nxt
     for r, st in zip(rows, stage_after):
         name = r["Kernel_Name"]
-        if "sg_gemm_kernel" in name or "sg_split_rows_kernel" in name:
+        if ("sg_gemm_kernel" in name or "sg_split_rows_kernel" in name or "absmax_kernel" in name
+                or "sg_bound_affine_kernel" in name):
             name = "%s [%s]" % (name.split("(")[0] if not name.startswith("(") else name[:60], st or "fp_mlp")
         per_kernel[name] += float(r["Counter_Value"]) * 1024.0
     return per_kernel
