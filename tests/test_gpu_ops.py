@@ -1461,3 +1461,43 @@ def test_split_gemm2_c_abi(dev):
         assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), 3.0, None, 0, None, 0, 0, 0, None, None, out.data_ptr(), Np, None, None, 0, None, st) != 0
         assert lib.pvn3d_split_gemm2(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0, 0, None, None, None, 0, None, outs.data_ptr(), Sout, None, st) != 0
         assert lib.pvn3d_split_rows2(P, K, X.data_ptr(), K, None, xs.data_ptr(), S, st) != 0
+
+
+@pytest.mark.parametrize("gain,outlier", [(2.0 ** 20, 0.0), (2.0 ** -20, 0.0), (1.0, 3.0e7), (1.0e-3, 5.0e4)])
+def test_fp16x2_chains_keep_fp32_accuracy_over_extreme_operand_ranges(dev, gain, outlier):
+    """fp16 has 5 exponent bits: the two-piece fp16 chains scale every operand by an exact power of two taken from a
+    device-side bound (csrc/sa_mlp_split.hip, AR = 1).  Features 2^20 times larger / smaller than usual, and ordinary
+    features with one huge outlier (which sets the bound for everyone: values 1e7 times smaller than the bound still
+    enter with an absolute error far below fp32's rounding of the sums they enter), must come out as close to the
+    fp32-MFMA chain as ordinary inputs do: 4e-6 of the output scale."""
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _fused_mlp, _small_batch
+    torch.manual_seed(17)
+    b, n, npoint, ns, c_in = 4, 1024, 256, 16, 64
+    sa = pm.PointnetSAModule(mlp=[c_in, 128, 196, 256], npoint=npoint, radius=0.08, nsample=ns).to(dev).eval()
+    fp = pm.PointnetFPModule(mlp=[256 + c_in, 256, 256]).to(dev).eval()
+    _randomize_bn(sa); _randomize_bn(fp)
+    xyz = T(clouds(91, b, n, 0.1), dev)
+    feats = (torch.randn(b, n, c_in, device=dev) * gain)
+    if outlier:
+        feats[1, 77, 5] = outlier
+        feats[3, 900, 60] = -outlier
+    feats = feats.transpose(1, 2)
+    few = _small_batch.MAX_FUSED_WGS
+    _small_batch.MAX_FUSED_WGS = 0
+    outs = {}
+    try:
+        for arith in ("fp16x2", "fp32"):
+            _fused_mlp.MLP_ARITH = arith
+            try:
+                with torch.no_grad():
+                    new_xyz, f1 = sa(xyz, feats)
+                    y = fp(xyz, new_xyz, feats, f1)
+            finally:
+                _fused_mlp.MLP_ARITH = _DEFAULT_ARITH
+            outs[arith] = (f1.clone(), y.clone())
+    finally:
+        _small_batch.MAX_FUSED_WGS = few
+    for a, r in zip(outs["fp16x2"], outs["fp32"]):
+        assert torch.isfinite(a).all() and not torch.equal(a, r)
+        scale = max(float(r.abs().max()), 1e-30)
+        assert float((a - r).abs().max()) / scale < 4e-6, (gain, outlier, float((a - r).abs().max()) / scale)
