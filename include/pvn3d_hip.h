@@ -250,6 +250,9 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  *                 coordinates of `xyz` (the relative coordinates are then within twice that); FP: unknown_absmax may be
  *                 NULL when c1 == 0.  The bounds must hold: a larger value costs nothing measurable, a smaller one
  *                 saturates operands at 65504 / scale.
+ *   out_absmax    DEVICE float or NULL: atomic max of |output| over the launch (accumulates: set it to 0 before the first
+ *                 launch that writes a table) -- the *_absmax of the level that consumes this output, without a pass of
+ *                 its own.
  * pvn3d_mlp_split2_ok answers pvn3d_mlp_split_ok's question for these kernels (smaller LDS footprint; one more chain
  * shape: SA level 1).  pvn3d_absmax: *out_max = max(*out_max, max |src[r][ch]|, r < rows, ch < c) as an atomic max on
  * the bit pattern -- set *out_max to 0 (or to a previous bound) before the call. */
@@ -258,12 +261,13 @@ int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const f
                                 const float* features_pm, int ld_feat, const int* idx, int n_layers,
                                 const int* dims_host, const void* const* w_split2, const float* const* bias_padded,
                                 const float* layer_meta, const float* features_absmax, const float* xyz_absmax,
-                                float* out_pm, int ld_out, int out_coff, void* stream);
+                                float* out_pm, int ld_out, int out_coff, float* out_absmax, void* stream);
 int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
                                int n_layers, const int* dims_host, const void* const* w_split2,
                                const float* const* bias_padded, const float* layer_meta, const float* known_absmax,
-                               const float* unknown_absmax, float* out, int out_point_major, int ld_out, void* stream);
+                               const float* unknown_absmax, float* out, int out_point_major, int ld_out,
+                               float* out_absmax, void* stream);
 int pvn3d_absmax(long long rows, int c, const float* src, int ld_src, float* out_max, void* stream);
 
 /* Layer-by-layer split-bf16 SharedMLP for chains whose hidden layer is too wide for the fused kernel (FP levels 2-3 of

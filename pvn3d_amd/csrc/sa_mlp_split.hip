@@ -93,6 +93,7 @@ struct S3Args {
   // device-side bounds of the layer-0 input: B_0 = max(*bound_a, mul_b * *bound_b, 1e-30)
   float sw[S3_MAX_LAYERS], wnorm[S3_MAX_LAYERS], bmax[S3_MAX_LAYERS];
   const float* bound_a; const float* bound_b; float mul_b;
+  unsigned* out_absmax;                         // device or nullptr: atomic max of |output| (bit pattern) for the consumer
   int dbg;                                      // tuning builds only (-DPVN3D_S3_TUNING, env PVN3D_S3_DBG): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
 };
 
@@ -406,6 +407,7 @@ struct S3Consumer {
   const float* s_bias;
   S3Ctl* ctl;
   S3Scales sc;             // fp16 x 2: power-of-two scales (all 1 for bf16 x 3)
+  float amax;              // running max |output| of this lane (out_absmax)
   int lane_, wave;
   unsigned phase;          // barrier arrivals expected so far
   unsigned chunk_no;       // chunks of this workgroup consumed so far (all blocks)
@@ -661,10 +663,11 @@ struct S3Consumer {
           const int row = mt * 32 + 8 * g + 4 * half;
           if (row + 3 < M) {
             *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g] * om, v[4 * g + 1] * om, v[4 * g + 2] * om, v[4 * g + 3] * om);
+            amax = fmaxf(amax, fmaxf(fmaxf(v[4 * g], v[4 * g + 1]), fmaxf(v[4 * g + 2], v[4 * g + 3])) * om);   // (post-ReLU: >= 0)
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (row + k < M) o[8 * g + k] = v[4 * g + k] * om;
+              if (row + k < M) { o[8 * g + k] = v[4 * g + k] * om; amax = fmaxf(amax, v[4 * g + k] * om); }
           }
         }
       }
@@ -792,12 +795,12 @@ struct S3Consumer {
           if (row < M && (ns < 64 || half == 0)) {
             float* o = out + ((size_t)bi * a.m + jbase) * a.ld_out + a.coff + row;
             if (nout <= 2) {
-              if (jbase < a.m) o[0] = __int_as_float(v[0]) * om;
-              if (nout == 2 && jbase + 1 < a.m) o[a.ld_out] = __int_as_float(v[1]) * om;
+              if (jbase < a.m) { o[0] = __int_as_float(v[0]) * om; amax = fmaxf(amax, __int_as_float(v[0]) * om); }
+              if (nout == 2 && jbase + 1 < a.m) { o[a.ld_out] = __int_as_float(v[1]) * om; amax = fmaxf(amax, __int_as_float(v[1]) * om); }
             } else {
 #pragma unroll
               for (int q = 0; q < 32; ++q)
-                if (q < nout && jbase + q < a.m) o[(size_t)q * a.ld_out] = __int_as_float(v[q]) * om;
+                if (q < nout && jbase + q < a.m) { o[(size_t)q * a.ld_out] = __int_as_float(v[q]) * om; amax = fmaxf(amax, __int_as_float(v[q]) * om); }
             }
           }
         }
@@ -815,6 +818,8 @@ struct S3Consumer {
             for (int k = 0; k < 4; ++k) {
               if (row + k < M) {
                 const float v0 = fmaxf(acc[t][0][4 * g + k], 0.f) * om, v1 = fmaxf(acc[t][1][4 * g + k], 0.f) * om;
+                if (g0 < a.cols_total) amax = fmaxf(amax, v0);
+                if (g1 < a.cols_total) amax = fmaxf(amax, v1);
                 if (a.point_major) {
                   if (g0 < a.cols_total) out[((size_t)bi * a.cols_total + g0) * a.ld_out + a.coff + row + k] = v0;
                   if (g1 < a.cols_total) out[((size_t)bi * a.cols_total + g1) * a.ld_out + a.coff + row + k] = v1;
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, &ctl, sc, lane, wave, 0u, 0u, 0};
+  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, &ctl, sc, 0.f, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -908,6 +913,13 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
       cbar(&ctl, c.phase, lane);
       if (wave == 0 && lane == 0) __hip_atomic_fetch_add(&ctl.blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+  }
+  if (a.out_absmax) {      // the consumer's bound on this table: one (conditional) atomic per MFMA wave of the launch
+    float m = c.amax;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0 && m > 0.f && __float_as_uint(m) > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(a.out_absmax, __float_as_uint(m));
   }
 }
 
@@ -1069,7 +1081,7 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
                        const float* features_pm, int ld_feat, const int* idx, int n_layers, const int* dims_host,
                        const void* const* w_split, const float* const* bias_padded, const float* layer_meta,
                        const float* bound_a, const float* bound_b, float mul_b, float* out_pm, int ld_out, int out_coff,
-                       void* stream) {
+                       float* out_absmax, void* stream) {
   if (b <= 0 || m <= 0) return 0;
   if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
     return (int)hipErrorInvalidValue;
@@ -1079,6 +1091,7 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   S3Args a = {};
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
   if (arith == 1 && !s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, mul_b)) return (int)hipErrorInvalidValue;
+  a.out_absmax = (unsigned*)out_absmax;
   a.is_sa = 1;
   a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
   a.idx = idx;
@@ -1096,24 +1109,24 @@ extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsampl
                                           const float* const* bias_padded, float* out_pm, int ld_out, int out_coff,
                                           void* stream) {
   return s3_sa_entry(0, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split,
-                     bias_padded, nullptr, nullptr, nullptr, 0.f, out_pm, ld_out, out_coff, stream);
+                     bias_padded, nullptr, nullptr, nullptr, 0.f, out_pm, ld_out, out_coff, nullptr, stream);
 }
 extern "C" int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz,
                                            const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
                                            int n_layers, const int* dims_host, const void* const* w_split2,
                                            const float* const* bias_padded, const float* layer_meta,
                                            const float* features_absmax, const float* xyz_absmax, float* out_pm,
-                                           int ld_out, int out_coff, void* stream) {
+                                           int ld_out, int out_coff, float* out_absmax, void* stream) {
   // |p - c| <= 2 max|xyz| bounds the relative coordinates whatever the index list holds
   return s3_sa_entry(1, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split2,
-                     bias_padded, layer_meta, features_absmax, xyz_absmax, 2.f, out_pm, ld_out, out_coff, stream);
+                     bias_padded, layer_meta, features_absmax, xyz_absmax, 2.f, out_pm, ld_out, out_coff, out_absmax, stream);
 }
 
 static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                        const float* unknown_pm, int ld_unknown, const int* idx, const float* weight, int n_layers,
                        const int* dims_host, const void* const* w_split, const float* const* bias_padded,
                        const float* layer_meta, const float* bound_a, const float* bound_b, float* out,
-                       int out_point_major, int ld_out, void* stream) {
+                       int out_point_major, int ld_out, float* out_absmax, void* stream) {
   if (b <= 0 || n <= 0) return 0;
   if (!known_pm || !idx || !weight || !out || !dims_host || !w_split || !bias_padded || (c1 > 0 && !unknown_pm))
     return (int)hipErrorInvalidValue;
@@ -1125,6 +1138,7 @@ static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const flo
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
   if (arith == 1 && (!s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, 1.f) || (c1 > 0 && !bound_b)))
     return (int)hipErrorInvalidValue;
+  a.out_absmax = (unsigned*)out_absmax;
   a.is_sa = 0;
   a.idx = idx; a.weight = weight;
   a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
@@ -1142,17 +1156,18 @@ extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, co
                                          const float* const* bias_padded, float* out, int out_point_major, int ld_out,
                                          void* stream) {
   return s3_fp_entry(0, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
-                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, stream);
+                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, nullptr, stream);
 }
 extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                           const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
                                           int n_layers, const int* dims_host, const void* const* w_split2,
                                           const float* const* bias_padded, const float* layer_meta,
                                           const float* known_absmax, const float* unknown_absmax, float* out,
-                                          int out_point_major, int ld_out, void* stream) {
+                                          int out_point_major, int ld_out, float* out_absmax, void* stream) {
   // interpolation weights are non-negative and sum to 1: |interp(known)| <= max|known|
   return s3_fp_entry(1, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
-                     w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, stream);
+                     w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, out_absmax,
+                     stream);
 }
 
 // max |x| over a point-major table [rows][ld] (channels [0, c)) -> *out (device float), as an atomic max on the bit

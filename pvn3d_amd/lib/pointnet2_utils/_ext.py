@@ -435,6 +435,27 @@ def table_absmax(base, rows, c, ld):
     return out
 
 
+def table_h16(base, rows, c, ld, slabs):
+    """-> (h16 buffer, bound): the (rows, c) point-major table at `base` as an h16 matrix of `slabs` 16-k slabs
+    (pvn3d_split_rows2) together with the device-side bound it was written with.  Cached on the tensor object like the
+    bound: a level's output is split once although two consumers contract over it (SA level l + 1's pre-contraction and
+    the skip half of an FP level read the same table)."""
+    bound = table_absmax(base, rows, c, ld)
+    key = (base.data_ptr(), int(rows), int(c), int(ld), int(slabs), base._version, bound.data_ptr())
+    cache = getattr(base, "_pvn3d_h16", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], bound
+    xs = torch.empty((int(rows) * int(slabs) * 64,), dtype=torch.uint8, device=base.device)
+    with on_device(base.device):
+        check(lib.pvn3d_split_rows2(int(rows), int(c), base.data_ptr(), int(ld), bound.data_ptr(), xs.data_ptr(), int(slabs),
+                                    _stream(base)), "split_rows2")
+    try:
+        base._pvn3d_h16 = (key, xs)
+    except AttributeError:
+        pass
+    return xs, bound
+
+
 def seed_absmax(view, rows, c, ld, bound):
     """Attach `bound` (device float32[1], already known -- e.g. a GEMM's out_absmax) to `view` as the cached result of
     table_absmax(view, rows, c, ld)."""
@@ -442,8 +463,10 @@ def seed_absmax(view, rows, c, ld, bound):
     return view
 
 
-def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, out_coff=0):
-    """Fused group -> SharedMLP (BN folded, fp32 MFMA) -> max over nsample, inference only.
+def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, out_coff=0, out_absmax=None):
+    """(out_absmax: optional device float32[1] that the fp16 x 2 kernel raises to max|output| -- the caller zeroes it once
+    per output table and seeds the table's bound with it; ignored by the other arithmetics.)
+    Fused group -> SharedMLP (BN folded, fp32 MFMA) -> max over nsample, inference only.
     packed: _fused_mlp.PackedMLP built with n_xyz_first=3 when use_xyz.  features: (B, C, n) in
     any layout (a transposed view of a point-major buffer is used in place).  Writes the
     packed.dims[-1] pooled channels into the point-major buffer out_pm (B, npoint, ld) at channel
@@ -478,7 +501,10 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
             check(lib.pvn3d_sa_mlp_maxpool_split2(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),
                                                   ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c,
                                                   meta, fa.data_ptr(), xa.data_ptr(), out_pm.data_ptr(), ld_out, out_coff,
+                                                  out_absmax.data_ptr() if out_absmax is not None else None,
                                                   _stream(xyz)), "sa_mlp_maxpool_split2")
+        if out_absmax is not None:
+            out_absmax._pvn3d_written = True
         return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
     if (vec and _fused_mlp.split_arith()
             and lib.pvn3d_mlp_split_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
@@ -542,11 +568,9 @@ def sa_precontract(features, packs, nsamples):
     y = torch.empty((B, n, n_out), dtype=torch.float32, device=dev)
     amax = None
     if h2:
-        fa = table_absmax(feat, B * n, C, ld)
+        xs, fa = table_h16(feat, B * n, C, ld, S)
         amax = torch.zeros(1, dtype=torch.float32, device=dev)
-        xs = torch.empty((B * n * S * 64,), dtype=torch.uint8, device=dev)
         with on_device(dev):
-            check(lib.pvn3d_split_rows2(B * n, C, feat.data_ptr(), ld, fa.data_ptr(), xs.data_ptr(), S, st), "split_rows2")
             check(lib.pvn3d_split_gemm2(B * n, n_out, S, xs.data_ptr(), fa.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0,
                                         0, None, None, y.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st), "split_gemm2")
     else:
@@ -593,15 +617,12 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
         # bounds -- abs-max of the two inputs, the rigorous bound of H from them -- and the output's abs-max for its consumer
         w = packed.h16(C2)
         n1p = w["b1"].numel()
-        ka, ua = table_absmax(kf, Pk, C2, ld_k), table_absmax(uf, P, C1, ld_u)
-        xk = torch.empty((Pk * w["s_a"] * 64,), dtype=torch.uint8, device=dev)
-        xu = torch.empty((P * w["s_b"] * 64,), dtype=torch.uint8, device=dev)
+        xk, ka = table_h16(kf, Pk, C2, ld_k, w["s_a"])
+        xu, ua = table_h16(uf, P, C1, ld_u, w["s_b"])
         z = torch.empty((Pk, n1p), dtype=torch.float32, device=dev)
         h = torch.empty((P * w["s_h"] * 64,), dtype=torch.uint8, device=dev)
         bnd = torch.zeros(2, dtype=torch.float32, device=dev)            # [0] bound of H, [1] abs-max of the output
         with on_device(dev):
-            check(lib.pvn3d_split_rows2(Pk, C2, kf.data_ptr(), ld_k, ka.data_ptr(), xk.data_ptr(), w["s_a"], st), "split_rows2")
-            check(lib.pvn3d_split_rows2(P, C1, uf.data_ptr(), ld_u, ua.data_ptr(), xu.data_ptr(), w["s_b"], st), "split_rows2")
             # |H| <= ||Wb||_inf max|skip| + ||Wa||_inf max|known| + max|b1|  (interpolation weights are >= 0 and sum to 1)
             check(lib.pvn3d_bound_affine(bnd.data_ptr(), ua.data_ptr(), w["nb"], ka.data_ptr(), w["na"], w["b1max"], st),
                   "bound_affine")
@@ -685,11 +706,9 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
             dev, st = known_feats.device, _stream(known_feats)
             z = torch.empty((B, m, n_out), dtype=torch.float32, device=dev)
             if h2:
-                ka = table_absmax(kf, B * m, C2, ld_k)
+                xs, ka = table_h16(kf, B * m, C2, ld_k, S)
                 amax = torch.zeros(1, dtype=torch.float32, device=dev)
-                xs = torch.empty((B * m * S * 64,), dtype=torch.uint8, device=dev)
                 with on_device(dev):
-                    check(lib.pvn3d_split_rows2(B * m, C2, kf.data_ptr(), ld_k, ka.data_ptr(), xs.data_ptr(), S, st), "split_rows2")
                     check(lib.pvn3d_split_gemm2(B * m, n_out, S, xs.data_ptr(), ka.data_ptr(), wp.data_ptr(), sw, None, 0, None,
                                                 0, 0, 0, None, None, z.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st),
                           "split_gemm2")
@@ -705,6 +724,8 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     if (vec and _fused_mlp.MLP_ARITH == "fp16x2"
             and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
         w2, meta = packed.split2()
+        # a point-major output feeds another fused level: leave its abs-max for that level's operand scale
+        amax = torch.zeros(1, dtype=torch.float32, device=known_feats.device) if point_major_out else None
         ka = table_absmax(kf, B * m, C2, ld_k)
         ua = table_absmax(uf, B * n, C1, ld_u) if uf is not None else None
         with on_device(known_feats.device):
@@ -712,9 +733,12 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                                                  uf.data_ptr() if uf is not None else None, ld_u, idx.data_ptr(),
                                                  weight.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c, meta,
                                                  ka.data_ptr(), ua.data_ptr() if ua is not None else None, out.data_ptr(),
-                                                 1 if point_major_out else 0, ld_out, _stream(known_feats)),
+                                                 1 if point_major_out else 0, ld_out,
+                                                 amax.data_ptr() if amax is not None else None, _stream(known_feats)),
                   "fp_interp_mlp_split2")
-        return out[:, :, :M].transpose(1, 2) if point_major_out else out
+        if point_major_out:
+            return seed_absmax(out[:, :, :M].transpose(1, 2), B * n, M, ld_out, amax)
+        return out
     if (vec and _fused_mlp.split_arith()
             and lib.pvn3d_mlp_split_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
         with on_device(known_feats.device):

@@ -186,6 +186,10 @@ class _PointnetSAModuleBase(nn.Module):
         if features is not None and all(g.use_xyz for g in self.groupers) and cols_min >= 64 * _small_batch.MAX_FUSED_WGS:
             with _stage("sa_mlp"):
                 pre = _ext.sa_precontract(features, packs, [g.nsample for g in self.groupers])
+        # fp16 x 2 chains leave the abs-max of what they write for the level that consumes this table (no extra pass);
+        # it only counts if EVERY scale of the level went through such a chain
+        amax = torch.zeros(1, dtype=torch.float32, device=xyz.device) if _fused_mlp.MLP_ARITH == "fp16x2" else None
+        amax_writers = 0
         for si, (grouper, mlp, packed, idx, off) in enumerate(zip(self.groupers, self.mlps, packs, idxs, offs)):
             if idx is None:
                 with _stage("ball_query"):
@@ -200,10 +204,18 @@ class _PointnetSAModuleBase(nn.Module):
                     _small_batch.sa_scale(xyz, new_xyz, features, idx, grouper.use_xyz or features is None, small, out_pm,
                                           off)
                 elif pre is not None:
-                    _ext.sa_mlp_maxpool(xyz, new_xyz, pre[si][0], idx, True, pre[si][1], out_pm, off)
+                    if amax is not None:
+                        amax._pvn3d_written = False
+                    _ext.sa_mlp_maxpool(xyz, new_xyz, pre[si][0], idx, True, pre[si][1], out_pm, off, out_absmax=amax)
+                    amax_writers += bool(amax is not None and amax._pvn3d_written)
                 else:
-                    _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off)
+                    if amax is not None:
+                        amax._pvn3d_written = False
+                    _ext.sa_mlp_maxpool(xyz, new_xyz, features, idx, grouper.use_xyz, packed, out_pm, off, out_absmax=amax)
+                    amax_writers += bool(amax is not None and amax._pvn3d_written)
         out = out_pm[:, :, :sum(widths)].transpose(1, 2)
+        if amax is not None and amax_writers == len(self.groupers) and getattr(self, "_point_major_out", False):
+            _ext.seed_absmax(out, out_pm.size(0) * out_pm.size(1), sum(widths), out_pm.size(2), amax)
         # Stand-alone the module returns what the reference returns: a contiguous (B, C_out, npoint) tensor
         # (a caller may .view() it).  Pointnet2MSG marks its own levels `_point_major_out`: the next fused
         # level gathers rows from the point-major buffer in place, so the transposed view is handed over.

@@ -340,7 +340,9 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
         # layer (three split GEMMs and two row splits each); nothing on the small-batch route, nothing on bf16 x 3 chains
         assert c["pvn3d_sa_mlp_maxpool"] == 2 and c["pvn3d_sa_mlp_maxpool_split2"] == 6 and c["pvn3d_sa_mlp_maxpool_split"] == 0
         assert c["pvn3d_fp_interp_mlp_split2"] == 2 and c["pvn3d_fp_interp_mlp"] == 0 and c["pvn3d_fp_interp_mlp_split"] == 0
-        assert c["pvn3d_split_gemm2"] == 2 + 1 + 3 + 3 and c["pvn3d_split_rows2"] == 2 + 1 + 2 + 2      # all in fp16 x 2
+        # (row splits: SA1's and SA2's outputs are split ONCE although the next SA level's pre-contraction and an FP
+        # level's skip half both contract over them: 7 tables minus 2 shared)
+        assert c["pvn3d_split_gemm2"] == 2 + 1 + 3 + 3 and c["pvn3d_split_rows2"] == 2 + 1 + 2 + 2 - 2   # all in fp16 x 2
         assert c["pvn3d_split_gemm"] == 0 and c["pvn3d_split_rows"] == 0
         assert not any(k.startswith("pvn3d_sb_") for k in spy_sb.calls)
     worst, worst_proj, proj_by_level = {}, 0.0, {}
