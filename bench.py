@@ -717,12 +717,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream, islands back to back")
-    ap.add_argument("--ms-kernel", default=None,
-                    help="MeanShift iteration kernel for the timed steps, e.g. 'sgpr+cap1024' (LDS-free, 1024 waves); "
-                         "default: the library's choice")
-    ap.add_argument("--geometry-ahead", action="store_true",
-                    help="enqueue the NEXT step's xyz-only work (FPS, ball query, three_nn) beside this step's MLPs "
-                         "(measured: 14.10 -> 13.98 ms per step; off by default, every step then stands alone)")
+    ap.add_argument("--ms-kernel", default="sgpr",
+                    help="MeanShift iteration kernel for the timed steps: 'sgpr' (default here: the LDS-free kernel built to "
+                         "run beside the MLP kernels, bit-identical results), 'sgpr+cap1024', 'packed+split', ...; "
+                         "'library' = the library's own default (the LDS kernel)")
+    ap.add_argument("--geometry-ahead", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-geometry-ahead", action="store_true",
+                    help="every step stands alone: its xyz-only work (FPS, ball query, three_nn) heads its own MLP stream. "
+                         "Default: a pipelined evaluator -- step i enqueues the geometry of step i+1's batch beside its own MLP "
+                         "kernels (round 5, with the MLP chains no longer matrix-bound: 11.26 -> 10.56 ms per step; round 4: 1 %)")
     ap.add_argument("--ops-only", action="store_true",
                     help="island (A) = bare SA/FP op chain with synthetic features (no MLP GEMMs)")
     ap.add_argument("--strong", action="store_true",
@@ -804,31 +807,34 @@ def main():
     # --serial both run back to back on one stream (per-stage event timings are taken in that
     # mode so they do not overlap).
     side = torch.cuda.Stream(device=dev)
-    if args.ms_kernel:
+    if args.ms_kernel and args.ms_kernel != "library":
         from pvn3d_amd.lib.utils import _vote_engine
         _vote_engine.DEFAULT_KERNEL = args.ms_kernel
 
     def gather_results(res):
         return gather_step_results(res, frames_local, frames_total, world, args.strong)
 
-    # --geometry-ahead: software pipelining across steps (a pipelined evaluator has the next batch's cloud while it works
-    # on this one): the xyz-only work of step i+1's batch is enqueued on the network's geometry stream BEFORE step i's
-    # MLP kernels, which then start at once on the handle that step i-1 left.  Every step still enqueues exactly one
-    # geometry pass, one MLP pass and one vote pass.  It buys 1 % (tools/step_timeline.py: inside a step the MLP stream
-    # waits 5.7 ms for level 0's FPS and then runs 5 ms alone, but the MeanShift iterations that run meanwhile are
-    # VALU-throughput-bound on the whole chip -- moving the MLPs beside them only makes both slower), so the default
-    # keeps every step self-contained.
-    geo_ahead = args.geometry_ahead and net is not None and not args.serial
+    # Software pipelining across steps (default since round 5; --no-geometry-ahead turns it off): a pipelined evaluator has
+    # the next batch's cloud while it works on this one, so the xyz-only work of step i+1's batch (FPS, ball query,
+    # three_nn: no features involved) is enqueued on the network's geometry stream BEFORE step i's MLP kernels, which then
+    # start at once on the handle that step i-1 left.  Every step still enqueues exactly one geometry pass, one MLP pass
+    # and one vote pass inside the timed region -- nothing is cached or skipped (the geometry is recomputed every step).
+    # Round 4 measured 1 % for this (the MLP kernels were matrix-bound and the MeanShift iterations VALU-bound: moving
+    # them beside each other only slowed both); with the chains at a third of their matrix-pipe time (round 5) the two
+    # islands do overlap: 11.26 -> 10.8 ms, and 10.56 ms with the LDS-free MeanShift kernel.  The self-contained step is
+    # measured right after the timed region and reported as `value_self_contained_steps`.
+    geo_ahead = not args.no_geometry_ahead and net is not None and not args.serial
     geo_next = [None]
 
-    def step(timer):
+    def step(timer, ahead=None):
+        ahead = geo_ahead if ahead is None else ahead
         if args.serial:
             keep = island_a(timer)
             res = run_postproc(inp, timer, args.poll_every)
             return keep, res, gather_results(res)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            if geo_ahead:
+            if ahead:
                 with torch.no_grad():
                     geo = geo_next[0] if geo_next[0] is not None else net.geometry_ahead(inp["pc"])
                     geo_next[0] = net.geometry_ahead(inp["pc"])
@@ -854,6 +860,22 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_alone = None
+    if geo_ahead:
+        # the same K steps with every step standing alone (its own geometry at the head of its MLP stream)
+        geo_next[0] = None
+        step(timer_off, ahead=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timer_off, ahead=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed_alone = time.perf_counter() - t1
     op_timer = StageTimer(False)
     if not args.no_stage_events:
         # per-stage kernel time: the same K steps once more, serialised on one stream so that the
@@ -877,9 +899,11 @@ def main():
         else:
             op_timer = timer
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_alone if elapsed_alone is not None else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if elapsed_alone is not None:
+            elapsed_alone = float(t[1].item())
 
     # sanity: the timed result is the real thing (pose close to the synthetic ground truth)
     pose0 = res["poses"][0].cpu().numpy()
@@ -993,6 +1017,8 @@ def main():
             leaf = {k: v for k, v in leaf.items() if k not in ("sa_mlp", "fp_mlp")}
             leaf["sa_mlp+fp_mlp"] = per_step["sa_mlp"] + per_step["fp_mlp"]
         dominant = max(leaf, key=leaf.get) if leaf else None
+        hm = {k: v for k, v in leaf.items() if rooflines.get(k, {}).get("bound") in ("hbm", "mfma")}
+        dominant_hm = max(hm, key=hm.get) if hm else None
         if net is not None and "pointnet2_msg_total" in per_step:
             # torch glue inside the forward (transposes, concat, interpolation weights)
             per_step["pointnet2_msg_other"] = per_step["pointnet2_msg_total"] - sum(
@@ -1019,16 +1045,29 @@ def main():
                        "parallelism": "frames sharded x%d; one all-gather of per-frame result rows per step%s"
                                       % (world, "" if world > 1 else " (no-op at 1 GPU)"),
                        "streams": "1 (serial)" if args.serial else "3 (Pointnet2MSG feature path || its xyz-only geometry (FPS, ball query, three_nn) || "
-                                  "vote-cluster-pose)" if net is not None else "2 (SA/FP ops || vote-cluster-pose)"},
+                                  "vote-cluster-pose)" if net is not None else "2 (SA/FP ops || vote-cluster-pose)",
+                       "pipelining": ("step i enqueues the xyz-only geometry of step i+1's batch beside its own MLP kernels "
+                                      "(one geometry + one MLP + one vote pass per step inside the timed region; "
+                                      "--no-geometry-ahead: every step alone, see value_self_contained_steps)") if geo_ahead
+                       else "none (every step stands alone)",
+                       "meanshift_kernel": args.ms_kernel},
             "op_chain_stage_ms_per_step": op_step if net is not None else None,
             "stage_ms_per_step": per_step,
             "dominant_stage": dominant,
-            "roofline": rooflines.get(dominant if dominant in rooflines else "ball_query+group"),
+            # the contract's `roofline` is an HBM or MFMA roofline: the largest stage that has one (the fused SA / FP chain
+            # family).  The vote stage -- as long as it, round 5 -- is VALU-issue bound: `roofline_valu` (and `rooflines`)
+            "roofline": rooflines.get(dominant_hm if dominant_hm in rooflines else "ball_query+group"),
+            "roofline_valu": rooflines.get("vote_cluster_pose"),
             "roofline_hbm": rooflines.get("ball_query+group"),
             "rooflines": rooflines,
             "meanshift_iters": {"min": int(iters.min()), "max": int(iters.max()), "mean": float(iters.mean())},
             "pose_err_vs_ground_truth": pose_err,
         }
+        if elapsed_alone is not None:
+            out["value_self_contained_steps"] = dict(value=total_frames / elapsed_alone, unit="frames/s",
+                                                     ms_per_step=elapsed_alone / args.steps * 1e3,
+                                                     note="every step with its own geometry at the head of its MLP stream "
+                                                          "(no cross-step pipelining)")
         # the same vote -> cluster -> pose call with the reference's stop rule run to its end (no winner stop): the
         # iteration counts the reference would run on THESE frames, and that the poses are the same bits
         from pvn3d_amd.lib.utils import _vote_engine as _ve
