@@ -264,8 +264,10 @@ def mlp_chain_table(net, scale, frames=64):
         # first conv's interpolated half runs over the known points)
         layerwise = not split and not split2 and not is_sa and _ext.fp_layerwise_shape_ok(cols * frames, c_b, dims)
         fl = 2.0 * sum(a * b for a, b in zip(dims[:-1], dims[1:])) * cols
-        if split2:
-            kind, peak = "fp16x2 split on v_mfma_f32_32x32x16_f16 (3 partial products per multiply)", PEAK_BF16_MFMA_TFLOPS / 3.0
+        if split2 or (layerwise and _fused_mlp.MLP_ARITH == "fp16x2"):
+            kind = ("fp16x2 split on v_mfma_f32_32x32x16_f16 (3 partial products per multiply)"
+                    + (", layer by layer" if layerwise else ""))
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
         elif split or layerwise:
             kind = "bf16x3 split on v_mfma_f32_32x32x16_bf16 (6 partial products)" + (", layer by layer" if layerwise else "")
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0
@@ -1031,8 +1033,9 @@ def main():
                       "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP; "
                       "fp32 operands and results throughout; the contraction runs on fp32 MFMA (SA level 0), as three exact "
                       "fp16 x fp16 partial products per multiply on fp16 MFMA with two fp16 pieces per operand (SA levels 1-3, FP "
-                      "levels 0-1; power-of-two range scaling from device-side bounds) or as six bf16 x bf16 partial products "
-                      "with three bf16 pieces (FP levels 2-3 and the pre-contractions, layer by layer); all three are as close "
+                      "levels 0-1 in one fused kernel per chain; FP levels 2-3 and the pre-contractions layer by layer; power-of-two "
+                      "range scaling from device-side bounds; PVN3D_MLP_ARITH=bf16x3 selects six bf16 x bf16 partial products "
+                      "with three bf16 pieces instead); all of them are as close "
                       "to an fp64 evaluation as the fp32 FMA chain (tests: 2e-5 of the output scale, measured 5e-7 - 1e-6)")
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",

@@ -478,6 +478,20 @@ struct S3Consumer {
     const int n_full = a.nA + a.nB;
     const bool tail = a.tail_w > 0;
     const int slabs = 2 * n_full + (tail ? 1 : 0);
+    if (wave >= ((a.M[0] + 31) >> 5)) {
+      // no row tile of layer 0: keep the ring's hand-over protocol only -- a slot's use counts as finished by this wave
+      // once the chunk is there (waiting for it keeps the wave from running ahead of the waves that do read, whose
+      // counts the loaders rely on before they refill a slot)
+      const int n_ch = n_full + (tail ? 1 : 0);
+      for (int c = 0; c < n_ch; ++c) {
+        const unsigned cn = chunk_no + c;
+        const int slot = cn & (S3_RING - 1);
+        lds_wait_ge(&ctl->rdy[slot], cn + 1);
+        lds_signal_add(&ctl->fin[slot], lane);
+      }
+      chunk_no += n_ch;
+      return;
+    }
     const WSrc<NTC> w = wsrc<NTC>(0, slabs, lane);
     init_acc<NTC>(acc, 0, 0, half);
     uint4 ringA[4][NTC][NP];
@@ -554,6 +568,7 @@ struct S3Consumer {
   template <int NTC>
   __device__ __forceinline__ void preloadA(uint4 (&R)[4][NMAX][NP], int l, int lane, int tile_base = 0) const {
     constexpr int RD = NTC >= 3 ? 2 : 4;
+    if (tile_base + wave >= ((a.M[l] + 31) >> 5)) return;        // this wave owns no row tile of the layer
     const int slabs = (a.K[l] + 15) >> 4;
     const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
 #pragma unroll
@@ -564,6 +579,9 @@ struct S3Consumer {
                                          int tile_base = 0) {
     const int half = lane >> 5, col = lane & 31;
     const int slabs = (a.K[l] + 15) >> 4;
+    // a layer narrower than 32 x S3_NWC channels leaves waves without a row tile (SA level 1: 64 channels = 2 tiles): they
+    // used to recompute the last tile and drop the result -- matrix-pipe, LDS and L2 traffic for nothing
+    if (tile_base + wave >= ((a.M[l] + 31) >> 5)) return;
     const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
     init_acc<NTC>(acc, l, boff, half, tile_base);
     BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);

@@ -142,18 +142,19 @@ def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
     """bench.mlp_chain_table asks the library's own dispatch tests (pvn3d_mlp_split2_ok / pvn3d_mlp_split_ok,
     _ext.fp_layerwise_shape_ok; host-only).  Default arithmetic ("fp16x2"): SA levels 1-3 and FP levels 0-1 of the
     backbone run the fused two-piece fp16 kernels (peak 2500 / 3 TFLOP/s of algorithmic fp32 flops), the 512-wide FP
-    levels 2-3 the layer-by-layer three-piece bf16 split GEMM when the forward has enough points (64 frames: yes, one
-    frame: no; 2500 / 6), SA level 0 the fp32-MFMA kernels (157.3).  Under "bf16x3" the round-4 table comes back."""
+    levels 2-3 the layer-by-layer split GEMM in the same two-piece arithmetic (pvn3d_split_gemm2; same price) when the
+    forward has enough points (64 frames: yes, one frame: no), SA level 0 the fp32-MFMA kernels (157.3).  Under
+    "bf16x3" the round-4 table (six products, 2500 / 6) comes back."""
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
     from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
     assert _fused_mlp.MLP_ARITH == "fp16x2"
     rows = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=64)
     h2 = {r["chain"] for r in rows if r["arithmetic"].startswith("fp16x2")}
     b3 = {r["chain"] for r in rows if r["arithmetic"].startswith("bf16x3")}
-    assert h2 == {"SA1.0", "SA1.1", "SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1"} and b3 == {"FP2", "FP3"}
+    assert h2 == {"SA1.0", "SA1.1", "SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1", "FP2", "FP3"} and b3 == set()
     assert {r["chain"] for r in rows if r["arithmetic"].endswith("layer by layer")} == {"FP2", "FP3"}
     one = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=1)
-    assert {r["chain"] for r in one if r["arithmetic"].startswith("bf16x3")} == set()
+    assert {r["chain"] for r in one if r["arithmetic"].endswith("layer by layer")} == set()
     assert len(rows) == 12
     for r in rows:
         want = 2500.0 / 3.0 if r["chain"] in h2 else (2500.0 / 6.0 if r["chain"] in b3 else 157.3)
@@ -165,5 +166,6 @@ def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
         _fused_mlp.MLP_ARITH = "fp16x2"
     assert {r["chain"] for r in old if r["arithmetic"].startswith("bf16x3")} == {"SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0",
                                                                                  "FP1", "FP2", "FP3"}
+    assert all(abs(r["peak_tflops"] - 2500.0 / 6.0) < 1e-9 for r in old if r["arithmetic"].startswith("bf16x3"))
     sa, fp = bench.mlp_flops_per_frame(Pointnet2MSG(input_channels=6), 1.0)
     assert abs(sum(r["flops_per_frame"] for r in rows) - (sa + fp)) < 1.0
