@@ -18,9 +18,14 @@ dev = torch.device("cuda:0")
 B = 64
 xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
 case = sys.argv[1] if len(sys.argv) > 1 else "sa2"
-if case == "sa2":
-    sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
-    feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
+if case in ("sa1", "sa2"):
+    if case == "sa1":
+        xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=2048, n_obj=512)["pcld"] for i in range(B)])).to(dev)
+        sa = pm.PointnetSAModule(mlp=[96, 64, 96, 128], npoint=512, radius=0.1, nsample=32).to(dev).eval()
+        feats = torch.randn(B, 2048, 96, device=dev).transpose(1, 2)
+    else:
+        sa = pm.PointnetSAModule(mlp=[256, 128, 196, 256], npoint=512, radius=0.1, nsample=32).to(dev).eval()
+        feats = torch.randn(B, 1024, 256, device=dev).transpose(1, 2)
     with torch.no_grad():
         geo = sa.sample_and_query(xyz)
         for _ in range(3):
@@ -39,7 +44,7 @@ else:
             fp(unk, kn, uf, kf, neighbours=nb)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 256)()
-f = lib._lib.pvn3d_debug_s3_prof_read if hasattr(lib, "_lib") else ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "pvn3d_amd", "libpvn3d_hip.so")).pvn3d_debug_s3_prof_read
+f = lib.pvn3d_debug_s3_prof_read          # exported by the -DPVN3D_S3_TUNING build only
 f.argtypes = [ctypes.c_void_p]
 assert f(buf) == 0
 t = np.array(buf[:], dtype=np.int64)
