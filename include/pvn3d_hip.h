@@ -255,8 +255,15 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  *                 its own.
  * pvn3d_mlp_split2_ok answers pvn3d_mlp_split_ok's question for these kernels (smaller LDS footprint; one more chain
  * shape: SA level 1).  pvn3d_absmax: *out_max = max(*out_max, max |src[r][ch]|, r < rows, ch < c) as an atomic max on
- * the bit pattern -- set *out_max to 0 (or to a previous bound) before the call. */
+ * the bit pattern -- set *out_max to 0 (or to a previous bound) before the call.
+ * Narrow set-abstraction chains (three layers of <= 128 channels, nsample 16 / 32; the shapes of the backbone's SA
+ * levels 0-1: 9 -> 16 -> 16 -> 32, 9 -> 32 -> 32 -> 64, 99 -> 64 -> 64 | 96 -> 128) run a kernel of their own behind
+ * pvn3d_sa_mlp_maxpool_split2 (weights of the whole chain resident in LDS, one wave per 32 columns through all layers);
+ * for c + 3 <= 16 it reads the feature rows element by element, so features_pm / ld_feat need no alignment there.
+ * pvn3d_set_sa_narrow(0) switches it off process-wide (A/B measurements: SA level 1 then runs the 4 + 4 wave kernel, SA
+ * level 0 is refused by pvn3d_mlp_split2_ok and stays on pvn3d_sa_mlp_maxpool); 1 = on, the default. */
 int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);
+void pvn3d_set_sa_narrow(int on);
 int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features_pm, int ld_feat, const int* idx, int n_layers,
                                 const int* dims_host, const void* const* w_split2, const float* const* bias_padded,

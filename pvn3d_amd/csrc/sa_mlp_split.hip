@@ -941,6 +941,376 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   }
 }
 
+
+// ======================================================================================================================
+// Narrow set-abstraction chains (every layer <= 128 channels: SA levels 0-1 of the backbone), fp16 x 2 arithmetic.
+//
+// The 4 + 4 wave kernel above spends a narrow chain's column block on everything but matrix work (profiles/NOTES.md,
+// round 5: SA level 1, 16.5 k cycles per 64 columns for 3.3 k of MFMAs -- weight fragments arrive from L2 with 0.6 k
+// cycles of cover against a 1 k round trip, five MFMA-wave barriers, two activation round trips through LDS).  Here
+//   * the WEIGHTS of all three layers sit in LDS for the lifetime of the (persistent) workgroup -- <= 100 KB for the
+//     shapes taken -- so an A fragment is an LDS read away;
+//   * a WAVE owns 32 columns (one centre of 32 samples, or two of 16) through the whole chain and never meets another
+//     wave: no barrier, no control words;
+//   * activations never leave registers: the D layout of v_mfma_f32_32x32x16_f16 (lane = column, registers = rows
+//     8 j + 4 half + i) IS a B fragment of the next layer once the next layer's K index is permuted inside every 16-k
+//     slab (k' = 8 (p >> 2) + 4 half + (p & 3) for fragment position p) -- a permutation applied to the weights while
+//     they are copied into LDS;
+//   * the last layer is computed TRANSPOSED (activations as the A operand, weights as B: the same register contents,
+//     swapped in the instruction): lane = output channel, registers = the tile's 32 columns, so the max over nsample
+//     is 15 v_max in registers and one cross-half exchange instead of 80 DPP steps per row tile;
+//   * the layer-0 B fragment of lane (column c, half h) is 8 consecutive channels of the gathered row, loaded straight
+//     from the point-major feature table (two 16-byte loads per 16-k slab), scaled and split in registers; the next
+//     tile's rows are requested as soon as layer 0 has consumed the current ones.
+// Arithmetic, scales, rounding and the reference semantics are those of the AR = 1 kernels above (same S3Args, same
+// host entry): results differ from them only in the summation order inside a slab.
+constexpr int NW_WAVES = 8;
+constexpr int NW_THREADS = 64 * NW_WAVES;
+
+template <bool VEC, int SF>
+struct NwRaw {
+  float4 f[VEC ? SF : 1][2];     // VEC: feature slabs (8 channels per lane and slab); else: the lane's 8 values of the only slab
+  float p[3], c[3];              // neighbour / centre coordinates (grouped_xyz -= new_xyz happens on arrival)
+};
+
+__device__ __forceinline__ void nw_split8(const float (&x)[8], float mul, uint4& bh, uint4& bl) {
+  const float y0[4] = {x[0] * mul, x[1] * mul, x[2] * mul, x[3] * mul};
+  const float y1[4] = {x[4] * mul, x[5] * mul, x[6] * mul, x[7] * mul};
+  uint2 h0, l0, h1, l1;
+  split4h(y0, h0, l0);
+  split4h(y1, h1, l1);
+  bh = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+// w.x in three partial products, smallest first; TR: the transposed product (activations as the A operand)
+template <bool TR>
+__device__ __forceinline__ void nw_mm(f32x16& acc, const uint4& wh, const uint4& wl, const uint4& xh, const uint4& xl) {
+  const f16x8 WH = __builtin_bit_cast(f16x8, wh), WL = __builtin_bit_cast(f16x8, wl);
+  const f16x8 XH = __builtin_bit_cast(f16x8, xh), XL = __builtin_bit_cast(f16x8, xl);
+  if (TR) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, WL, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XL, WH, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(XH, WH, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL, XH, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XL, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XH, acc, 0, 0, 0);
+  }
+}
+// relu(acc) * mul of one row tile -> the B fragments (two pieces) of the next layer's slabs 2 t and 2 t + 1
+__device__ __forceinline__ void nw_next_frags(const f32x16& acc, float mul, uint4 (&b0)[2], uint4 (&b1)[2]) {
+  float x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = fmaxf(acc[k], 0.f);
+  nw_split8(x, mul, b0[0], b0[1]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = fmaxf(acc[8 + k], 0.f);
+  nw_split8(x, mul, b1[0], b1[1]);
+}
+
+// A layer's weight fragments sit in LDS in the order they are used (slab-major, row tile inside: fragment i = s T + t
+// at i * 2048 bytes), so a layer is one stream of NF fragments; NW_PF of them are requested ahead of the MFMAs that
+// use them (the compiler's own schedule was load -> wait -> three MFMAs: ~100 exposed LDS round trips per tile)
+constexpr int NW_PF = 2;
+struct NwFrag { uint4 h, l; };
+__device__ __forceinline__ NwFrag nw_ld(const char* w, int i) {
+  NwFrag f;
+  f.h = *reinterpret_cast<const uint4*>(w + i * 2048);
+  f.l = *reinterpret_cast<const uint4*>(w + i * 2048 + 1024);
+  return f;
+}
+template <int NF>
+__device__ __forceinline__ void nw_prime(NwFrag (&q)[NW_PF + 1], const char* w) {
+#pragma unroll
+  for (int i = 0; i < NW_PF; ++i)
+    if (i < NF) q[i] = nw_ld(w, i);
+}
+
+// S0, S1, S2: 16-k slabs of the three layers (S1 = ceil(M0 / 16), S2 = ceil(M1 / 16)); T2: 32-row tiles of the last
+// layer; VEC: the feature table is read in 16-byte pieces (C a multiple of 16, aligned rows; S0 = C / 16 + 1, the last
+// slab holds the relative coordinates) -- otherwise C + 3 <= 16 channels, element by element (SA level 0: 6 features +
+// 3 coordinates); MINW: waves per SIMD the register budget is set for (2 = one workgroup per CU, 4 = two)
+template <int S0, int S1, int S2, int T2, bool VEC, int MINW>
+__global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Args a, int tiles_per_frame, int tiles_total) {
+  extern __shared__ __attribute__((aligned(16))) char s_mem[];
+  __shared__ float s_amax[NW_WAVES];
+  constexpr int T0 = (S1 + 1) / 2, T1 = (S2 + 1) / 2;
+  constexpr int SF = VEC ? S0 - 1 : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  constexpr int s1 = S1, s2 = S2;
+  constexpr int w1_off = S0 * T0 * 2048, w2_off = w1_off + S1 * T1 * 2048;
+  constexpr int bias_off = w2_off + S2 * T2 * 2048;
+  const S3Scales sc = s3_scales(a);
+  // ---- weights and biases -> LDS, once
+  {
+    const uint4* src = a.W[0];
+    uint4* dst = reinterpret_cast<uint4*>(s_mem);
+    for (int i = tid; i < S0 * T0 * 128; i += NW_THREADS) dst[i] = src[i];
+  }
+#pragma unroll
+  for (int l = 1; l < 3; ++l) {
+    // K permuted inside every slab: fragment position p of half h holds k = 8 (p >> 2) + 4 h + (p & 3), i.e. the low
+    // 8 bytes of lane (m, h) come from bytes [8 h, 8 h + 8) of the packed lane (m, 0), the high 8 bytes from lane (m, 1)
+    const char* src = reinterpret_cast<const char*>(a.W[l]);
+    char* dst = s_mem + (l == 1 ? w1_off : w2_off);
+    const int units = (l == 1 ? s1 * T1 : s2 * T2) * 256;
+    for (int u = tid; u < units; u += NW_THREADS) {
+      const int f = u >> 8, pc = (u >> 7) & 1, ln = (u >> 1) & 63, q = u & 1;
+      const int m = ln & 31, h = ln >> 5;
+      *reinterpret_cast<uint2*>(dst + f * 2048 + pc * 1024 + ln * 16 + 8 * q) =
+          *reinterpret_cast<const uint2*>(src + f * 2048 + pc * 1024 + (m + 32 * q) * 16 + 8 * h);
+    }
+  }
+  float* s_bias = reinterpret_cast<float*>(s_mem + bias_off);
+  {
+    int off = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const int mp = (l == 0 ? T0 : l == 1 ? T1 : T2) * 32;
+      const float bm = sc.bias_mul[l];
+      for (int i = tid; i < mp; i += NW_THREADS) s_bias[off + i] = a.bias[l][i] * bm;
+      off += mp;
+    }
+  }
+  __syncthreads();
+  const char* w0 = s_mem + lane * 16;
+  const char* w1 = s_mem + w1_off + lane * 16;
+  const char* w2 = s_mem + w2_off + lane * 16;
+  const float* sb0 = s_bias;
+  const float* sb1 = s_bias + T0 * 32;
+  const float* sb2 = s_bias + (T0 + T1) * 32;
+  const int C = a.K[0] - 3;
+  const int ns = a.ns;
+  const float s0 = sc.s_in[0];
+  const float om = sc.next_mul[2];
+  float amax = 0.f;
+
+  // this lane's column of tile t: neighbour index, then the row segments of the gather
+  auto tile_id = [&](int t, int& bi, int& gc) -> int {
+    bi = t / tiles_per_frame;
+    gc = min((t - bi * tiles_per_frame) * 32 + col, a.cols_total - 1);
+    return a.idx[(size_t)bi * a.cols_total + gc];
+  };
+  auto gather = [&](NwRaw<VEC, SF>& r, int bi, int gc, int id) {
+    const float* row = a.tabA + ((size_t)bi * a.rowsA + id) * a.ldA;
+    if (VEC) {
+#pragma unroll
+      for (int s = 0; s < SF; ++s) {
+        r.f[s][0] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * half);
+        r.f[s][1] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * half + 4);
+      }
+    } else {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = 8 * half + k;
+        v[k] = kk < C ? row[kk] : 0.f;
+      }
+      r.f[0][0] = make_float4(v[0], v[1], v[2], v[3]);
+      r.f[0][1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    const float* p = a.xyz + ((size_t)bi * a.n + id) * 3;
+    const float* c = a.new_xyz + ((size_t)bi * a.m + gc / ns) * 3;
+    r.p[0] = p[0]; r.p[1] = p[1]; r.p[2] = p[2];
+    r.c[0] = c[0]; r.c[1] = c[1]; r.c[2] = c[2];
+  };
+
+  const int gw = blockIdx.x * NW_WAVES + wave, nw = gridDim.x * NW_WAVES;
+  NwRaw<VEC, SF> raw;
+  int tile = gw;
+  if (tile < tiles_total) {
+    int bi, gc;
+    const int id = tile_id(tile, bi, gc);
+    gather(raw, bi, gc, id);
+  }
+  for (; tile < tiles_total; tile += nw) {
+    const int tn = tile + nw;
+    int bi_n = 0, gc_n = 0, id_n = 0;
+    if (tn < tiles_total) id_n = tile_id(tn, bi_n, gc_n);           // (arrives under layer 0)
+    const int bi = tile / tiles_per_frame;
+    const int tcol = (tile - bi * tiles_per_frame) * 32;
+
+    // ---- layer 0: B fragments from the gathered rows
+    f32x16 acc0[T0];
+    NwFrag q[NW_PF + 1];
+    nw_prime<S0 * T0>(q, w0);
+#pragma unroll
+    for (int t = 0; t < T0; ++t) acc_bias(acc0[t], sb0 + 32 * t, half);
+    const float rel[3] = {raw.p[0] - raw.c[0], raw.p[1] - raw.c[1], raw.p[2] - raw.c[2]};      // grouped_xyz -= new_xyz
+#pragma unroll
+    for (int s = 0; s < S0; ++s) {
+      float x[8];
+      if (VEC && s < SF) {
+        x[0] = raw.f[s][0].x; x[1] = raw.f[s][0].y; x[2] = raw.f[s][0].z; x[3] = raw.f[s][0].w;
+        x[4] = raw.f[s][1].x; x[5] = raw.f[s][1].y; x[6] = raw.f[s][1].z; x[7] = raw.f[s][1].w;
+      } else if (VEC) {
+        // the coordinate slab: k = C + 0..2 in the low half's first positions
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = 0.f;
+        if (half == 0) { x[0] = rel[0]; x[1] = rel[1]; x[2] = rel[2]; }
+      } else {
+        x[0] = raw.f[0][0].x; x[1] = raw.f[0][0].y; x[2] = raw.f[0][0].z; x[3] = raw.f[0][0].w;
+        x[4] = raw.f[0][1].x; x[5] = raw.f[0][1].y; x[6] = raw.f[0][1].z; x[7] = raw.f[0][1].w;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int d = 8 * half + k - C;
+          if (d >= 0 && d < 3) x[k] = d == 0 ? rel[0] : d == 1 ? rel[1] : rel[2];
+        }
+      }
+      uint4 bh, bl;
+      nw_split8(x, s0, bh, bl);
+#pragma unroll
+      for (int t = 0; t < T0; ++t) {
+        constexpr int NF = S0 * T0;
+        const int i = s * T0 + t;
+        if (i + NW_PF < NF) q[(i + NW_PF) % (NW_PF + 1)] = nw_ld(w0, i + NW_PF);
+        nw_mm<false>(acc0[t], q[i % (NW_PF + 1)].h, q[i % (NW_PF + 1)].l, bh, bl);
+        __builtin_amdgcn_sched_barrier(0);      // keeps the request NW_PF fragments ahead (the scheduler sinks it otherwise)
+      }
+    }
+    // the next tile's rows: the registers are free now, the loads land under layers 1-2
+    __builtin_amdgcn_sched_barrier(0);
+    if (tn < tiles_total) gather(raw, bi_n, gc_n, id_n);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- layer 1 (its first fragments travel under the activation split)
+    nw_prime<S1 * T1>(q, w1);
+    uint4 b1[2 * T0][2];
+#pragma unroll
+    for (int t = 0; t < T0; ++t) nw_next_frags(acc0[t], sc.next_mul[0], b1[2 * t], b1[2 * t + 1]);
+    f32x16 acc1[T1];
+#pragma unroll
+    for (int t = 0; t < T1; ++t) acc_bias(acc1[t], sb1 + 32 * t, half);
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+#pragma unroll
+      for (int t = 0; t < T1; ++t) {
+        constexpr int NF = S1 * T1;
+        const int i = s * T1 + t;
+        if (i + NW_PF < NF) q[(i + NW_PF) % (NW_PF + 1)] = nw_ld(w1, i + NW_PF);
+        nw_mm<false>(acc1[t], q[i % (NW_PF + 1)].h, q[i % (NW_PF + 1)].l, b1[s][0], b1[s][1]);
+        __builtin_amdgcn_sched_barrier(0);      // keeps the request NW_PF fragments ahead (the scheduler sinks it otherwise)
+      }
+    }
+    // ---- layer 2, transposed: lane = output channel 32 t + col, registers = columns 8 j + 4 half + i of the tile
+    nw_prime<S2 * T2>(q, w2);
+    uint4 b2[2 * T1][2];
+#pragma unroll
+    for (int t = 0; t < T1; ++t) nw_next_frags(acc1[t], sc.next_mul[1], b2[2 * t], b2[2 * t + 1]);
+    f32x16 acc2[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+      const float b = sb2[32 * t + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = b;
+    }
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+#pragma unroll
+      for (int t = 0; t < T2; ++t) {
+        constexpr int NF = S2 * T2;
+        const int i = s * T2 + t;
+        if (i + NW_PF < NF) q[(i + NW_PF) % (NW_PF + 1)] = nw_ld(w2, i + NW_PF);
+        nw_mm<true>(acc2[t], q[i % (NW_PF + 1)].h, q[i % (NW_PF + 1)].l, b2[s][0], b2[s][1]);
+        __builtin_amdgcn_sched_barrier(0);      // keeps the request NW_PF fragments ahead (the scheduler sinks it otherwise)
+      }
+    }
+    // ---- relu, max over the centre's columns, store
+    const int M = a.M[2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) {
+      float lo = fmaxf(fmaxf(acc2[t][0], acc2[t][1]), fmaxf(acc2[t][2], acc2[t][3]));       // columns 0..15 (j = 0, 1)
+      lo = fmaxf(lo, fmaxf(fmaxf(acc2[t][4], acc2[t][5]), fmaxf(acc2[t][6], acc2[t][7])));
+      float hi = fmaxf(fmaxf(acc2[t][8], acc2[t][9]), fmaxf(acc2[t][10], acc2[t][11]));     // columns 16..31 (j = 2, 3)
+      hi = fmaxf(hi, fmaxf(fmaxf(acc2[t][12], acc2[t][13]), fmaxf(acc2[t][14], acc2[t][15])));
+      lo = fmaxf(lo, 0.f);
+      hi = fmaxf(hi, 0.f);
+      const int row = 32 * t + col;
+      if (ns == 32) {
+        float v = fmaxf(lo, hi);
+        v = fmaxf(v, __shfl_xor(v, 32, 64)) * om;
+        const int centre = tcol >> 5;
+        if (half == 0 && row < M && centre < a.m) {
+          a.out[((size_t)bi * a.m + centre) * a.ld_out + a.coff + row] = v;
+          amax = fmaxf(amax, v);
+        }
+      } else {
+        lo = fmaxf(lo, __shfl_xor(lo, 32, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+        const int centre = (tcol >> 4) + half;
+        const float v = (half ? hi : lo) * om;
+        if (row < M && centre < a.m) {
+          a.out[((size_t)bi * a.m + centre) * a.ld_out + a.coff + row] = v;
+          amax = fmaxf(amax, v);
+        }
+      }
+    }
+  }
+  if (a.out_absmax) {            // one conditional atomic per workgroup
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW_WAVES; ++w) m = fmaxf(m, s_amax[w]);
+      if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.out_absmax, __float_as_uint(m));
+    }
+  }
+}
+
+// process-wide A/B switch of the narrow-chain kernel (pvn3d_set_sa_narrow; tools/s3_time.py)
+int g_nw_enabled = 1;
+
+// 1..4: instance that takes the chain; -1: none.  c = feature channels (dims[0] = c + 3)
+int nw_signature(int c, int nsample, int n_layers, const int* dims) {
+  if (!g_nw_enabled || n_layers != 3 || (nsample != 16 && nsample != 32) || c < 0 || dims[0] != c + 3) return -1;
+  for (int l = 1; l <= 3; ++l)
+    if (dims[l] <= 0 || dims[l] > 128) return -1;
+  const int s1 = (dims[1] + 15) / 16, s2 = (dims[2] + 15) / 16, t2 = (dims[3] + 31) / 32;
+  const bool small_k = c + 3 <= 16;                 // one slab, element-wise gather
+  const bool vec_k = c == 96;                       // S0 = 7 (the instantiated slab count)
+  if (small_k && s1 == 1 && s2 == 1 && t2 == 1) return 1;       // 9 -> 16 -> 16 -> 32
+  if (small_k && s1 == 2 && s2 == 2 && t2 == 2) return 2;       // 9 -> 32 -> 32 -> 64
+  if (vec_k && s1 == 4 && s2 == 4 && t2 == 4) return 3;         // 99 -> 64 -> 64 -> 128
+  if (vec_k && s1 == 4 && s2 == 6 && t2 == 4) return 4;         // 99 -> 64 -> 96 -> 128
+  return -1;
+}
+
+int nw_launch(S3Args& a, int sig, hipStream_t st) {
+  const int t[3] = {(a.M[0] + 31) / 32, (a.M[1] + 31) / 32, (a.M[2] + 31) / 32};
+  const int s0 = (a.K[0] + 15) / 16, s1 = (a.M[0] + 15) / 16, s2 = (a.M[1] + 15) / 16;
+  const size_t lds = (size_t)(s0 * t[0] + s1 * t[1] + s2 * t[2]) * 2048 + (size_t)(t[0] + t[1] + t[2]) * 32 * 4;
+  if (lds > 150 * 1024) return -1;
+  const int tpf = pvn3d_ceil_div(a.cols_total, 32);
+  const long long total = (long long)tpf * a.n_frames;
+  if (total > 0x7fffffff) return -1;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+#define NW_GO(S0, S1, S2, T2, VEC, MINW)                                                                               \
+  do {                                                                                                                 \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(sa_chain_narrow_kernel<S0, S1, S2, T2, VEC, MINW>));           \
+    const int grid = (int)min((long long)cus * (MINW / 2), (total + NW_WAVES - 1) / NW_WAVES);                         \
+    hipLaunchKernelGGL((sa_chain_narrow_kernel<S0, S1, S2, T2, VEC, MINW>), dim3(grid), dim3(NW_THREADS), lds, st, a,  \
+                       tpf, (int)total);                                                                               \
+  } while (0)
+  if (sig == 1) NW_GO(1, 1, 1, 1, false, 4);
+  else if (sig == 2) NW_GO(1, 2, 2, 2, false, 4);
+  else if (sig == 3) NW_GO(7, 4, 4, 4, true, 2);
+  else if (sig == 4) NW_GO(7, 4, 6, 4, true, 2);
+  else return -1;
+#undef NW_GO
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
 bool vec_ok(const float* p, int ld) { return p != nullptr && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Chain signature = row tiles per MFMA wave in each layer (x rounds of the last layer); the instantiated ones are the
@@ -1061,6 +1431,7 @@ extern "C" int pvn3d_debug_s3_prof_read(unsigned long long* host256) {
 // c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.
 static int s3_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int arith) {
   if (!dims_host || n_layers < 2 || n_layers > 3) return 0;
+  if (is_sa && arith == 1 && nw_signature(c_a, nsample, n_layers, dims_host) >= 0) return 1;      // narrow-chain kernel
   if (c_a <= 0 || (c_a % S3_KC) != 0) return 0;                       // whole 32-channel row-gather chunks
   if (is_sa) {
     if (nsample <= 0 || (nsample & (nsample - 1)) || nsample > 64) return 0;
@@ -1103,8 +1474,11 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   if (b <= 0 || m <= 0) return 0;
   if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
     return (int)hipErrorInvalidValue;
-  if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith) || dims_host[0] != c + 3 || !vec_ok(features_pm, ld_feat) ||
-      ld_feat < c || out_coff < 0 || ld_out < out_coff + dims_host[n_layers])
+  // narrow chains (fp16 x 2): a kernel of their own; the element-wise instances (c + 3 <= 16) take any row stride
+  const int nsig = arith == 1 ? nw_signature(c, nsample, n_layers, dims_host) : -1;
+  const bool narrow = nsig >= 0 && (nsig <= 2 || vec_ok(features_pm, ld_feat));
+  if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith) || dims_host[0] != c + 3 ||
+      (!narrow && !vec_ok(features_pm, ld_feat)) || ld_feat < c || out_coff < 0 || ld_out < out_coff + dims_host[n_layers])
     return (int)hipErrorInvalidValue;
   S3Args a = {};
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
@@ -1118,9 +1492,18 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   a.cols_total = m * nsample;
   a.n_frames = b;
   a.out = out_pm; a.point_major = 1; a.ld_out = ld_out; a.coff = out_coff;
-  const int rc = s3_launch(a, s3_signature(1, n_layers, dims_host, nsample, arith), (hipStream_t)stream, arith);
+  if (narrow) {
+    const int rc = nw_launch(a, nsig, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
+  const int sig = s3_signature(1, n_layers, dims_host, nsample, arith);
+  if (sig < 0 || (c % S3_KC) != 0 || !vec_ok(features_pm, ld_feat)) return (int)hipErrorInvalidValue;
+  const int rc = s3_launch(a, sig, (hipStream_t)stream, arith);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
+// A/B switch of the narrow-chain kernel (1 = on, the default): with 0 the shapes it takes fall back to the 4 + 4 wave
+// kernels (SA level 1) or are refused by pvn3d_mlp_split2_ok (SA level 0: fp32-MFMA kernels of sa_mlp.hip)
+extern "C" void pvn3d_set_sa_narrow(int on) { g_nw_enabled = on ? 1 : 0; }
 extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz,
                                           const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
                                           int n_layers, const int* dims_host, const void* const* w_split,

@@ -335,10 +335,11 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
     print("B = %d C-ABI calls:" % B, dict((k, v) for k, v in sorted(c.items()) if "mlp" in k or "split" in k),
           "small-batch:", dict(spy_sb.calls))
     if B == 64:
-        # SA0: two fp32-MFMA chains; SA1: two fp16 x 2 chains; SA2-3 pre-contracted (one split GEMM per level) + two
-        # fp16 x 2 chains each; FP0 pre-contracted (one split GEMM) + fp16 x 2 chain, FP1 fp16 x 2 chain; FP2-3 layer by
-        # layer (three split GEMMs and two row splits each); nothing on the small-batch route, nothing on bf16 x 3 chains
-        assert c["pvn3d_sa_mlp_maxpool"] == 2 and c["pvn3d_sa_mlp_maxpool_split2"] == 6 and c["pvn3d_sa_mlp_maxpool_split"] == 0
+        # SA0-1: two fp16 x 2 chains each (the narrow-chain kernel behind the split2 entry point); SA2-3 pre-contracted
+        # (one split GEMM per level) + two fp16 x 2 chains each; FP0 pre-contracted (one split GEMM) + fp16 x 2 chain,
+        # FP1 fp16 x 2 chain; FP2-3 layer by layer (three split GEMMs and two row splits each); nothing on the
+        # small-batch route, nothing on bf16 x 3 chains, nothing left on the fp32-MFMA kernels
+        assert c["pvn3d_sa_mlp_maxpool"] == 0 and c["pvn3d_sa_mlp_maxpool_split2"] == 8 and c["pvn3d_sa_mlp_maxpool_split"] == 0
         assert c["pvn3d_fp_interp_mlp_split2"] == 2 and c["pvn3d_fp_interp_mlp"] == 0 and c["pvn3d_fp_interp_mlp_split"] == 0
         # (row splits: SA1's and SA2's outputs are split ONCE although the next SA level's pre-contraction and an FP
         # level's skip half both contract over them: 7 tables minus 2 shared)

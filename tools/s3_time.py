@@ -31,6 +31,17 @@ def main():
     torch.manual_seed(0)
     xyz = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=1024, n_obj=256)["pcld"] for i in range(B)])).to(dev)
     cases = []
+    # SA level 0: 12288 -> 2048 centres, 6 features read in place from the (B, N, 9) cloud, ns 16 / 32 (narrow-chain kernel)
+    pc0 = torch.from_numpy(np.stack([np.concatenate([f["pcld"], f["feats"].T], 1).astype(np.float32) for f in
+                                     (synth.synth_frame(frame=i, n_pts=12288, n_obj=3072) for i in range(B))])).to(dev)
+    xyz0 = pc0[..., :3].contiguous()
+    for ns, radius, mlp in ((16, 0.0175, [6, 16, 16, 32]), (32, 0.025, [6, 32, 32, 64])):
+        sa = pm.PointnetSAModule(mlp=list(mlp), npoint=2048, radius=radius, nsample=ns).to(dev).eval()
+        feats = pc0[..., 3:].transpose(1, 2)
+        with torch.no_grad():
+            geo = sa.sample_and_query(xyz0)
+        cases.append(("SA0 ns%d" % ns, lambda sa=sa, feats=feats, geo=geo: sa(xyz0, feats, geometry=geo),
+                      2.0 * (9 * mlp[1] + mlp[1] * mlp[2] + mlp[2] * mlp[3]) * 2048 * ns * B))
     # SA level 1: 2048 -> 1024 centres, C = 96, ns 16 / 32 (fp16 x 2 only: chain signature 111)
     xyz1 = torch.from_numpy(np.stack([synth.synth_frame(frame=i, n_pts=2048, n_obj=256)["pcld"] for i in range(B)])).to(dev)
     for ns, radius, mlp in ((16, 0.025, [96, 64, 64, 128]), (32, 0.05, [96, 64, 96, 128])):
@@ -87,12 +98,19 @@ def main():
                 res[arith] = ms_of(fn)
                 o = fn()
                 outs[arith] = (o[1] if isinstance(o, tuple) else o).clone()
+        extra = ""
+        if name.startswith(("SA0", "SA1")):
+            from pvn3d_amd._lib import lib
+            lib.pvn3d_set_sa_narrow(0)
+            with torch.no_grad():
+                extra = "   [narrow-chain kernel off: %7.3f ms]" % ms_of(fn)
+            lib.pvn3d_set_sa_narrow(1)
         sc = max(1.0, float(outs["fp32"].abs().max()))
         print("%-9s fp32 mfma %7.3f ms (%6.1f TF/s)   bf16x3 %7.3f ms (%6.1f)   fp16x2 %7.3f ms (%6.1f TF/s fp32-equivalent)   "
               "max|diff|/scale vs fp32 chain: bf16x3 %.1e fp16x2 %.1e   dbg=%s" % (
                   name, res["fp32"], flops / res["fp32"] / 1e9, res["bf16x3"], flops / res["bf16x3"] / 1e9,
                   res["fp16x2"], flops / res["fp16x2"] / 1e9, float((outs["bf16x3"] - outs["fp32"]).abs().max()) / sc,
-                  float((outs["fp16x2"] - outs["fp32"]).abs().max()) / sc, os.environ.get("PVN3D_S3_DBG", "0")))
+                  float((outs["fp16x2"] - outs["fp32"]).abs().max()) / sc, os.environ.get("PVN3D_S3_DBG", "0")) + extra)
     _fused_mlp.MLP_ARITH = "fp16x2"
 
 
