@@ -997,14 +997,17 @@ __device__ __forceinline__ void nw_mm(f32x16& acc, const uint4& wh, const uint4&
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XH, acc, 0, 0, 0);
   }
 }
+// relu on the bit pattern: one v_max_i32 (a float is negative iff its pattern is a negative integer; fmaxf costs a
+// second, canonicalising v_max per value because the compiler cannot know that an MFMA result is no signalling NaN)
+__device__ __forceinline__ float nw_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // relu(acc) * mul of one row tile -> the B fragments (two pieces) of the next layer's slabs 2 t and 2 t + 1
 __device__ __forceinline__ void nw_next_frags(const f32x16& acc, float mul, uint4 (&b0)[2], uint4 (&b1)[2]) {
   float x[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) x[k] = fmaxf(acc[k], 0.f);
+  for (int k = 0; k < 8; ++k) x[k] = nw_relu(acc[k]);
   nw_split8(x, mul, b0[0], b0[1]);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) x[k] = fmaxf(acc[8 + k], 0.f);
+  for (int k = 0; k < 8; ++k) x[k] = nw_relu(acc[8 + k]);
   nw_split8(x, mul, b1[0], b1[1]);
 }
 
@@ -1199,13 +1202,13 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
     uint4 b2[2 * T1][2];
 #pragma unroll
     for (int t = 0; t < T1; ++t) nw_next_frags(acc1[t], sc.next_mul[1], b2[2 * t], b2[2 * t + 1]);
+    // (accumulators start at zero -- free, an inline constant of the first MFMA -- and the bias, one value per lane
+    // here, is added to the results: broadcasting it into 16 registers per tile cost 64 moves)
     f32x16 acc2[T2];
 #pragma unroll
-    for (int t = 0; t < T2; ++t) {
-      const float b = sb2[32 * t + col];
+    for (int t = 0; t < T2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[t][r] = b;
-    }
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 #pragma unroll
     for (int s = 0; s < S2; ++s) {
 #pragma unroll
@@ -1221,24 +1224,28 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
     const int M = a.M[2];
 #pragma unroll
     for (int t = 0; t < T2; ++t) {
-      float lo = fmaxf(fmaxf(acc2[t][0], acc2[t][1]), fmaxf(acc2[t][2], acc2[t][3]));       // columns 0..15 (j = 0, 1)
-      lo = fmaxf(lo, fmaxf(fmaxf(acc2[t][4], acc2[t][5]), fmaxf(acc2[t][6], acc2[t][7])));
-      float hi = fmaxf(fmaxf(acc2[t][8], acc2[t][9]), fmaxf(acc2[t][10], acc2[t][11]));     // columns 16..31 (j = 2, 3)
-      hi = fmaxf(hi, fmaxf(fmaxf(acc2[t][12], acc2[t][13]), fmaxf(acc2[t][14], acc2[t][15])));
-      lo = fmaxf(lo, 0.f);
-      hi = fmaxf(hi, 0.f);
+      // max_c relu(y_c + b) on the bit patterns: signed-integer max orders the non-negative floats correctly and ranks
+      // every negative one below them, and the 0 in the chain is the relu (v_max3_i32: 8 per half tile pair)
+      const float b = sb2[32 * t + col];
+      int k[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) k[r] = __float_as_int(acc2[t][r] + b);
+      int ilo = max(max(max(k[0], k[1]), max(k[2], k[3])), max(max(k[4], k[5]), max(k[6], k[7])));       // columns 0..15 (j = 0, 1)
+      int ihi = max(max(max(k[8], k[9]), max(k[10], k[11])), max(max(k[12], k[13]), max(k[14], k[15])));  // columns 16..31
+      float lo = __int_as_float(max(ilo, 0));
+      float hi = __int_as_float(max(ihi, 0));
       const int row = 32 * t + col;
       if (ns == 32) {
-        float v = fmaxf(lo, hi);
-        v = fmaxf(v, __shfl_xor(v, 32, 64)) * om;
+        float v = __int_as_float(max(__float_as_int(lo), __float_as_int(hi)));
+        v = __int_as_float(max(__float_as_int(v), __float_as_int(__shfl_xor(v, 32, 64)))) * om;
         const int centre = tcol >> 5;
         if (half == 0 && row < M && centre < a.m) {
           a.out[((size_t)bi * a.m + centre) * a.ld_out + a.coff + row] = v;
           amax = fmaxf(amax, v);
         }
       } else {
-        lo = fmaxf(lo, __shfl_xor(lo, 32, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+        lo = __int_as_float(max(__float_as_int(lo), __float_as_int(__shfl_xor(lo, 32, 64))));
+        hi = __int_as_float(max(__float_as_int(hi), __float_as_int(__shfl_xor(hi, 32, 64))));
         const int centre = (tcol >> 4) + half;
         const float v = (half ? hi : lo) * om;
         if (row < M && centre < a.m) {
