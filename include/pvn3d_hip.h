@@ -259,7 +259,7 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  * Narrow set-abstraction chains (three layers of <= 128 channels, nsample 16 / 32; the shapes of the backbone's SA
  * levels 0-1: 9 -> 16 -> 16 -> 32, 9 -> 32 -> 32 -> 64, 99 -> 64 -> 64 | 96 -> 128) run a kernel of their own behind
  * pvn3d_sa_mlp_maxpool_split2 (weights of the whole chain resident in LDS, one wave per 32 columns through all layers);
- * for c + 3 <= 16 it reads the feature rows element by element, so features_pm / ld_feat need no alignment there.
+ * for c == 6 it reads the six-float feature rows in place, so features_pm / ld_feat need no 16-byte alignment there.
  * pvn3d_set_sa_narrow(0) switches it off process-wide (A/B measurements: SA level 1 then runs the 4 + 4 wave kernel, SA
  * level 0 is refused by pvn3d_mlp_split2_ok and stays on pvn3d_sa_mlp_maxpool); 1 = on, the default. */
 int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);

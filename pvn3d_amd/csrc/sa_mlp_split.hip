@@ -196,6 +196,9 @@ __device__ __forceinline__ S3Scales s3_scales(const S3Args& a) {
     sc.next_mul[l] = l + 1 < a.n_layers ? sc.s_in[l + 1] / sc.bias_mul[l] : 1.f / sc.bias_mul[l];
   return sc;
 }
+// relu on the bit pattern: one v_max_i32 (a float is negative iff its pattern is a negative integer; fmaxf(x, 0) costs a
+// second, canonicalising v_max per value because the compiler cannot know that an MFMA result is no signalling NaN)
+__device__ __forceinline__ float s3_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // two fp16 pieces of four (already scaled) fp32 values, both rounded to nearest (v_cvt_pk_f16_f32): h = fp16(x),
 // l = fp16(x - h) -- the residual x - h is exact in fp32, |x - h - l| <= 2^-22 |x|, and the rounding is symmetric (a
 // truncating split, one instruction cheaper per pair, biases every post-ReLU activation downwards: the sums over
@@ -967,6 +970,11 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
 constexpr int NW_WAVES = 8;
 constexpr int NW_THREADS = 64 * NW_WAVES;
 
+// 4-byte aligned groups of floats read with ONE load instruction (global memory takes unaligned wide accesses; a
+// divergent gather costs the texture path one pass per instruction and lane, whatever the width)
+struct __attribute__((packed, aligned(4))) NwF3 { float v[3]; };
+struct __attribute__((packed, aligned(4))) NwF6 { float v[6]; };
+
 template <bool VEC, int SF>
 struct NwRaw {
   float4 f[VEC ? SF : 1][2];     // VEC: feature slabs (8 channels per lane and slab); else: the lane's 8 values of the only slab
@@ -997,17 +1005,14 @@ __device__ __forceinline__ void nw_mm(f32x16& acc, const uint4& wh, const uint4&
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, XH, acc, 0, 0, 0);
   }
 }
-// relu on the bit pattern: one v_max_i32 (a float is negative iff its pattern is a negative integer; fmaxf costs a
-// second, canonicalising v_max per value because the compiler cannot know that an MFMA result is no signalling NaN)
-__device__ __forceinline__ float nw_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // relu(acc) * mul of one row tile -> the B fragments (two pieces) of the next layer's slabs 2 t and 2 t + 1
 __device__ __forceinline__ void nw_next_frags(const f32x16& acc, float mul, uint4 (&b0)[2], uint4 (&b1)[2]) {
   float x[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) x[k] = nw_relu(acc[k]);
+  for (int k = 0; k < 8; ++k) x[k] = s3_relu(acc[k]);
   nw_split8(x, mul, b0[0], b0[1]);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) x[k] = nw_relu(acc[8 + k]);
+  for (int k = 0; k < 8; ++k) x[k] = s3_relu(acc[8 + k]);
   nw_split8(x, mul, b1[0], b1[1]);
 }
 
@@ -1091,9 +1096,9 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   float amax = 0.f;
 
   // this lane's column of tile t: neighbour index, then the row segments of the gather
-  auto tile_id = [&](int t, int& bi, int& gc) -> int {
-    bi = t / tiles_per_frame;
-    gc = min((t - bi * tiles_per_frame) * 32 + col, a.cols_total - 1);
+  // (frame bi, tile tin inside the frame)
+  auto tile_id = [&](int bi, int tin, int& gc) -> int {
+    gc = min(tin * 32 + col, a.cols_total - 1);
     return a.idx[(size_t)bi * a.cols_total + gc];
   };
   auto gather = [&](NwRaw<VEC, SF>& r, int bi, int gc, int id) {
@@ -1105,35 +1110,34 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
         r.f[s][1] = *reinterpret_cast<const float4*>(row + 16 * s + 8 * half + 4);
       }
     } else {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int kk = 8 * half + k;
-        v[k] = kk < C ? row[kk] : 0.f;
-      }
-      r.f[0][0] = make_float4(v[0], v[1], v[2], v[3]);
-      r.f[0][1] = make_float4(v[4], v[5], v[6], v[7]);
+      // the backbone's first level: six features per point (C = 6, the only element-wise shape instantiated); both
+      // halves of the wave request the row, the upper half only uses fragment positions >= 8
+      const NwF6 f = *reinterpret_cast<const NwF6*>(row);
+      r.f[0][0] = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
+      r.f[0][1] = make_float4(f.v[4], f.v[5], 0.f, 0.f);
     }
-    const float* p = a.xyz + ((size_t)bi * a.n + id) * 3;
-    const float* c = a.new_xyz + ((size_t)bi * a.m + gc / ns) * 3;
-    r.p[0] = p[0]; r.p[1] = p[1]; r.p[2] = p[2];
-    r.c[0] = c[0]; r.c[1] = c[1]; r.c[2] = c[2];
+    const NwF3 p = *reinterpret_cast<const NwF3*>(a.xyz + ((size_t)bi * a.n + id) * 3);
+    const NwF3 c = *reinterpret_cast<const NwF3*>(a.new_xyz + ((size_t)bi * a.m + gc / ns) * 3);
+    r.p[0] = p.v[0]; r.p[1] = p.v[1]; r.p[2] = p.v[2];
+    r.c[0] = c.v[0]; r.c[1] = c.v[1]; r.c[2] = c.v[2];
   };
 
   const int gw = blockIdx.x * NW_WAVES + wave, nw = gridDim.x * NW_WAVES;
   NwRaw<VEC, SF> raw;
   int tile = gw;
+  int bi = tile / tiles_per_frame, tin = tile - bi * tiles_per_frame;        // the only division: the walk below steps
   if (tile < tiles_total) {
-    int bi, gc;
-    const int id = tile_id(tile, bi, gc);
+    int gc;
+    const int id = tile_id(bi, tin, gc);
     gather(raw, bi, gc, id);
   }
   for (; tile < tiles_total; tile += nw) {
     const int tn = tile + nw;
-    int bi_n = 0, gc_n = 0, id_n = 0;
-    if (tn < tiles_total) id_n = tile_id(tn, bi_n, gc_n);           // (arrives under layer 0)
-    const int bi = tile / tiles_per_frame;
-    const int tcol = (tile - bi * tiles_per_frame) * 32;
+    int bi_n = bi, tin_n = tin + nw;
+    while (tin_n >= tiles_per_frame) { tin_n -= tiles_per_frame; ++bi_n; }
+    int gc_n = 0, id_n = 0;
+    if (tn < tiles_total) id_n = tile_id(bi_n, tin_n, gc_n);           // (arrives under layer 0)
+    const int tcol = tin * 32;
 
     // ---- layer 0: B fragments from the gathered rows
     f32x16 acc0[T0];
@@ -1154,13 +1158,11 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
         for (int k = 0; k < 8; ++k) x[k] = 0.f;
         if (half == 0) { x[0] = rel[0]; x[1] = rel[1]; x[2] = rel[2]; }
       } else {
-        x[0] = raw.f[0][0].x; x[1] = raw.f[0][0].y; x[2] = raw.f[0][0].z; x[3] = raw.f[0][0].w;
-        x[4] = raw.f[0][1].x; x[5] = raw.f[0][1].y; x[6] = raw.f[0][1].z; x[7] = raw.f[0][1].w;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int d = 8 * half + k - C;
-          if (d >= 0 && d < 3) x[k] = d == 0 ? rel[0] : d == 1 ? rel[1] : rel[2];
-        }
+        // k = 0..5 features, 6..8 relative coordinates: positions 0..7 in the low half, position 8 opens the high half
+        x[0] = half ? rel[2] : raw.f[0][0].x;
+        x[1] = half ? 0.f : raw.f[0][0].y; x[2] = half ? 0.f : raw.f[0][0].z; x[3] = half ? 0.f : raw.f[0][0].w;
+        x[4] = half ? 0.f : raw.f[0][1].x; x[5] = half ? 0.f : raw.f[0][1].y;
+        x[6] = half ? 0.f : rel[0]; x[7] = half ? 0.f : rel[1];
       }
       uint4 bh, bl;
       nw_split8(x, s0, bh, bl);
@@ -1254,6 +1256,8 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
         }
       }
     }
+    bi = bi_n;
+    tin = tin_n;
   }
   if (a.out_absmax) {            // one conditional atomic per workgroup
 #pragma unroll
@@ -1279,7 +1283,7 @@ int nw_signature(int c, int nsample, int n_layers, const int* dims) {
   for (int l = 1; l <= 3; ++l)
     if (dims[l] <= 0 || dims[l] > 128) return -1;
   const int s1 = (dims[1] + 15) / 16, s2 = (dims[2] + 15) / 16, t2 = (dims[3] + 31) / 32;
-  const bool small_k = c + 3 <= 16;                 // one slab, element-wise gather
+  const bool small_k = c == 6;                      // one slab, the 6-float row read in place (any row stride)
   const bool vec_k = c == 96;                       // S0 = 7 (the instantiated slab count)
   if (small_k && s1 == 1 && s2 == 1 && t2 == 1) return 1;       // 9 -> 16 -> 16 -> 32
   if (small_k && s1 == 2 && s2 == 2 && t2 == 2) return 2;       // 9 -> 32 -> 32 -> 64
@@ -1481,7 +1485,7 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   if (b <= 0 || m <= 0) return 0;
   if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
     return (int)hipErrorInvalidValue;
-  // narrow chains (fp16 x 2): a kernel of their own; the element-wise instances (c + 3 <= 16) take any row stride
+  // narrow chains (fp16 x 2): a kernel of their own; the six-feature instances (c == 6) take any row stride
   const int nsig = arith == 1 ? nw_signature(c, nsample, n_layers, dims_host) : -1;
   const bool narrow = nsig >= 0 && (nsig <= 2 || vec_ok(features_pm, ld_feat));
   if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith) || dims_host[0] != c + 3 ||

@@ -493,9 +493,9 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
         out_coff = 0
     ld_out = out_pm.size(2)
     vec = use_xyz and feat is not None and ld_feat % 4 == 0 and feat.data_ptr() % 16 == 0
-    # (the narrow-chain kernel reads a table of <= 13 feature channels element by element: any row stride, e.g. the
-    # in-place view pc[..., 3:] of SA level 0)
-    few = use_xyz and feat is not None and C + 3 <= 16
+    # (the narrow-chain kernel reads a six-feature table in place, whatever its row stride: the view pc[..., 3:] of SA
+    # level 0)
+    few = use_xyz and feat is not None and C == 6
     if ((vec or few) and _fused_mlp.MLP_ARITH == "fp16x2" and (SPLIT2_NARROW or packed.dims[1] >= 128)
             and lib.pvn3d_mlp_split2_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
         w2, meta = packed.split2()
