@@ -140,18 +140,28 @@ def test_train_step_algorithmic_work():
 
 def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
     """bench.mlp_chain_table asks the library's own dispatch tests (pvn3d_mlp_split2_ok / pvn3d_mlp_split_ok,
-    _ext.fp_layerwise_shape_ok; host-only).  Default arithmetic ("fp16x2"): SA levels 1-3 and FP levels 0-1 of the
-    backbone run the fused two-piece fp16 kernels (peak 2500 / 3 TFLOP/s of algorithmic fp32 flops), the 512-wide FP
-    levels 2-3 the layer-by-layer split GEMM in the same two-piece arithmetic (pvn3d_split_gemm2; same price) when the
-    forward has enough points (64 frames: yes, one frame: no), SA level 0 the fp32-MFMA kernels (157.3).  Under
-    "bf16x3" the round-4 table (six products, 2500 / 6) comes back."""
+    _ext.fp_layerwise_shape_ok; host-only).  Default arithmetic ("fp16x2"): every SA level and FP levels 0-1 of the
+    backbone run fused two-piece fp16 kernels (SA levels 0-1 the narrow-chain kernel; peak 2500 / 3 TFLOP/s of
+    algorithmic fp32 flops), the 512-wide FP levels 2-3 the layer-by-layer split GEMM in the same two-piece arithmetic
+    (pvn3d_split_gemm2; same price) when the forward has enough points (64 frames: yes, one frame: no).  With the
+    narrow-chain kernel switched off SA level 0 is back on the fp32-MFMA kernels (157.3); under "bf16x3" the round-4
+    table (six products, 2500 / 6) comes back."""
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
     from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
     assert _fused_mlp.MLP_ARITH == "fp16x2"
     rows = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=64)
     h2 = {r["chain"] for r in rows if r["arithmetic"].startswith("fp16x2")}
     b3 = {r["chain"] for r in rows if r["arithmetic"].startswith("bf16x3")}
-    assert h2 == {"SA1.0", "SA1.1", "SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1", "FP2", "FP3"} and b3 == set()
+    assert h2 == {"SA0.0", "SA0.1", "SA1.0", "SA1.1", "SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1", "FP2", "FP3"}
+    assert b3 == set()
+    from pvn3d_amd._lib import lib
+    lib.pvn3d_set_sa_narrow(0)
+    try:
+        off = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=64)
+    finally:
+        lib.pvn3d_set_sa_narrow(1)
+    assert {r["chain"] for r in off if r["arithmetic"].startswith("fp32")} == {"SA0.0", "SA0.1"}
+    assert all(abs(r["peak_tflops"] - 157.3) < 1e-9 for r in off if r["arithmetic"].startswith("fp32"))
     assert {r["chain"] for r in rows if r["arithmetic"].endswith("layer by layer")} == {"FP2", "FP3"}
     one = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=1)
     assert {r["chain"] for r in one if r["arithmetic"].endswith("layer by layer")} == set()

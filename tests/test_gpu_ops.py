@@ -1,5 +1,7 @@
 """Parity of the gfx950 pointnet2 ops (through the C ABI, via the reference-API shim) against
 the CPU oracle on identical seeded inputs.  Indices bit-exact; gathers exact."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -680,6 +682,69 @@ def test_fused_sa_mlp_generic_paths(dev, c_in, mlp, ns, npoint, n, mlp_route):
     assert getattr(sa.mlps[0], "_pvn3d_packed")[1] is not None
     assert out_f.shape == out_u.shape
     assert (out_f - out_u).abs().max().item() < 1e-4 * max(out_u.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,mlp,ns,npoint,n,B", [
+    (6, [6, 16, 16, 32], 16, 37, 700, 14),      # SA level 0, scale 0: two centres per tile, ragged last tile (37 x 16)
+    (6, [6, 32, 32, 64], 32, 41, 700, 7),       # SA level 0, scale 1: features read in place from the (B, N, 9) cloud
+    (96, [96, 64, 64, 128], 16, 75, 600, 7),    # SA level 1, scale 0: odd centre count, 75 x 16 columns
+    (96, [96, 64, 96, 128], 32, 50, 600, 6),    # SA level 1, scale 1
+    (96, [96, 64, 96, 128], 32, 1024, 2048, 20),  # more tiles than waves of the persistent grid: every wave loops
+])
+def test_narrow_chain_kernel_matches_the_other_kernels_and_torch(dev, c_in, mlp, ns, npoint, n, B):
+    """The narrow-chain kernel of csrc/sa_mlp_split.hip (SA levels 0-1: weights resident in LDS, one wave per 32
+    columns through the whole chain, transposed last layer) behind pvn3d_sa_mlp_maxpool_split2: against the kernels it
+    replaces (pvn3d_set_sa_narrow(0): the 4 + 4 wave fp16 x 2 kernel for SA level 1, the fp32-MFMA kernel for SA level
+    0) to a few 1e-6 of the output scale, against the op-by-op torch composition to 2e-5, bit-identical run to run, and
+    the abs-max it leaves for the next level equals the table's."""
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _ext, _fused_mlp
+    if _fused_mlp.MLP_ARITH != "fp16x2":
+        pytest.skip("fp16 x 2 kernels only")
+    from pvn3d_amd.lib.pointnet2_utils import _small_batch
+    assert B * npoint * ns >= 64 * _small_batch.MAX_FUSED_WGS        # (below that the modules take the small-batch route)
+    torch.manual_seed(5)
+    sa = pm.PointnetSAModule(mlp=list(mlp), npoint=npoint, radius=0.09, nsample=ns).to(dev).eval()
+    _randomize_bn(sa)
+    sa._point_major_out = True
+    xyz = T(clouds(21, B, n, 0.1), dev)
+    if c_in == 6:
+        pc = torch.cat([xyz, 3.0 * torch.randn(B, n, 6, device=dev)], 2).contiguous()
+        feats = pc[..., 3:].transpose(1, 2)                  # row stride 9 floats: not 16-byte aligned
+    else:
+        feats = (40.0 * torch.randn(B, n, c_in, device=dev)).transpose(1, 2)
+    with torch.no_grad():
+        geo = sa.sample_and_query(xyz)
+        _, out_n = sa(xyz, feats, geometry=geo)
+        _, out_n2 = sa(xyz, feats, geometry=geo)
+        lib.pvn3d_set_sa_narrow(0)
+        try:
+            _, out_o = sa(xyz, feats, geometry=geo)
+        finally:
+            lib.pvn3d_set_sa_narrow(1)
+        pm.FUSED_INFERENCE = False
+        try:
+            _, out_u = sa(xyz, feats.contiguous(), geometry=None)
+        finally:
+            pm.FUSED_INFERENCE = True
+    torch.cuda.synchronize()
+    dims = (ctypes.c_int * 4)(mlp[0] + 3, *mlp[1:])
+    assert lib.pvn3d_mlp_split2_ok(1, c_in, 0, ns, 3, dims) == 1
+    lib.pvn3d_set_sa_narrow(0)
+    try:
+        assert lib.pvn3d_mlp_split2_ok(1, c_in, 0, ns, 3, dims) == (1 if c_in == 96 else 0)
+    finally:
+        lib.pvn3d_set_sa_narrow(1)
+    scale = max(out_u.abs().max().item(), 1.0)
+    assert out_n.shape == out_u.shape == (B, mlp[-1], npoint)
+    assert torch.equal(out_n, out_n2)
+    assert (out_n - out_o).abs().max().item() < 4e-6 * scale
+    assert (out_n - out_u).abs().max().item() < 2e-5 * scale
+    bound = getattr(out_n, "_pvn3d_absmax", None)
+    assert bound is not None and abs(bound[1].item() - out_n.abs().max().item()) == 0.0
+    if c_in == 6:       # switched off, SA level 0 runs the fp32-MFMA kernel, which leaves no bound behind
+        assert getattr(out_o, "_pvn3d_absmax", None) is None
 
 
 @pytest.mark.gpu

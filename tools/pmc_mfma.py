@@ -35,13 +35,18 @@ FRAMES = 64
 N_XCD = 8          # GRBM_GUI_ACTIVE comes back summed over the XCDs
 
 
+def is_chain(name):
+    """a fused-chain kernel: the fp32 / split 4 + 4 wave families (mlp_chain_*) or the narrow-chain kernel of SA levels 0-1"""
+    return "mlp_chain" in name or "sa_chain_narrow" in name
+
+
 def group_launches(launches):
     """launches: [(dispatch id, kernel name)] of the whole run, in order -> one list of dispatch ids per entry of CHAINS
     for the LAST fused forward.  A forward starts at SA level 0's first kernel.  A chain is one mlp_chain* launch, except:
     FP levels 3 / 2 run layer by layer on the split GEMM (three consecutive sg_gemm launches, csrc/split_gemm.hip), and
     a single sg_gemm in front of a chain kernel is that level's pre-contraction (_ext.sa_precontract, the FP level-0
     form in _ext.fp_interp_mlp) -- booked on the chain that follows it."""
-    first = next(k for _, k in launches if "mlp_chain" in k)
+    first = next(k for _, k in launches if is_chain(k))
     start = max(i for i, (_, k) in enumerate(launches) if k == first)
     groups, pending = [], []
     for d, k in launches[start:]:
@@ -68,11 +73,11 @@ def main():
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900)
     ctr = collections.OrderedDict()
     for r in csv.DictReader(open(glob.glob(out + "/**/*counter_collection.csv", recursive=True)[0])):
-        if "mlp_chain" in r["Kernel_Name"] or "sg_gemm" in r["Kernel_Name"]:
+        if is_chain(r["Kernel_Name"]) or "sg_gemm" in r["Kernel_Name"]:
             ctr.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
     dur = {}
     for r in csv.DictReader(open(glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0])):
-        if "mlp_chain" in r["Kernel_Name"] or "sg_gemm" in r["Kernel_Name"]:
+        if is_chain(r["Kernel_Name"]) or "sg_gemm" in r["Kernel_Name"]:
             dur[int(r["Dispatch_Id"])] = ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                                           r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0])
     groups = group_launches([(d, dur[d][1]) for d in sorted(ctr)])
@@ -90,9 +95,9 @@ def main():
         # on could deliver of THAT quantity at the measured clock (bf16 peak / 6 for the split chains).
         # fp16 x 2 chains (round 5; template argument AR = 1 of mlp_chain_s3_kernel / sg_gemm_kernel): three fp16 partial
         # products per multiply on v_mfma_f32_32x32x16_f16 -> bf16/fp16 peak / 3.
-        split = "s3_kernel" in kern or "sg_gemm" in kern
+        split = "s3_kernel" in kern or "sg_gemm" in kern or "sa_chain_narrow" in kern
         last = dur[g[-1]][1]
-        fp16 = split and (last.rstrip().endswith(", 1>") or "sg_gemm_kernel<1>" in last)
+        fp16 = split and (last.rstrip().endswith(", 1>") or "sg_gemm_kernel<1>" in last or "sa_chain_narrow" in last)
         per_clk = 1024.0 / 3.0 if fp16 else 1024.0 / 6.0 if split else 64.0
         rows.append(dict(chain=name, kernel=kern, arithmetic="fp16x2 split (3 fp16 MFMA products per fp32 multiply)" if fp16
                          else "bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split
