@@ -264,6 +264,18 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  * level 0 is refused by pvn3d_mlp_split2_ok and stays on pvn3d_sa_mlp_maxpool); 1 = on, the default. */
 int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);
 void pvn3d_set_sa_narrow(int on);
+/* The FP chain in its pre-contracted form: the caller promises that the first c2 columns of layer 0's weights are the
+ * identity (known_pm holds the first conv's interpolated half, already applied per KNOWN point: what
+ * _ext.fp_interp_mlp does for FP level 0), i.e. layer 0 = relu(interp(known) + Wb.skip + b0).  Arguments and results as
+ * pvn3d_fp_interp_mlp_split2, which computes the same thing by multiplying with that identity and is what this entry
+ * point falls back to; for c2 = 128, c1 = 6, 128 -> 128, channel-major output (FP level 0 of the backbone) the
+ * narrow-chain kernel adds the interpolated rows to the accumulators instead (pvn3d_set_sa_narrow switches it too). */
+int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                                   const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                                   int n_layers, const int* dims_host, const void* const* w_split2,
+                                   const float* const* bias_padded, const float* layer_meta,
+                                   const float* known_absmax, const float* unknown_absmax, float* out,
+                                   int out_point_major, int ld_out, float* out_absmax, void* stream);
 int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features_pm, int ld_feat, const int* idx, int n_layers,
                                 const int* dims_host, const void* const* w_split2, const float* const* bias_padded,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pvn3d_set_sa_narrow": (None, [_i]),
     "pvn3d_sa_mlp_maxpool_split2": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "pvn3d_fp_interp_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "pvn3d_fp_interp_add_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "pvn3d_absmax": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p]),
     "pvn3d_split_rows2": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p, _i, _p]),
     "pvn3d_split_gemm2": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),

@@ -1036,8 +1036,8 @@ __device__ __forceinline__ void nw_prime(NwFrag (&q)[NW_PF + 1], const char* w) 
 
 // S0, S1, S2: 16-k slabs of the three layers (S1 = ceil(M0 / 16), S2 = ceil(M1 / 16)); T2: 32-row tiles of the last
 // layer; VEC: the feature table is read in 16-byte pieces (C a multiple of 16, aligned rows; S0 = C / 16 + 1, the last
-// slab holds the relative coordinates) -- otherwise C + 3 <= 16 channels, element by element (SA level 0: 6 features +
-// 3 coordinates); MINW: waves per SIMD the register budget is set for (2 = one workgroup per CU, 4 = two)
+// slab holds the relative coordinates) -- otherwise C = 6: the six-float rows of SA level 0 read in place (6 features +
+// 3 coordinates = one slab); MINW: waves per SIMD the register budget is set for (2 = one workgroup per CU, 4 = two)
 template <int S0, int S1, int S2, int T2, bool VEC, int MINW>
 __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Args a, int tiles_per_frame, int tiles_total) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
@@ -1089,7 +1089,6 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   const float* sb0 = s_bias;
   const float* sb1 = s_bias + T0 * 32;
   const float* sb2 = s_bias + (T0 + T1) * 32;
-  const int C = a.K[0] - 3;
   const int ns = a.ns;
   const float s0 = sc.s_in[0];
   const float om = sc.next_mul[2];
@@ -1274,6 +1273,176 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   }
 }
 
+// ---- feature propagation, pre-contracted two-layer chain (FP level 0 of the backbone) on the same plan ---------------------
+// y0 = relu(interp(z) + Wb.skip + b0), y1 = relu(W1.y0 + b1): z (B, m, M0) is the first conv's interpolated half, already
+// applied per KNOWN point (_ext.fp_interp_mlp's pre-contraction).  The 4 + 4 wave kernel receives this chain with an
+// identity block in front of Wb and multiplies the interpolated rows by it -- M0 / 16 slabs of MFMAs that copy.  Here a
+// wave owns 32 unknown points: the three neighbours' rows of z are read in the ACCUMULATOR layout (lane = column,
+// registers = rows 8 j + 4 half + i: 16-byte pieces of a row), weighted, scaled and added to the bias -- that is layer
+// 0's accumulator before the skip slab's MFMAs; layer 1 and the weights in LDS as in the set-abstraction kernel; the
+// result leaves in the channel-major (B, M1, n) layout of the reference, 128 contiguous bytes per register and half-wave.
+struct __attribute__((packed, aligned(4))) NwI3 { int v[3]; };
+
+template <int T, int MINW>
+__global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Args a, int tiles_per_frame, int tiles_total) {
+  extern __shared__ __attribute__((aligned(16))) char s_mem[];
+  __shared__ float s_amax[NW_WAVES];
+  constexpr int S1 = 2 * T;                          // layer 1 contracts over M0 = 32 T channels
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  constexpr int w1_off = T * 2048, bias_off = w1_off + S1 * T * 2048;
+  const S3Scales sc = s3_scales(a);
+  {   // the skip slab of layer 0 (the slab behind the identity block), layer 1 with its K permuted, biases in the accumulators' scale
+    const uint4* src = a.W[0] + (size_t)(S1 * T) * 128;
+    uint4* dst = reinterpret_cast<uint4*>(s_mem);
+    for (int i = tid; i < T * 128; i += NW_THREADS) dst[i] = src[i];
+    const char* src1 = reinterpret_cast<const char*>(a.W[1]);
+    char* dst1 = s_mem + w1_off;
+    for (int u = tid; u < S1 * T * 256; u += NW_THREADS) {
+      const int f = u >> 8, pc = (u >> 7) & 1, ln = (u >> 1) & 63, q = u & 1;
+      const int m = ln & 31, h = ln >> 5;
+      *reinterpret_cast<uint2*>(dst1 + f * 2048 + pc * 1024 + ln * 16 + 8 * q) =
+          *reinterpret_cast<const uint2*>(src1 + f * 2048 + pc * 1024 + (m + 32 * q) * 16 + 8 * h);
+    }
+    float* sb = reinterpret_cast<float*>(s_mem + bias_off);
+    for (int i = tid; i < 32 * T; i += NW_THREADS) {
+      sb[i] = a.bias[0][i] * sc.bias_mul[0];
+      sb[32 * T + i] = a.bias[1][i] * sc.bias_mul[1];
+    }
+  }
+  __syncthreads();
+  const char* w0 = s_mem + lane * 16;
+  const char* w1 = s_mem + w1_off + lane * 16;
+  const float* sb0 = reinterpret_cast<const float*>(s_mem + bias_off);
+  const float* sb1 = sb0 + 32 * T;
+  const float bm0 = sc.bias_mul[0], s0 = sc.s_in[0], om = sc.next_mul[1];
+  const int n = a.cols_total, M1 = a.M[1];
+  float amax = 0.f;
+
+  const int gw = blockIdx.x * NW_WAVES + wave, nw = gridDim.x * NW_WAVES;
+  int tile = gw;
+  int bi = tile / tiles_per_frame, tin = tile - bi * tiles_per_frame;
+  for (; tile < tiles_total; tile += nw) {
+    const int g = tin * 32 + col, gc = min(g, n - 1);
+    const size_t o3 = ((size_t)bi * n + gc) * 3;
+    const NwI3 id = *reinterpret_cast<const NwI3*>(a.idx + o3);
+    const NwF3 wt = *reinterpret_cast<const NwF3*>(a.weight + o3);
+    const NwF6 sk = *reinterpret_cast<const NwF6*>(a.tabB + ((size_t)bi * a.rowsB + gc) * a.ldB);
+    const float* z0 = a.tabA + ((size_t)bi * a.rowsA + id.v[0]) * a.ldA + 4 * half;
+    const float* z1 = a.tabA + ((size_t)bi * a.rowsA + id.v[1]) * a.ldA + 4 * half;
+    const float* z2 = a.tabA + ((size_t)bi * a.rowsA + id.v[2]) * a.ldA + 4 * half;
+    // ---- layer 0's accumulators: (three_interpolate(z) (pointnet2_utils.py:136-170: p0 w0 + p1 w1 + p2 w2, unfused, in
+    // this order) in the accumulators' scale) + bias
+    f32x16 acc0[T];
+    NwFrag q[NW_PF + 1];
+    nw_prime<T>(q, w0);
+    // (rows of tile t + 1 are requested before tile t's are used; without the fences the compiler requests all four
+    // tiles at once -- 192 registers -- and spills)
+    float4 P[2][3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      P[0][0][j] = *reinterpret_cast<const float4*>(z0 + 8 * j);
+      P[0][1][j] = *reinterpret_cast<const float4*>(z1 + 8 * j);
+      P[0][2][j] = *reinterpret_cast<const float4*>(z2 + 8 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      if (t + 1 < T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          P[(t + 1) & 1][0][j] = *reinterpret_cast<const float4*>(z0 + 32 * (t + 1) + 8 * j);
+          P[(t + 1) & 1][1][j] = *reinterpret_cast<const float4*>(z1 + 32 * (t + 1) + 8 * j);
+          P[(t + 1) & 1][2][j] = *reinterpret_cast<const float4*>(z2 + 32 * (t + 1) + 8 * j);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 bb = *reinterpret_cast<const float4*>(sb0 + 32 * t + 8 * j + 4 * half);
+        const float4 a0 = P[t & 1][0][j], a1 = P[t & 1][1][j], a2 = P[t & 1][2][j];
+        acc0[t][4 * j + 0] = (a0.x * wt.v[0] + a1.x * wt.v[1] + a2.x * wt.v[2]) * bm0 + bb.x;
+        acc0[t][4 * j + 1] = (a0.y * wt.v[0] + a1.y * wt.v[1] + a2.y * wt.v[2]) * bm0 + bb.y;
+        acc0[t][4 * j + 2] = (a0.z * wt.v[0] + a1.z * wt.v[1] + a2.z * wt.v[2]) * bm0 + bb.z;
+        acc0[t][4 * j + 3] = (a0.w * wt.v[0] + a1.w * wt.v[1] + a2.w * wt.v[2]) * bm0 + bb.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the skip slab: k = M0 + 0..5 in the low half's positions 0..5
+    {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = half ? 0.f : sk.v[k];
+      x[6] = 0.f; x[7] = 0.f;
+      uint4 bh, bl;
+      nw_split8(x, s0, bh, bl);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (t + NW_PF < T) q[(t + NW_PF) % (NW_PF + 1)] = nw_ld(w0, t + NW_PF);
+        nw_mm<false>(acc0[t], q[t % (NW_PF + 1)].h, q[t % (NW_PF + 1)].l, bh, bl);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- layer 1
+    nw_prime<S1 * T>(q, w1);
+    uint4 b1[S1][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) nw_next_frags(acc0[t], sc.next_mul[0], b1[2 * t], b1[2 * t + 1]);
+    __builtin_amdgcn_sched_barrier(0);               // (layer 0's accumulators are dead before layer 1's are born)
+    f32x16 acc1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc_bias(acc1[t], sb1 + 32 * t, half);
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        constexpr int NF = S1 * T;
+        const int i = s * T + t;
+        if (i + NW_PF < NF) q[(i + NW_PF) % (NW_PF + 1)] = nw_ld(w1, i + NW_PF);
+        nw_mm<false>(acc1[t], q[i % (NW_PF + 1)].h, q[i % (NW_PF + 1)].l, b1[s][0], b1[s][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- relu, store: register 4 j + i of tile t = channel 32 t + 8 j + 4 half + i of this lane's point (M1 = 32 T).
+    // One wave-uniform row pointer walks the channels (a running scalar: 64 precomputed row offsets per lane were
+    // hoisted out of the tile loop and spilled), the lane adds its point and its half's four rows once
+    if (g < n) {
+      const unsigned voff = ((unsigned)g + 4u * (unsigned)half * (unsigned)n) * 4u;
+      const char* rowp = reinterpret_cast<const char*>(a.out + (size_t)bi * M1 * n);
+      const size_t step = (size_t)n * 4;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = s3_relu(acc1[t][4 * j + i]) * om;
+            *reinterpret_cast<float*>(const_cast<char*>(rowp) + voff) = v;
+            amax = fmaxf(amax, v);
+            rowp += step;
+          }
+          rowp += 4 * step;
+          asm volatile("" : "+s"(rowp));      // keep it a running pointer
+        }
+    }
+    tin += nw;
+    while (tin >= tiles_per_frame) { tin -= tiles_per_frame; ++bi; }
+  }
+  if (a.out_absmax) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW_WAVES; ++w) m = fmaxf(m, s_amax[w]);
+      if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.out_absmax, __float_as_uint(m));
+    }
+  }
+}
+
 // process-wide A/B switch of the narrow-chain kernel (pvn3d_set_sa_narrow; tools/s3_time.py)
 int g_nw_enabled = 1;
 
@@ -1318,6 +1487,29 @@ int nw_launch(S3Args& a, int sig, hipStream_t st) {
   else if (sig == 4) NW_GO(7, 4, 6, 4, true, 2);
   else return -1;
 #undef NW_GO
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
+
+// the pre-contracted FP chain the narrow kernel takes: M0 = M1 = 128, six skip channels, channel-major output
+bool nwfp_ok(int c2, int c1, int n_layers, const int* dims, int out_point_major) {
+  return g_nw_enabled && n_layers == 2 && c2 == 128 && c1 == 6 && dims[0] == c2 + c1 && dims[1] == 128 && dims[2] == 128 &&
+         !out_point_major;
+}
+int nwfp_launch(S3Args& a, hipStream_t st) {
+  constexpr int T = 4;
+  const size_t lds = (size_t)(T + 2 * T * T) * 2048 + (size_t)2 * 32 * T * 4;
+  const int tpf = pvn3d_ceil_div(a.cols_total, 32);
+  const long long total = (long long)tpf * a.n_frames;
+  if (total > 0x7fffffff) return -1;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(fp_chain_narrow_kernel<T, 2>));
+  const int grid = (int)min((long long)cus, (total + NW_WAVES - 1) / NW_WAVES);
+  hipLaunchKernelGGL((fp_chain_narrow_kernel<T, 2>), dim3(grid), dim3(NW_THREADS), lds, st, a, tpf, (int)total);
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
@@ -1580,6 +1772,39 @@ extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, c
   return s3_fp_entry(1, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
                      w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, out_absmax,
                      stream);
+}
+
+// The pre-contracted form (DESIGN 4.7b''): the caller promises that the first c2 columns of layer 0's weights are the
+// identity (PackedMLP.precontracted), i.e. layer 0 = relu(interp(known) + Wb.skip + b0) with known_pm holding the first
+// conv's interpolated half per known point.  Same arguments and results as pvn3d_fp_interp_mlp_split2 (which computes
+// the same thing by multiplying with that identity); the shapes the narrow kernel takes skip those MFMAs.
+extern "C" int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
+                                              const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
+                                              int n_layers, const int* dims_host, const void* const* w_split2,
+                                              const float* const* bias_padded, const float* layer_meta,
+                                              const float* known_absmax, const float* unknown_absmax, float* out,
+                                              int out_point_major, int ld_out, float* out_absmax, void* stream) {
+  if (b > 0 && n > 0 && dims_host && known_pm && unknown_pm && idx && weight && out && w_split2 && bias_padded &&
+      nwfp_ok(c2, c1, n_layers, dims_host, out_point_major) && vec_ok(known_pm, ld_known) && ld_known >= c2 &&
+      ld_unknown >= c1 && unknown_absmax) {
+    S3Args a = {};
+    if (!s3_fill(&a, n_layers, dims_host, w_split2, bias_padded) ||
+        !s3_fill_scales(&a, n_layers, layer_meta, known_absmax, unknown_absmax, 1.f))
+      return (int)hipErrorInvalidValue;
+    a.out_absmax = (unsigned*)out_absmax;
+    a.is_sa = 0;
+    a.idx = idx; a.weight = weight;
+    a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known;
+    a.tabB = unknown_pm; a.rowsB = n; a.ldB = ld_unknown;
+    a.cols_total = n;
+    a.n_frames = b;
+    a.out = out; a.point_major = 0; a.ld_out = ld_out; a.coff = 0;
+    const int rc = nwfp_launch(a, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
+  return pvn3d_fp_interp_mlp_split2(b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers,
+                                    dims_host, w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out,
+                                    out_point_major, ld_out, out_absmax, stream);
 }
 
 // max |x| over a point-major table [rows][ld] (channels [0, c)) -> *out (device float), as an atomic max on the bit

@@ -692,6 +692,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     # interpolation (six times fewer points, and the chain then gathers 128 instead of 256 channels per neighbour) --
     # the regrouping of _fp_layerwise_split with the fused kernel behind it
     split_ok = lib.pvn3d_mlp_split2_ok if _fused_mlp.MLP_ARITH == "fp16x2" else lib.pvn3d_mlp_split_ok
+    precontracted = False          # layer 0 of `packed` starts with an identity block over kf's channels
     if (FP_PRECONTRACT and _fused_mlp.split_arith() and packed.n_layers == 2 and C1 > 0 and C2 >= 256
             and packed.dims[1] % 32 == 0 and 2 * packed.dims[1] <= C2 and n >= 4 * m and B * m >= 4096
             and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0):
@@ -723,6 +724,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                     check(lib.pvn3d_split_gemm(B * m, n_out, S, xs.data_ptr(), wp.data_ptr(), None, 0, None, 0, 0, 0, None,
                                                None, z.data_ptr(), n_out, None, 0, st), "split_gemm")
             kf, ld_k, C2, packed = z, n_out, pre.dims[1], pre
+            precontracted = True
     vec = ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
     if (vec and _fused_mlp.MLP_ARITH == "fp16x2"
             and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
@@ -731,8 +733,11 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
         amax = torch.zeros(1, dtype=torch.float32, device=known_feats.device) if point_major_out else None
         ka = table_absmax(kf, B * m, C2, ld_k)
         ua = table_absmax(uf, B * n, C1, ld_u) if uf is not None else None
+        # (the pre-contracted form has an entry point of its own: the shapes its kernel takes add the interpolated rows
+        # to the accumulators instead of multiplying them with the identity block)
+        entry = lib.pvn3d_fp_interp_add_mlp_split2 if precontracted else lib.pvn3d_fp_interp_mlp_split2
         with on_device(known_feats.device):
-            check(lib.pvn3d_fp_interp_mlp_split2(B, n, m, C2, C1, kf.data_ptr(), ld_k,
+            check(entry(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                                  uf.data_ptr() if uf is not None else None, ld_u, idx.data_ptr(),
                                                  weight.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c, meta,
                                                  ka.data_ptr(), ua.data_ptr() if ua is not None else None, out.data_ptr(),

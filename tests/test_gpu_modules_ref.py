@@ -340,7 +340,8 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
         # FP1 fp16 x 2 chain; FP2-3 layer by layer (three split GEMMs and two row splits each); nothing on the
         # small-batch route, nothing on bf16 x 3 chains, nothing left on the fp32-MFMA kernels
         assert c["pvn3d_sa_mlp_maxpool"] == 0 and c["pvn3d_sa_mlp_maxpool_split2"] == 8 and c["pvn3d_sa_mlp_maxpool_split"] == 0
-        assert c["pvn3d_fp_interp_mlp_split2"] == 2 and c["pvn3d_fp_interp_mlp"] == 0 and c["pvn3d_fp_interp_mlp_split"] == 0
+        assert c["pvn3d_fp_interp_mlp_split2"] == 1 and c["pvn3d_fp_interp_add_mlp_split2"] == 1       # FP1, FP0 (pre-contracted)
+        assert c["pvn3d_fp_interp_mlp"] == 0 and c["pvn3d_fp_interp_mlp_split"] == 0
         # (row splits: SA1's and SA2's outputs are split ONCE although the next SA level's pre-contraction and an FP
         # level's skip half both contract over them: 7 tables minus 2 shared)
         assert c["pvn3d_split_gemm2"] == 2 + 1 + 3 + 3 and c["pvn3d_split_rows2"] == 2 + 1 + 2 + 2 - 2   # all in fp16 x 2

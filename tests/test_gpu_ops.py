@@ -748,6 +748,67 @@ def test_narrow_chain_kernel_matches_the_other_kernels_and_torch(dev, c_in, mlp,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,n,m", [(4, 4096 + 37, 1024), (9, 2048, 512)])
+def test_narrow_fp_chain_kernel_matches_the_identity_form_and_torch(dev, B, n, m):
+    """FP level 0's shape (256 + 6 -> 128 -> 128, channel-major output, skip features read in place from a (B, n, 9)
+    cloud): _ext.fp_interp_mlp pre-contracts the first conv and calls pvn3d_fp_interp_add_mlp_split2, whose narrow-chain
+    kernel adds the interpolated rows to the accumulators; switched off, the same entry point multiplies them with the
+    identity block (the 4 + 4 wave kernel).  Both against each other (4e-6 of the output scale), against the op-by-op
+    torch composition (2e-5), run to run (bits), with a ragged last tile (n = 4133)."""
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import pointnet2_modules as pm, _ext, _fused_mlp
+    if _fused_mlp.MLP_ARITH != "fp16x2":
+        pytest.skip("fp16 x 2 kernels only")
+    assert n >= 4 * m and B * m >= 4096                       # the pre-contraction's own conditions (_ext.fp_interp_mlp)
+    torch.manual_seed(6)
+    fp = pm.PointnetFPModule(mlp=[262, 128, 128]).to(dev).eval()
+    _randomize_bn(fp)
+    unknown = T(clouds(31, B, n, 0.1), dev)
+    known = unknown[:, :m].contiguous()
+    pc = torch.cat([unknown, 2.0 * torch.randn(B, n, 6, device=dev)], 2).contiguous()
+    uf = pc[..., 3:].transpose(1, 2)                          # row stride 9 floats
+    kf = (7.0 * torch.randn(B, m, 256, device=dev)).transpose(1, 2)
+    calls = []
+    real = _ext.lib.pvn3d_fp_interp_add_mlp_split2
+
+    class _Spy(object):
+        def __getattr__(self, name):
+            f = getattr(lib, name)
+            if name != "pvn3d_fp_interp_add_mlp_split2":
+                return f
+
+            def g(*a):
+                calls.append(name)
+                return f(*a)
+            return g
+    with torch.no_grad():
+        nb = fp.neighbours(unknown, known)
+        _ext.lib = _Spy()
+        try:
+            out_n = fp(unknown, known, uf, kf, neighbours=nb)
+        finally:
+            _ext.lib = lib
+        out_n2 = fp(unknown, known, uf, kf, neighbours=nb)
+        lib.pvn3d_set_sa_narrow(0)
+        try:
+            out_o = fp(unknown, known, uf, kf, neighbours=nb)
+        finally:
+            lib.pvn3d_set_sa_narrow(1)
+        pm.FUSED_INFERENCE = False
+        try:
+            out_u = fp(unknown, known, uf.contiguous(), kf.contiguous())
+        finally:
+            pm.FUSED_INFERENCE = True
+    torch.cuda.synchronize()
+    assert real is not None and calls == ["pvn3d_fp_interp_add_mlp_split2"]
+    scale = max(out_u.abs().max().item(), 1.0)
+    assert out_n.shape == out_u.shape == (B, 128, n) and out_n.is_contiguous()
+    assert torch.equal(out_n, out_n2)
+    assert (out_n - out_o).abs().max().item() < 4e-6 * scale
+    assert (out_n - out_u).abs().max().item() < 2e-5 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c2,c1,mlp,n,m", [
     (70, 0, [70, 64], 300, 90),             # known width not a multiple of 32, no skip features
     (64, 33, [97, 140, 30], 257, 64),       # skip features with a generic tail

@@ -37,7 +37,7 @@ N_XCD = 8          # GRBM_GUI_ACTIVE comes back summed over the XCDs
 
 def is_chain(name):
     """a fused-chain kernel: the fp32 / split 4 + 4 wave families (mlp_chain_*) or the narrow-chain kernel of SA levels 0-1"""
-    return "mlp_chain" in name or "sa_chain_narrow" in name
+    return "mlp_chain" in name or "chain_narrow" in name
 
 
 def group_launches(launches):
@@ -95,9 +95,9 @@ def main():
         # on could deliver of THAT quantity at the measured clock (bf16 peak / 6 for the split chains).
         # fp16 x 2 chains (round 5; template argument AR = 1 of mlp_chain_s3_kernel / sg_gemm_kernel): three fp16 partial
         # products per multiply on v_mfma_f32_32x32x16_f16 -> bf16/fp16 peak / 3.
-        split = "s3_kernel" in kern or "sg_gemm" in kern or "sa_chain_narrow" in kern
+        split = "s3_kernel" in kern or "sg_gemm" in kern or "chain_narrow" in kern
         last = dur[g[-1]][1]
-        fp16 = split and (last.rstrip().endswith(", 1>") or "sg_gemm_kernel<1>" in last or "sa_chain_narrow" in last)
+        fp16 = split and (last.rstrip().endswith(", 1>") or "sg_gemm_kernel<1>" in last or "chain_narrow" in last)
         per_clk = 1024.0 / 3.0 if fp16 else 1024.0 / 6.0 if split else 64.0
         rows.append(dict(chain=name, kernel=kern, arithmetic="fp16x2 split (3 fp16 MFMA products per fp32 multiply)" if fp16
                          else "bf16x3 split (6 bf16 MFMA products per fp32 multiply)" if split

@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 STAGE_OF = [("[sa_mlp]", "sa_mlp"), ("[fp_mlp]", "fp_mlp"),      # split-GEMM launches, tagged by run_pass
-            ("sa_chain_narrow_kernel", "sa_mlp"),
+            ("sa_chain_narrow_kernel", "sa_mlp"), ("fp_chain_narrow_kernel", "fp_mlp"),
             ("mlp_chain_s3_kernel<true", "sa_mlp"), ("mlp_chain_s3_kernel<false", "fp_mlp"),
             ("mlp_chain_kernel<true", "sa_mlp"), ("mlp_chain_wide_kernel<true", "sa_mlp"),
             ("mlp_chain_mid_kernel<true", "sa_mlp"), ("mlp_chain_cols_kernel<true", "sa_mlp"),
@@ -46,7 +46,7 @@ def run_pass(counter, outdir, extra=()):
     nxt, stage_after = None, [None] * len(rows)
     for i in range(len(rows) - 1, -1, -1):
         k = rows[i]["Kernel_Name"]
-        if "mlp_chain" in k or "sa_chain_narrow" in k:
+        if "mlp_chain" in k or "chain_narrow" in k:
             nxt = "sa_mlp" if ("<true" in k or "sa_chain_narrow" in k) else "fp_mlp"
         stage_after[i] = nxt
     for r, st in zip(rows, stage_after):
