@@ -1031,11 +1031,12 @@ def main():
         else:
             island = ("Pointnet2MSG forward (4 SA-MSG + 4 FP levels, random-init weights, eval): FPS, gather, "
                       "ball_query, fused group->SharedMLP->max-pool and three_nn, fused three_interpolate->SharedMLP; "
-                      "fp32 operands and results throughout; the contraction runs on fp32 MFMA (SA level 0), as three exact "
-                      "fp16 x fp16 partial products per multiply on fp16 MFMA with two fp16 pieces per operand (SA levels 1-3, FP "
-                      "levels 0-1 in one fused kernel per chain; FP levels 2-3 and the pre-contractions layer by layer; power-of-two "
-                      "range scaling from device-side bounds; PVN3D_MLP_ARITH=bf16x3 selects six bf16 x bf16 partial products "
-                      "with three bf16 pieces instead); all of them are as close "
+                      "fp32 operands and results throughout; the contraction runs as three exact fp16 x fp16 partial products "
+                      "per multiply on fp16 MFMA with two fp16 pieces per operand (every SA level and FP levels 0-1 in one fused "
+                      "kernel per chain -- SA levels 0-1 and FP level 0 the narrow-chain kernels with the chain's weights in LDS; "
+                      "FP levels 2-3 and the pre-contractions layer by layer; power-of-two range scaling from device-side "
+                      "bounds; PVN3D_MLP_ARITH=bf16x3 selects six bf16 x bf16 partial products with three bf16 pieces, fp32 the "
+                      "fp32-MFMA kernels); all of them are as close "
                       "to an fp64 evaluation as the fp32 FMA chain (tests: 2e-5 of the output scale, measured 5e-7 - 1e-6)")
         out = {
             "metric": "frames/sec (12 288 pts, 8 kps) end-to-end vote+cluster+pose; idx bit-exact",
