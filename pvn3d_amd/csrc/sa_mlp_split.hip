@@ -1034,6 +1034,31 @@ __device__ __forceinline__ void nw_prime(NwFrag (&q)[NW_PF + 1], const char* w) 
     if (i < NF) q[i] = nw_ld(w, i);
 }
 
+// XCD-aware tile walk of the narrow-chain kernels.  Workgroups are dealt round-robin to the 8 XCDs in linear-id order and
+// every XCD has its own L2: with the plain walk (tile = global wave id, += waves of the launch) consecutive tiles of one
+// frame go to all eight XCDs, and each of them fetches its own copy of that frame's tables from HBM (r05 counters: 7.8 x
+// the compulsory reads in the FP kernel, 6.3 x in SA level 0).  Here XCD x = blockIdx.x & 7 works through the frames
+// x, x + 8, ... with its own workgroups only (the launch rounds the grid to a multiple of 8); the tile numbering below
+// is LOCAL to that frame subset.  Any other frame count / grid keeps the plain walk (f0 = 0, fs = 1).
+struct NwWalk { int lw, nlw, f0, fs, total; };
+__device__ __forceinline__ NwWalk nw_walk(int wave, int tiles_per_frame, int tiles_total, int n_frames) {
+  NwWalk w;
+  if ((gridDim.x & 7) == 0 && (n_frames & 7) == 0) {
+    w.f0 = blockIdx.x & 7;
+    w.fs = 8;
+    w.lw = (int)(blockIdx.x >> 3) * NW_WAVES + wave;
+    w.nlw = (int)(gridDim.x >> 3) * NW_WAVES;
+    w.total = tiles_per_frame * (n_frames >> 3);
+  } else {
+    w.f0 = 0;
+    w.fs = 1;
+    w.lw = blockIdx.x * NW_WAVES + wave;
+    w.nlw = gridDim.x * NW_WAVES;
+    w.total = tiles_total;
+  }
+  return w;
+}
+
 // S0, S1, S2: 16-k slabs of the three layers (S1 = ceil(M0 / 16), S2 = ceil(M1 / 16)); T2: 32-row tiles of the last
 // layer; VEC: the feature table is read in 16-byte pieces (C a multiple of 16, aligned rows; S0 = C / 16 + 1, the last
 // slab holds the relative coordinates) -- otherwise C = 6: the six-float rows of SA level 0 read in place (6 features +
@@ -1121,10 +1146,17 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
     r.c[0] = c.v[0]; r.c[1] = c.v[1]; r.c[2] = c.v[2];
   };
 
-  const int gw = blockIdx.x * NW_WAVES + wave, nw = gridDim.x * NW_WAVES;
+  const NwWalk wk = nw_walk(wave, tiles_per_frame, tiles_total, a.n_frames);
+  const int nw = wk.nlw;
+  tiles_total = wk.total;                                                    // (local to this XCD's frames from here on)
   NwRaw<VEC, SF> raw;
-  int tile = gw;
-  int bi = tile / tiles_per_frame, tin = tile - bi * tiles_per_frame;        // the only division: the walk below steps
+  int tile = wk.lw;
+  int bi, tin;
+  {
+    const int lf = tile / tiles_per_frame;                                   // the only division: the walk below steps
+    tin = tile - lf * tiles_per_frame;
+    bi = wk.f0 + wk.fs * lf;
+  }
   if (tile < tiles_total) {
     int gc;
     const int id = tile_id(bi, tin, gc);
@@ -1133,7 +1165,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   for (; tile < tiles_total; tile += nw) {
     const int tn = tile + nw;
     int bi_n = bi, tin_n = tin + nw;
-    while (tin_n >= tiles_per_frame) { tin_n -= tiles_per_frame; ++bi_n; }
+    while (tin_n >= tiles_per_frame) { tin_n -= tiles_per_frame; bi_n += wk.fs; }
     int gc_n = 0, id_n = 0;
     if (tn < tiles_total) id_n = tile_id(bi_n, tin_n, gc_n);           // (arrives under layer 0)
     const int tcol = tin * 32;
@@ -1320,9 +1352,16 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
   const int n = a.cols_total, M1 = a.M[1];
   float amax = 0.f;
 
-  const int gw = blockIdx.x * NW_WAVES + wave, nw = gridDim.x * NW_WAVES;
-  int tile = gw;
-  int bi = tile / tiles_per_frame, tin = tile - bi * tiles_per_frame;
+  const NwWalk wk = nw_walk(wave, tiles_per_frame, tiles_total, a.n_frames);
+  const int nw = wk.nlw;
+  tiles_total = wk.total;
+  int tile = wk.lw;
+  int bi, tin;
+  {
+    const int lf = tile / tiles_per_frame;
+    tin = tile - lf * tiles_per_frame;
+    bi = wk.f0 + wk.fs * lf;
+  }
   for (; tile < tiles_total; tile += nw) {
     const int g = tin * 32 + col, gc = min(g, n - 1);
     const size_t o3 = ((size_t)bi * n + gc) * 3;
@@ -1426,7 +1465,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
         }
     }
     tin += nw;
-    while (tin >= tiles_per_frame) { tin -= tiles_per_frame; ++bi; }
+    while (tin >= tiles_per_frame) { tin -= tiles_per_frame; bi += wk.fs; }
   }
   if (a.out_absmax) {
 #pragma unroll
@@ -1477,7 +1516,8 @@ int nw_launch(S3Args& a, int sig, hipStream_t st) {
 #define NW_GO(S0, S1, S2, T2, VEC, MINW)                                                                               \
   do {                                                                                                                 \
     PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(sa_chain_narrow_kernel<S0, S1, S2, T2, VEC, MINW>));           \
-    const int grid = (int)min((long long)cus * (MINW / 2), (total + NW_WAVES - 1) / NW_WAVES);                         \
+    int grid = (int)min((long long)cus * (MINW / 2), (total + NW_WAVES - 1) / NW_WAVES);                               \
+    if (grid >= 8) grid &= ~7;            /* a multiple of 8: the kernel's frame -> XCD walk (nw_walk) */              \
     hipLaunchKernelGGL((sa_chain_narrow_kernel<S0, S1, S2, T2, VEC, MINW>), dim3(grid), dim3(NW_THREADS), lds, st, a,  \
                        tpf, (int)total);                                                                               \
   } while (0)
@@ -1508,7 +1548,8 @@ int nwfp_launch(S3Args& a, hipStream_t st) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(fp_chain_narrow_kernel<T, 2>));
-  const int grid = (int)min((long long)cus, (total + NW_WAVES - 1) / NW_WAVES);
+  int grid = (int)min((long long)cus, (total + NW_WAVES - 1) / NW_WAVES);
+  if (grid >= 8) grid &= ~7;              // a multiple of 8: the kernel's frame -> XCD walk (nw_walk)
   hipLaunchKernelGGL((fp_chain_narrow_kernel<T, 2>), dim3(grid), dim3(NW_THREADS), lds, st, a, tpf, (int)total);
   PVN3D_LAUNCH_CHECK();
   return 0;
