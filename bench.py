@@ -257,7 +257,7 @@ def mlp_chain_table(net, scale, frames=64):
         arr = (ctypes.c_int * len(dims))(*dims)
         args = (1 if is_sa else 0, c_a, c_b, ns, len(dims) - 1, arr)
         split2 = (_fused_mlp.MLP_ARITH == "fp16x2" and (_ext.SPLIT2_NARROW or dims[1] >= 128)
-                  and bool(lib.pvn3d_mlp_split2_ok(*args)))
+                  and bool(lib.pvn3d_mlp_split2_ok(*args, _ext._mlp_flags())))
         split = not split2 and _fused_mlp.split_arith() and bool(lib.pvn3d_mlp_split_ok(*args))
         # FP levels 2-3: layer by layer on the split GEMM (csrc/split_gemm.hip).  flops_per_frame stays the
         # reference's formulation (conv over [interp; skip] on the unknown points); the launches execute fewer (the

@@ -75,6 +75,16 @@ int pvn3d_fps_nest_verify(int b, int n0, int n_levels, const int* m_levels, cons
 int pvn3d_fps_ws_words(int n);
 int pvn3d_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, void* ws, int* idxs,
                                      int* dmax_out, const int* nest_flags, int nest_level, void* stream);
+/* The same call with the number of waves that share a cloud's sampling rounds as a per-call argument (round 6).  The
+ * reference gives a cloud a 512-thread block (sampling_gpu.cu:175-185).  waves_per_cloud: 0 or 1 = one wave per cloud
+ * (what pvn3d_furthest_point_sampling_ws runs); >= 2, for 4096 < n <= 12288 = one wave per 64-point slot of the culled
+ * kernel's 64 cells (2 waves up to 8192 points, 3 above): every wave keeps the cells' cached maxima, updates its own slot of
+ * the touched cells and exchanges one (max, arg-max) entry per refreshed cell through LDS sequence words, no barrier.
+ * Indices are identical whatever the value; the multi-wave form measured 1.45 x SLOWER (csrc/fps_cells.hip) and
+ * is kept as an independently written cross-check. */
+int pvn3d_furthest_point_sampling_ws_waves(int b, int n, int m, const float* dataset, void* ws, int* idxs,
+                                           int* dmax_out, const int* nest_flags, int nest_level, int waves_per_cloud,
+                                           void* stream);
 
 /* replaces gather_points_kernel_wrapper, sampling_gpu.cu:22-29.
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
@@ -260,33 +270,44 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  * levels 0-1: 9 -> 16 -> 16 -> 32, 9 -> 32 -> 32 -> 64, 99 -> 64 -> 64 | 96 -> 128) run a kernel of their own behind
  * pvn3d_sa_mlp_maxpool_split2 (weights of the whole chain resident in LDS, one wave per 32 columns through all layers);
  * for c == 6 it reads the six-float feature rows in place, so features_pm / ld_feat need no 16-byte alignment there.
- * pvn3d_set_sa_narrow(0) switches it off process-wide (A/B measurements: SA level 1 then runs the 4 + 4 wave kernel, SA
- * level 0 is refused by pvn3d_mlp_split2_ok and stays on pvn3d_sa_mlp_maxpool); 1 = on, the default. */
-int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host);
-void pvn3d_set_sa_narrow(int on);
+ * Round 6, two more arguments on every *_split2 entry point:
+ *   out_row_mul   DEVICE float[ceil(M_last / 32) * 32] or NULL: per-output-channel multiplier applied to the results (after
+ *                 the ReLU, together with the chain's own power-of-two scale).  It lets the caller scale every ROW of a
+ *                 weight matrix into fp16's range on its own: the host side (PackedMLP.split2) rescales the network
+ *                 diagonally -- W~_l = D_l W_l D_(l-1)^-1, b~_l = D_l b_l with power-of-two diagonals chosen so that every
+ *                 hidden channel's bound is ~1 -- which is exact, keeps rows whose BatchNorm scale is orders of magnitude
+ *                 apart at full two-piece precision, and leaves D_L^-1 to be undone here.  out_absmax is taken on the
+ *                 multiplied values.
+ *   flags         0 or PVN3D_MLP_NO_NARROW: a PER-CALL switch that keeps the chain off the narrow-chain kernels (A/B
+ *                 measurements: SA level 1 then runs the 4 + 4 wave kernel, SA level 0 is refused by pvn3d_mlp_split2_ok
+ *                 and stays on pvn3d_sa_mlp_maxpool).  The library has no process-wide switch (no global mutable state). */
+#define PVN3D_MLP_NO_NARROW 1
+int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int flags);
 /* The FP chain in its pre-contracted form: the caller promises that the first c2 columns of layer 0's weights are the
  * identity (known_pm holds the first conv's interpolated half, already applied per KNOWN point: what
  * _ext.fp_interp_mlp does for FP level 0), i.e. layer 0 = relu(interp(known) + Wb.skip + b0).  Arguments and results as
  * pvn3d_fp_interp_mlp_split2, which computes the same thing by multiplying with that identity and is what this entry
  * point falls back to; for c2 = 128, c1 = 6, 128 -> 128, channel-major output (FP level 0 of the backbone) the
- * narrow-chain kernel adds the interpolated rows to the accumulators instead (pvn3d_set_sa_narrow switches it too). */
+ * narrow-chain kernel adds the interpolated rows to the accumulators instead (flags & PVN3D_MLP_NO_NARROW: not). */
 int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                    const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
                                    int n_layers, const int* dims_host, const void* const* w_split2,
                                    const float* const* bias_padded, const float* layer_meta,
                                    const float* known_absmax, const float* unknown_absmax, float* out,
-                                   int out_point_major, int ld_out, float* out_absmax, void* stream);
+                                   int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul, int flags,
+                                   void* stream);
 int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz, const float* new_xyz,
                                 const float* features_pm, int ld_feat, const int* idx, int n_layers,
                                 const int* dims_host, const void* const* w_split2, const float* const* bias_padded,
                                 const float* layer_meta, const float* features_absmax, const float* xyz_absmax,
-                                float* out_pm, int ld_out, int out_coff, float* out_absmax, void* stream);
+                                float* out_pm, int ld_out, int out_coff, float* out_absmax, const float* out_row_mul,
+                                int flags, void* stream);
 int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
                                int n_layers, const int* dims_host, const void* const* w_split2,
                                const float* const* bias_padded, const float* layer_meta, const float* known_absmax,
                                const float* unknown_absmax, float* out, int out_point_major, int ld_out,
-                               float* out_absmax, void* stream);
+                               float* out_absmax, const float* out_row_mul, int flags, void* stream);
 int pvn3d_absmax(long long rows, int c, const float* src, int ld_src, float* out_max, void* stream);
 
 /* Layer-by-layer split-bf16 SharedMLP for chains whose hidden layer is too wide for the fused kernel (FP levels 2-3 of
@@ -317,6 +338,10 @@ int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* x_s16, cons
  * pvn3d_bound_affine of such bounds); the same pointer must be passed where the matrix is written and where it is read.
  *   pvn3d_split_rows2: fp32 rows -> h16 (scale from *src_bound).
  *   pvn3d_split_gemm2: pvn3d_split_gemm on h16 operands; w_h16 holds w_scale * W (w_scale a power of two, host);
+ *       w_row_mul (round 6; DEVICE float[ceil(n_out / 128) * 128] or NULL): per-output-channel multiplier of the
+ *       accumulators, applied with 1 / (w_scale * x scale) BEFORE the interpolated rows and the bias are added -- so that
+ *       every ROW of W can carry its own power-of-two scale (w_h16 row o = w_scale * rs[o] * W[o], w_row_mul[o] = 1 / rs[o])
+ *       and a row whose BatchNorm scale is far below the matrix maximum keeps both fp16 pieces normal;
  *       out_absmax (optional): atomic max of |out_f32| -- set it to 0 before; out_bound: the bound the h16 output is
  *       written with (required with out_h16).  Three partial products per multiply on v_mfma_f32_32x32x16_f16.
  *   pvn3d_bound_affine: *out = 1.01 (ca * *a + cb * *b + c0) (b may be NULL): the rigorous bound |W x + ...| <=
@@ -324,9 +349,9 @@ int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* x_s16, cons
 int pvn3d_split_rows2(long long rows, int c, const float* src, int ld_src, const float* src_bound, void* dst_h16, int slabs,
                       void* stream);
 int pvn3d_split_gemm2(int n_points, int n_out, int slabs, const void* x_h16, const float* x_bound, const void* w_h16,
-                      float w_scale, const float* bias_padded, int relu, const float* z, int ldz, int z_points_per_frame,
-                      int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
-                      float* out_absmax, void* out_h16, int slabs_out, const float* out_bound, void* stream);
+                      float w_scale, const float* w_row_mul, const float* bias_padded, int relu, const float* z, int ldz,
+                      int z_points_per_frame, int z_rows_per_frame, const int* idx, const float* weight, float* out_f32,
+                      int ld_out, float* out_absmax, void* out_h16, int slabs_out, const float* out_bound, void* stream);
 int pvn3d_bound_affine(float* out, const float* a, float ca, const float* b, float cb, float c0, void* stream);
 
 /* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */

@@ -26,6 +26,7 @@ SIGNATURES = {
     "pvn3d_fps_nest_verify": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     "pvn3d_fps_ws_words": (_i, [_i]),
     "pvn3d_furthest_point_sampling_ws": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "pvn3d_furthest_point_sampling_ws_waves": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_gather_points": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
     "pvn3d_gather_points_grad": (_i, [_i, _i, _i, _i, _p, _p, _p, _p]),
     "pvn3d_ball_query": (_i, [_i, _i, _i, _f, _i, _p, _p, _p, _p]),
@@ -44,14 +45,13 @@ SIGNATURES = {
     "pvn3d_mlp_split_ok": (_i, [_i, _i, _i, _i, _i, _p]),
     "pvn3d_sa_mlp_maxpool_split": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_fp_interp_mlp_split": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
-    "pvn3d_mlp_split2_ok": (_i, [_i, _i, _i, _i, _i, _p]),
-    "pvn3d_set_sa_narrow": (None, [_i]),
-    "pvn3d_sa_mlp_maxpool_split2": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
-    "pvn3d_fp_interp_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
-    "pvn3d_fp_interp_add_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "pvn3d_mlp_split2_ok": (_i, [_i, _i, _i, _i, _i, _p, _i]),
+    "pvn3d_sa_mlp_maxpool_split2": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "pvn3d_fp_interp_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "pvn3d_fp_interp_add_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "pvn3d_absmax": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p]),
     "pvn3d_split_rows2": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p, _i, _p]),
-    "pvn3d_split_gemm2": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
+    "pvn3d_split_gemm2": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
     "pvn3d_bound_affine": (_i, [_p, _p, _f, _p, _f, _f, _p]),
     "pvn3d_split_rows": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _i, _p]),
     "pvn3d_split_gemm": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p]),

@@ -125,15 +125,41 @@ constexpr int MI_SLABLO = 48;    // [8]  float: level-2 origin per slab
 constexpr int MI_SLABSC = 56;    // [8]  float: level-2 scale per slab
 constexpr int MI_CBOX = 64;      // [64][6] floats: cell boxes
 
+// One cloud after the build phase: where its arrays live, the slab boundaries (ranks along the widest axis).
 template <int SPC>
-__global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int Q,
-                                                        const float* __restrict__ dataset,
-                                                        int* __restrict__ ws, int* __restrict__ idxs,
-                                                        int* __restrict__ dmax) {
+struct FcCloud {
+  float *X, *Y, *T, *Zl, *Zg;      // by position (cell * CELL + q); Zl: LDS (SPC < 3), Zg: workspace
+  int *hist, *misc, *sorted_k;     // aux region of LDS (histogram | misc), point index by rank (workspace)
+  float* miscf;
+  int bnd[9];
+  // cell (s, t): ranks [bnd[s] + t*len/8, bnd[s] + (t+1)*len/8), positions cell*CELL + [0, cnt)
+  __device__ __forceinline__ int cell_start(int c) const {
+    const int s = c >> 3, t = c & 7;
+    int b0 = 0, b1 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
+    return b0 + ((t * (b1 - b0)) >> 3);
+  }
+  __device__ __forceinline__ int cell_cnt(int c) const {
+    const int s = c >> 3, t = c & 7;
+    int b0 = 0, b1 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
+    const int sl = b1 - b0;
+    return (((t + 1) * sl) >> 3) - ((t * sl) >> 3);
+  }
+};
+
+// Build phase, all 256 threads of the workgroup (ends with a barrier): the cloud cut into 64 equal-count cells; x, y and the
+// running minima by position in LDS, z in LDS or in the workspace, the point index by rank in the workspace, the cell
+// boxes in the misc region.  `dataset` / `ws` already point at this workgroup's cloud.  xinit: words at the start of the
+// histogram region that are set to `xinit_val` before the last barrier (the multi-wave rounds' exchange area).
+template <int SPC>
+__device__ __forceinline__ void fc_build(FcCloud<SPC>& cl, int n, const float* __restrict__ dataset, int* __restrict__ ws,
+                                         float* s_dyn, int xinit, int xinit_val) {
   constexpr int CELL = SPC * 64;      // positions per cell
   constexpr int NPOS = 64 * CELL;     // positions in LDS
   constexpr int PPT = 16 * SPC;       // points per thread during the build
-  extern __shared__ float s_dyn[];
   float* const X = s_dyn;          // x, y by position (cell * CELL + q)
   float* const Y = X + NPOS;
   float* const T = Y + NPOS;       // running minimum distance ("temp" of the reference) by position
@@ -148,14 +174,10 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
   float* const miscf = reinterpret_cast<float*>(misc);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  dataset += (size_t)blockIdx.x * n * 3;
   // workspace of the cloud: z by position (NPOS floats; LDS holds x, y and temp), then the point index by
   // rank (n ints; rank = position with the pads of the cells squeezed out)
-  ws += (size_t)blockIdx.x * (NPOS + n);
   float* const Zg = reinterpret_cast<float*>(ws);
   int* const sorted_k = ws + NPOS;
-  idxs += (size_t)blockIdx.x * m;
-  if (dmax) dmax += (size_t)blockIdx.x * m;
 
   // ------------------------------------------------------------------ build: points in registers
   float px[PPT], py[PPT], pz[PPT];
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     sc1 = e[a1] > 0.f ? (float)FC_BINS1 / e[a1] : 0.f;
   }
   // slab boundaries (ranks along a1): slab s = [s*n/8, (s+1)*n/8)
-  int bnd[9];
+  int (&bnd)[9] = cl.bnd;
 #pragma unroll
   for (int s = 0; s <= 8; ++s) bnd[s] = (int)(((long long)s * n) >> 3);
 
@@ -308,26 +330,13 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     }
   }
   __syncthreads();
-  // cell (s, t): ranks [bnd[s] + t*len/8, bnd[s] + (t+1)*len/8), positions cell*CELL + [0, cnt)
-  auto cell_start = [&](int c) {
-    const int s = c >> 3, t = c & 7;
-    int b0 = 0, b1 = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
-    return b0 + ((t * (b1 - b0)) >> 3);
-  };
-  auto cell_cnt = [&](int c) {
-    const int s = c >> 3, t = c & 7;
-    int b0 = 0, b1 = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { if (s == q) { b0 = bnd[q]; b1 = bnd[q + 1]; } }
-    const int sl = b1 - b0;
-    return (((t + 1) * sl) >> 3) - ((t * sl) >> 3);
-  };
+  cl.X = X; cl.Y = Y; cl.T = T; cl.Zl = Zl; cl.Zg = Zg;
+  cl.hist = hist; cl.misc = misc; cl.miscf = miscf; cl.sorted_k = sorted_k;
+  for (int i = tid; i < xinit; i += 256) hist[i] = xinit_val;      // (the histogram is dead from here on)
   // cell boxes: wave w reduces cells w*16 .. w*16+15
   for (int cc = 0; cc < 16; ++cc) {
     const int c = wave * 16 + cc;
-    const int cnt = cell_cnt(c);
+    const int cnt = cl.cell_cnt(c);
     float bl[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
     float bh[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
@@ -354,7 +363,33 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     }
   }
   __syncthreads();
+}
+
+template <int SPC>
+__global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int Q,
+                                                        const float* __restrict__ dataset,
+                                                        int* __restrict__ ws, int* __restrict__ idxs,
+                                                        int* __restrict__ dmax) {
+  constexpr int CELL = SPC * 64;      // positions per cell
+  constexpr int NPOS = 64 * CELL;     // positions in LDS
+  constexpr bool Z_IN_LDS = SPC < 3;
+  extern __shared__ float s_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  dataset += (size_t)blockIdx.x * n * 3;
+  ws += (size_t)blockIdx.x * (NPOS + n);
+  idxs += (size_t)blockIdx.x * m;
+  if (dmax) dmax += (size_t)blockIdx.x * m;
+  FcCloud<SPC> cl;
+  fc_build<SPC>(cl, n, dataset, ws, s_dyn, 0, 0);
   if (wave != 0) return;
+  float* const X = cl.X;
+  float* const Y = cl.Y;
+  float* const T = cl.T;
+  float* const Zl = cl.Zl;
+  float* const Zg = cl.Zg;
+  const float* const miscf = cl.miscf;
+  const int* const sorted_k = cl.sorted_k;
+  auto cell_start = [&](int c) { return cl.cell_start(c); };
 
   // ------------------------------------------------------------------ the serial rounds: wave 0 alone
   // A wave that runs alone on its SIMD issues one instruction every 5 cycles at best and every 8 when it
@@ -543,7 +578,9 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
     unsigned long long mask = __ballot(lb <= __int_as_float(cmax));
     unsigned long long fullm = __ballot(dw < __int_as_float(cmax));
     // the own cell is handled apart (cw = -1 clears bit 63: only when no cell is touched, or before `force`)
-    asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(cw));
+    // (readfirstlane: the inline-asm "s" operands below do not stop the compiler from keeping the wave-uniform cw in a VGPR)
+    const int cws = __builtin_amdgcn_readfirstlane(cw);
+    asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(cws));
     mask |= force;
     fullm = (fullm | force) & mask;
     force = 0;
@@ -560,10 +597,10 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
       }
     }
     // the sample's own cell: its data was requested as soon as the arg-max of the previous round was known
-    if (__builtin_expect(cw >= 0, 1)) {
+    if (__builtin_expect(cws >= 0, 1)) {
       int vi[SPC];
-      update_cell(cw, ra, vi);
-      refresh_cell(cw, ra, vi);
+      update_cell(cws, ra, vi);
+      refresh_cell(cws, ra, vi);
     }
     if (c1 >= 0) {
       int vi[SPC];
@@ -620,6 +657,342 @@ __global__ __launch_bounds__(256) void fps_cells_kernel(int n, int m, int L, int
   if (m == 1 && lane == 0) idxs[0] = 0;
 }
 
+// ======================================================================================================================
+// Multi-wave rounds (4096 < n <= 12288): SPC waves per cloud on SPC SIMDs of one CU, wave w owns SLOT w -- positions
+// 64 w .. 64 w + 63 -- of EVERY cell.  (sampling_gpu.cu:69-173 gives a cloud a 512-thread block; the one-wave kernel
+// above spends ~250 dependent-issue slots per round, most of them on the three slots of the touched cells.)
+//   * every wave keeps the complete per-cell caches (max, arg-max position and coordinates: lane = cell) and runs the cull
+//     test and the arg-max over the cells redundantly -- same inputs, same instructions, same results: the next sample
+//     needs no exchange;
+//   * a touched cell costs a wave one slot instead of three; a cell whose cache must be refreshed (the sample's own cell
+//     and the cells whose cached arg-max the sample lowers: 1.3 per round) is reduced over the wave's 64 points, the lane
+//     holding the wave's maximum writes a 20-byte entry (max, position, coordinates) into an LDS exchange area, the wave
+//     raises its sequence word, and -- after updating the cells that need no refresh, which covers the round trip -- reads
+//     the other waves' entries: the cell's new cache is the largest entry;
+//   * no barrier: sequence words are monotone counters in LDS, polled with one ds_read_b128; the LDS executes a wave's
+//     instructions in order, so an entry written before the counter is visible to whoever has seen the counter.  Entries
+//     are double-buffered by exchange parity (a wave can be at most one exchange ahead of the slowest);
+//   * ties -- more than one wave, or more than one lane of the winning wave, at the maximum -- are resolved like in the
+//     one-wave kernel with the reference block's order (smallest fc_prio) through a second exchange of keys; every wave
+//     takes the same decisions from the same published words, so the waves never disagree on the sequence of exchanges.
+// Index-exact with the one-wave kernel by construction: the running minima are the same values in the same positions,
+// a cell's cache is the same (max, smallest-priority arg-max), the cross-cell arg-max is the same code.
+//
+// MEASURED (round 6, profiles/r06_fps_multiwave.txt): index-exact on every FPS test, and SLOWER than one wave -- 12288 ->
+// 2048: 2.21 ms (1.08 us per round) against 1.53 ms (0.75).  Cycles per round and wave (-DPVN3D_FC_PROF): cull test 315 +
+// arg-max over the cells 390-470 are the same work as in the one-wave kernel and stay serial; what the three waves share
+// (one slot instead of three per touched cell) is replaced by slot partials + publish 745, the LDS round trip 350-430
+// (no failed poll: that is ONE ds_read_b128 of the sequence words behind the wave's own queued LDS traffic) and the
+// combination of the entries into the caches 680 -- 2 040 cycles where the one-wave kernel spends ~1 090 on its three
+// slots.  A wave alone on its SIMD pays 8-16 cycles per instruction whatever the instruction does, so fewer points per
+// wave buy nothing and every exchange step is ~25 more instructions on the serial path.  The kernel stays selectable
+// (waves_per_cloud >= 2) as an independently written cross-check of the one-wave kernel; it is not the default.
+constexpr int FX_B = 8;                                   // refreshed cells per exchange
+constexpr int FX_SEQ = 0;                                 // [4] exchange counters, one per wave
+constexpr int FX_ENT = 16;                                // entries [2 parities][FX_B cells][4 waves][8 words]
+constexpr int FX_TIE = FX_ENT + 2 * FX_B * 4 * 8;         // tie entries [2 parities][4 waves][8 words]
+constexpr int FX_WORDS = FX_TIE + 2 * 4 * 8;
+constexpr int FX_NONE = (int)0x80000000;                  // initial value of every word: below every counter / entry
+
+// Tuning build only (-DPVN3D_FC_PROF, tools/build_probe_lib.sh, tools/fps_prof.py): cycles per phase of a round, summed
+// over the rounds, written by every wave over the first words of the cloud's workspace when the run is over.
+#ifdef PVN3D_FC_PROF
+#define FC_PROF_DECL unsigned fc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long fc_t = __builtin_readcyclecounter()
+#define FC_PROF(P)                                                  \
+  do {                                                              \
+    const unsigned long long t__ = __builtin_readcyclecounter();    \
+    fc_acc[P] += (unsigned)(t__ - fc_t);                            \
+    fc_t = t__;                                                     \
+  } while (0)
+#define FC_PROF_CNT(P, V) fc_acc[P] += (unsigned)(V)
+#else
+#define FC_PROF_DECL do { } while (0)
+#define FC_PROF(P) do { } while (0)
+#define FC_PROF_CNT(P, V) do { } while (0)
+#endif
+
+template <int SPC>
+__global__ __launch_bounds__(256) void fps_cells_mw_kernel(int n, int m, int L, int Q,
+                                                           const float* __restrict__ dataset,
+                                                           int* __restrict__ ws, int* __restrict__ idxs,
+                                                           int* __restrict__ dmax) {
+  static_assert(SPC == 2 || SPC == 3, "one wave per 64-point slot of a cell");
+  constexpr int CELL = SPC * 64;
+  constexpr int NPOS = 64 * CELL;
+  constexpr bool Z_IN_LDS = SPC < 3;
+  extern __shared__ float s_dyn[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  dataset += (size_t)blockIdx.x * n * 3;
+  ws += (size_t)blockIdx.x * (NPOS + n);
+  idxs += (size_t)blockIdx.x * m;
+  if (dmax) dmax += (size_t)blockIdx.x * m;
+  FcCloud<SPC> cl;
+  fc_build<SPC>(cl, n, dataset, ws, s_dyn, FX_WORDS, FX_NONE);
+  if (wave >= SPC) return;
+  float* const X = cl.X;
+  float* const Y = cl.Y;
+  float* const T = cl.T;
+  float* const Zl = cl.Zl;
+  float* const Zg = cl.Zg;
+  const float* const miscf = cl.miscf;
+  const int* const sorted_k = cl.sorted_k;
+  int* const xw = cl.hist;                        // the exchange area (the histogram is dead)
+  const int soff = wave * 64 + lane;              // this lane's position inside every cell
+
+  // lane c = cell c (every wave holds all of it)
+  const float lox = miscf[MI_CBOX + lane * 6 + 0], loy = miscf[MI_CBOX + lane * 6 + 1],
+              loz = miscf[MI_CBOX + lane * 6 + 2];
+  const float hix = miscf[MI_CBOX + lane * 6 + 3], hiy = miscf[MI_CBOX + lane * 6 + 4],
+              hiz = miscf[MI_CBOX + lane * 6 + 5];
+  const int cstart = cl.cell_start(lane);
+  int cmax = __float_as_int(1e10f);
+  int cq = 0;
+  float cwx = 0.f, cwy = 0.f, cwz = 0.f;
+
+  const float p0x = dataset[0], p0y = dataset[1], p0z = dataset[2];
+  float sx = p0x, sy = p0y, sz = p0z;
+  int res = -1, resd = 0;                         // wave 0 only
+  FC_PROF_DECL;
+
+  struct Slot { float x, y, z, t; };
+  auto load_slot = [&](int c, Slot& r) {
+    const int p = c * CELL + soff;
+    r.x = X[p];
+    r.y = Y[p];
+    r.t = T[p];
+    r.z = Z_IN_LDS ? Zl[p] : Zg[p];
+  };
+  // this wave's points of cell c against the current sample; returns the new running minimum's bit pattern
+  auto update_slot = [&](int c, const Slot& r) -> int {
+    const float dx = r.x - sx, dy = r.y - sy, dz = r.z - sz;
+    const float d = dx * dx + dy * dy + dz * dz;
+    float d2;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(r.t));       // (see update_cell above)
+    T[c * CELL + soff] = d2;
+    return __float_as_int(d2);
+  };
+
+  int xc = 0;          // exchanges published so far (every wave counts alike)
+  int nx = 0, tx = 0;  // ... of which batches of refreshed cells / tie resolutions: parity of the two entry areas
+  const unsigned seq_addr = (unsigned)(uintptr_t)(xw + FX_SEQ);
+  auto publish = [&]() {
+    ++xc;
+    asm volatile("" ::: "memory");                 // (entries first: the LDS executes this wave's writes in order)
+    if (lane == 0) __hip_atomic_store(&xw[FX_SEQ + wave], xc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto wait_all = [&]() {
+    // watchdog: a protocol error must end as a kernel fault, never as a hung GPU (the longest legitimate wait is another
+    // wave's share of a round, a few microseconds)
+    unsigned spins = 0;
+    for (;;) {
+      int4 s;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(s) : "v"(seq_addr) : "memory");
+      int mn = min(s.x, s.y);
+      if (SPC == 3) mn = min(mn, s.z);
+      if (__builtin_amdgcn_readfirstlane(mn) >= xc) break;
+      if (++spins > (1u << 22)) __builtin_trap();
+    }
+    FC_PROF_CNT(6, spins);
+  };
+  // the lane `wl` of this wave writes (key, q, coordinates of its point) as this wave's entry
+  auto put_entry = [&](int* e, int wl, int key, int q, const Slot& r) {
+    if (lane == wl) {
+      *reinterpret_cast<int4*>(e) = make_int4(key, q, __float_as_int(r.x), __float_as_int(r.y));
+      e[4] = __float_as_int(r.z);
+    }
+  };
+  // the four entries at `base` (unused waves: FX_NONE): largest key, whether it is unique, and its entry's words
+  auto get_entries = [&](const int* base, int& key, bool& unique, unsigned& winners, int& q, float& x, float& y, float& z,
+                         int4& mine) {
+    const int* e = base + (lane & 3) * 8;
+    mine = *reinterpret_cast<const int4*>(e);
+    const int zb = e[4];
+    int red = mine.x;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(red));
+    key = __builtin_amdgcn_readfirstlane(red);
+    winners = (unsigned)__ballot(mine.x == key) & 0xfu;
+    unique = (winners & (winners - 1u)) == 0u;
+    const int wl = __builtin_ctz(winners);
+    q = __builtin_amdgcn_readlane(mine.y, wl);
+    x = __int_as_float(__builtin_amdgcn_readlane(mine.z, wl));
+    y = __int_as_float(__builtin_amdgcn_readlane(mine.w, wl));
+    z = __int_as_float(__builtin_amdgcn_readlane(zb, wl));
+  };
+
+  int cw = -1;
+  unsigned long long force = ~0ull;
+  Slot ra, rb;
+  for (int j = 1; j < m; ++j) {
+    const int cws = __builtin_amdgcn_readfirstlane(cw);
+    load_slot(cws < 0 ? 0 : cws, ra);
+    // 1. cull test and "is the cached arg-max lowered" test, one lane per cell (as in the one-wave kernel)
+    const float ax = __builtin_fmaxf(__builtin_fmaxf(lox - sx, sx - hix), 0.f);
+    const float ay = __builtin_fmaxf(__builtin_fmaxf(loy - sy, sy - hiy), 0.f);
+    const float az = __builtin_fmaxf(__builtin_fmaxf(loz - sz, sz - hiz), 0.f);
+    const float lb = ax * ax + ay * ay + az * az;
+    const float ex = cwx - sx, ey = cwy - sy, ez = cwz - sz;
+    const float dw = ex * ex + ey * ey + ez * ez;
+    unsigned long long mask = __ballot(lb <= __int_as_float(cmax));
+    unsigned long long fullm = __ballot(dw < __int_as_float(cmax));
+    asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(cws));
+    mask |= force;
+    fullm = (fullm | force) & mask;
+    force = 0;
+    unsigned long long uset = mask & ~fullm;       // touched, cache unchanged: this wave's slot is updated, nothing else
+    unsigned long long rset = fullm;               // cache refreshed (+ the sample's own cell)
+    bool own = cws >= 0;
+    bool first = true;
+    FC_PROF(0);
+    do {
+      // 2. a batch of <= FX_B refreshed cells: update this wave's slot, publish the slot's (max, arg-max)
+      int* const ebase = xw + FX_ENT + ((nx + 1) & 1) * (FX_B * 4 * 8) + wave * 8;
+      unsigned long long blist = 0;
+      int nb = 0;
+      auto part = [&](int c, const Slot& r) {
+        const int vi = update_slot(c, r);
+        const int Mw = fc_wave_max_i32(vi);
+        const unsigned long long e = __ballot(vi == Mw);
+        const int wl = __builtin_ctzll(e);
+        const int tie = (Mw >= 0 && (e & (e - 1))) ? 256 : 0;
+        put_entry(ebase + nb * 32, wl, Mw, soff - lane + wl + tie, r);
+        blist |= (unsigned long long)c << (8 * nb);
+        ++nb;
+      };
+      if (own) {
+        part(cws, ra);
+        own = false;
+      }
+      while (rset && nb < FX_B) {
+        const int c = __builtin_ctzll(rset);
+        rset &= rset - 1;
+        load_slot(c, rb);
+        part(c, rb);
+      }
+      if (nb) {
+        ++nx;
+        publish();
+      }
+      FC_PROF(1);
+      // 3. (under the exchange's round trip) the touched cells whose cache stays
+      if (first) {
+        first = false;
+        while (uset) {
+          const int c = __builtin_ctzll(uset);
+          uset &= uset - 1;
+          load_slot(c, rb);
+          (void)update_slot(c, rb);
+        }
+      }
+      FC_PROF(2);
+      // 4. the cells' new caches from all waves' entries
+      if (nb) {
+        wait_all();
+        FC_PROF(3);
+        const int* const rbase = xw + FX_ENT + (nx & 1) * (FX_B * 4 * 8);
+        for (int b = 0; b < nb; ++b) {
+          const int c = (int)((blist >> (8 * b)) & 255u);
+          int M, q;
+          float wx, wy, wz;
+          bool unique;
+          unsigned winners;
+          int4 mine;
+          get_entries(rbase + b * 32, M, unique, winners, q, wx, wy, wz, mine);
+          const bool lane_tie = ((unsigned)__ballot((mine.y & 256) != 0) & winners) != 0u;
+          if (__builtin_expect(M >= 0 && (!unique || lane_tie), 0)) {
+            // equal maxima: the reference's order = smallest priority, over every wave's points at the maximum
+            const int cs = __builtin_amdgcn_readlane(cstart, c);
+            Slot r;
+            load_slot(c, r);
+            unsigned key = 0xffffffffu;
+            if (__float_as_int(r.t) == M) key = (fc_prio(sorted_k[cs + soff], L, Q) << 8) | (unsigned)soff;
+            const unsigned kmin = fc_wave_min_u32(key);
+            const int wl = __builtin_ctzll(__ballot(key == kmin));
+            ++tx;
+            put_entry(xw + FX_TIE + ((tx & 1) * 4 + wave) * 8, wl, kmin == 0xffffffffu ? FX_NONE + 1 : 0x7fffffff - (int)kmin,
+                      (int)(kmin & 255u), r);
+            publish();
+            wait_all();
+            int tk;
+            get_entries(xw + FX_TIE + (tx & 1) * 4 * 8, tk, unique, winners, q, wx, wy, wz, mine);
+          }
+          q &= 255;
+          if (M < 0) { q = 0; wx = 0.f; wy = 0.f; wz = 0.f; }
+          // (readfirstlane: a no-op for values the compiler already keeps in SGPRs, and the guarantee the "s" operands need)
+          M = __builtin_amdgcn_readfirstlane(M);
+          q = __builtin_amdgcn_readfirstlane(q);
+          wx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wx)));
+          wy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wy)));
+          wz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(wz)));
+          asm volatile(
+              "s_mov_b32 m0, %[c]\n\t"
+              "s_nop 1\n\t"
+              "v_writelane_b32 %[cmax], %[M], m0\n\t"
+              "v_writelane_b32 %[cq], %[q], m0\n\t"
+              "v_writelane_b32 %[cwx], %[wx], m0\n\t"
+              "v_writelane_b32 %[cwy], %[wy], m0\n\t"
+              "v_writelane_b32 %[cwz], %[wz], m0"
+              : [cmax] "+v"(cmax), [cq] "+v"(cq), [cwx] "+v"(cwx), [cwy] "+v"(cwy), [cwz] "+v"(cwz)
+              : [M] "s"(M), [q] "s"(q), [wx] "s"(wx), [wy] "s"(wy), [wz] "s"(wz), [c] "s"(c)
+              : "m0");
+        }
+      }
+      FC_PROF(4);
+    } while (rset);
+    // 5. arg-max over the cells (every wave, identically)
+    const int G = fc_wave_max_i32(cmax);
+    int wrank;
+    if (__builtin_expect(G < 0, 0)) {
+      wrank = -1;
+      cw = -1;
+      sx = p0x; sy = p0y; sz = p0z;
+    } else {
+      const unsigned long long g = __ballot(cmax == G);
+      cw = __builtin_ctzll(g);
+      if (__builtin_expect((g & (g - 1)) != 0, 0)) {
+        unsigned key = 0xffffffffu;
+        if (cmax == G) key = (fc_prio(sorted_k[cstart + cq], L, Q) << 6) | (unsigned)lane;
+        key = fc_wave_min_u32(key);
+        cw = (int)(key & 63u);
+      }
+      wrank = __builtin_amdgcn_readlane(cstart, cw) + __builtin_amdgcn_readlane(cq, cw);
+      sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwx), cw));
+      sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwy), cw));
+      sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cwz), cw));
+    }
+    // 6. results: wave 0, 64 rounds per coalesced store
+    if (wave == 0) {
+      const int jl = j & 63;
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 1\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                   : "+v"(res), "+v"(resd) : "s"(wrank), "s"(G), "s"(jl) : "m0");
+      if ((j & 63) == 63 || j == m - 1) {
+        const int jj = (j & ~63) + lane;
+        if (jj <= j) {
+          idxs[jj] = res < 0 ? 0 : sorted_k[res];
+          if (dmax && jj >= 1) dmax[jj] = resd;
+        }
+      }
+    }
+    FC_PROF(5);
+  }
+  if (m == 1 && wave == 0 && lane == 0) idxs[0] = 0;
+#ifdef PVN3D_FC_PROF
+  if (lane < 8) {
+    unsigned v = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v = lane == p ? fc_acc[p] : v;
+    reinterpret_cast<unsigned*>(ws)[wave * 8 + lane] = v;
+  }
+#endif
+}
+
 }  // namespace
 
 // Workspace words (4 bytes each) per cloud for n points; 0 = this size is not served by the cell kernel.
@@ -631,11 +1004,27 @@ int pvn3d_fps_cells_ws_words(int n) {
 
 // b clouds of n points (64 < n <= 12288), ws = b * pvn3d_fps_cells_ws_words(n) words.  Returns -1 when the
 // shape is not served.
+// waves: 0 / 1 = the one-wave kernel (the default: faster, see the multi-wave kernel's header); >= 2 = one wave per
+// 64-point slot of a cell (n > 4096: 2 or 3 waves).
 int pvn3d_fps_cells_launch(int b, int n, int m, int L, int Q, const float* dataset, int* ws, int* idxs,
-                           int* dmax, hipStream_t st) {
+                           int* dmax, int waves, hipStream_t st) {
   if (n <= 64 || n > 12288 || !ws) return -1;
   const int spc = (n + 4095) / 4096;
   const size_t lds = (size_t)((spc < 3 ? 4 : 3) * 64 * spc * 64 + FC_AUX_INTS) * sizeof(float);
+  static_assert(FX_WORDS <= FC_BINS1, "the exchange area lives in the histogram region");
+  if (waves >= 2 && spc >= 2) {
+#define FC_LAUNCH_MW(SPC)                                                                      \
+  do {                                                                                         \
+    auto kern = fps_cells_mw_kernel<SPC>;                                                      \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(kern));                                \
+    hipLaunchKernelGGL(kern, dim3(b), dim3(256), lds, st, n, m, L, Q, dataset, ws, idxs, dmax); \
+  } while (0)
+    if (spc == 2) FC_LAUNCH_MW(2);
+    else FC_LAUNCH_MW(3);
+#undef FC_LAUNCH_MW
+    PVN3D_LAUNCH_CHECK();
+    return 0;
+  }
 #define FC_LAUNCH(SPC)                                                                         \
   do {                                                                                         \
     auto kern = fps_cells_kernel<SPC>;                                                         \

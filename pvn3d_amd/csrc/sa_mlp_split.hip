@@ -94,6 +94,8 @@ struct S3Args {
   float sw[S3_MAX_LAYERS], wnorm[S3_MAX_LAYERS], bmax[S3_MAX_LAYERS];
   const float* bound_a; const float* bound_b; float mul_b;
   unsigned* out_absmax;                         // device or nullptr: atomic max of |output| (bit pattern) for the consumer
+  const float* out_row_mul;                     // device [ceil(M_last / 32) * 32] or nullptr: per-output-channel multiplier of the results
+  int no_narrow;                                // per-call: keep the chain off the narrow-chain kernels (A/B measurements)
   int dbg;                                      // tuning builds only (-DPVN3D_S3_TUNING, env PVN3D_S3_DBG): 1 no gathers, 2 no index loads, 64 cycle stamps of workgroup 0
 };
 
@@ -181,6 +183,10 @@ __device__ __forceinline__ S3Scales s3_scales(const S3Args& a) {
   S3Scales sc;
   float B = a.bound_a ? *a.bound_a : 1.f;
   if (a.bound_b) B = fmaxf(B, a.mul_b * *a.bound_b);
+  // (an all-zero input table has bound 0: with the 1e-30 floor of s3_pow2_scale the scale products sw * s_in reached inf and
+  // bias * inf = NaN for the zero pad entries; 2^-60 keeps every product finite -- s_in <= 2^74, sw <= 2^40 -- and changes
+  // nothing for a table whose bound is a real value)
+  B = fmaxf(B, 8.67e-19f);
 #pragma unroll
   for (int l = 0; l < S3_MAX_LAYERS; ++l) {
     if (l < a.n_layers) {
@@ -408,6 +414,7 @@ struct S3Consumer {
   char* P;
   char* ring;
   const float* s_bias;
+  const float* s_om;       // per row of the last layer: accumulator -> output
   S3Ctl* ctl;
   S3Scales sc;             // fp16 x 2: power-of-two scales (all 1 for bf16 x 3)
   float amax;              // running max |output| of this lane (out_absmax)
@@ -655,7 +662,6 @@ struct S3Consumer {
   __device__ __forceinline__ void pool_dpp_t(const f32x16 (&acc)[2], int mt, int bi, int col0, int lane) {
     const int half = lane >> 5, col = lane & 31;
     const int M = a.M[NL - 1];
-    const float om = AR == 1 ? sc.next_mul[NL - 1] : 1.f;        // accumulator -> output (exact power of two)
     const bool writer = NS == 16 ? (lane & 15) == 15 : (lane & 31) == 31;
 #pragma unroll
     for (int ct = 0; ct < (NS == 64 ? 1 : 2); ++ct) {
@@ -682,13 +688,15 @@ struct S3Consumer {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = mt * 32 + 8 * g + 4 * half;
+          const float4 om = *reinterpret_cast<const float4*>(s_om + row);      // accumulator -> output, per row
+          const float w[4] = {v[4 * g] * om.x, v[4 * g + 1] * om.y, v[4 * g + 2] * om.z, v[4 * g + 3] * om.w};
           if (row + 3 < M) {
-            *reinterpret_cast<float4*>(o + 8 * g) = make_float4(v[4 * g] * om, v[4 * g + 1] * om, v[4 * g + 2] * om, v[4 * g + 3] * om);
-            amax = fmaxf(amax, fmaxf(fmaxf(v[4 * g], v[4 * g + 1]), fmaxf(v[4 * g + 2], v[4 * g + 3])) * om);   // (post-ReLU: >= 0)
+            *reinterpret_cast<float4*>(o + 8 * g) = make_float4(w[0], w[1], w[2], w[3]);
+            amax = fmaxf(amax, fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])));   // (post-ReLU: >= 0)
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (row + k < M) { o[8 * g + k] = v[4 * g + k] * om; amax = fmaxf(amax, v[4 * g + k] * om); }
+              if (row + k < M) { o[8 * g + k] = w[k]; amax = fmaxf(amax, w[k]); }
           }
         }
       }
@@ -771,7 +779,6 @@ struct S3Consumer {
     // ---- epilogue on the last layer's accumulators (rows wave + 4 t, both column tiles)
     const int lane = fresh_lane();
     const int half = lane >> 5, col = lane & 31;
-    const float om = AR == 1 ? sc.next_mul[NL - 1] : 1.f;          // accumulator -> output (exact power of two)
     if (IS_SA) {
       // max over the nsample columns of each centre through a wave-private [32][S3_EPAD] patch in P (see sa_mlp.hip;
       // measured against the DPP form of the multi-round kernels: 4.0k vs 7.6k cycles for two tiles)
@@ -813,6 +820,7 @@ struct S3Consumer {
           if (ns >= 32) v[0] = max(v[0], v[1]);
           if (ns >= 64) v[0] = max(v[0], __shfl_xor(v[0], 32, 64));
           const int row = mt * 32 + col;
+          const float om = s_om[row];                    // accumulator -> output of this row
           if (row < M && (ns < 64 || half == 0)) {
             float* o = out + ((size_t)bi * a.m + jbase) * a.ld_out + a.coff + row;
             if (nout <= 2) {
@@ -835,9 +843,12 @@ struct S3Consumer {
           for (int g = 0; g < 4; ++g) {
             const int row = mt * 32 + 8 * g + 4 * half;
             const int g0 = col0 + col, g1 = col0 + 32 + col;
+            const float4 om4 = *reinterpret_cast<const float4*>(s_om + row);     // accumulator -> output, per row
+            const float omk[4] = {om4.x, om4.y, om4.z, om4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (row + k < M) {
+                const float om = omk[k];
                 const float v0 = fmaxf(acc[t][0][4 * g + k], 0.f) * om, v1 = fmaxf(acc[t][1][4 * g + k], 0.f) * om;
                 if (g0 < a.cols_total) amax = fmaxf(amax, v0);
                 if (g1 < a.cols_total) amax = fmaxf(amax, v1);
@@ -890,6 +901,16 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
         off += mp;
       }
     }
+    // accumulator -> output of the last layer, per row: the chain's own (exact power-of-two) scale times the caller's
+    // per-channel multiplier (the row scales it folded into the last layer's weights and bias)
+    const int lastl = a.n_layers - 1;
+    const int mpl = ((a.M[lastl] + 31) >> 5) << 5;
+    float om = 1.f;
+    if (AR == 1) {
+#pragma unroll
+      for (int l = 0; l < S3_MAX_LAYERS; ++l) om = l == lastl ? sc.next_mul[l] : om;      // (constant indices: registers)
+    }
+    for (int i = tid; i < mpl; i += S3_THREADS) s_bias[a.bias_all + i] = a.out_row_mul ? a.out_row_mul[i] * om : om;
   }
   __syncthreads();          // the only s_barrier: from here on the two roles only meet through LDS words
 
@@ -924,7 +945,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, &ctl, sc, 0.f, lane, wave, 0u, 0u, 0};
+  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, s_bias + a.bias_all, &ctl, sc, 0.f, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -1075,6 +1096,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   constexpr int s1 = S1, s2 = S2;
   constexpr int w1_off = S0 * T0 * 2048, w2_off = w1_off + S1 * T1 * 2048;
   constexpr int bias_off = w2_off + S2 * T2 * 2048;
+  constexpr int om_off = bias_off + (T0 + T1 + T2) * 32 * 4;         // the last layer's per-row output multipliers
   const S3Scales sc = s3_scales(a);
   // ---- weights and biases -> LDS, once
   {
@@ -1106,6 +1128,9 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
       for (int i = tid; i < mp; i += NW_THREADS) s_bias[off + i] = a.bias[l][i] * bm;
       off += mp;
     }
+    // accumulator -> output, per row: the chain's (power-of-two) scale times the caller's per-channel multiplier
+    float* s_omw = reinterpret_cast<float*>(s_mem + om_off);
+    for (int i = tid; i < T2 * 32; i += NW_THREADS) s_omw[i] = a.out_row_mul ? a.out_row_mul[i] * sc.next_mul[2] : sc.next_mul[2];
   }
   __syncthreads();
   const char* w0 = s_mem + lane * 16;
@@ -1116,7 +1141,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
   const float* sb2 = s_bias + (T0 + T1) * 32;
   const int ns = a.ns;
   const float s0 = sc.s_in[0];
-  const float om = sc.next_mul[2];
+  const float* s_om = reinterpret_cast<const float*>(s_mem + om_off);
   float amax = 0.f;
 
   // this lane's column of tile t: neighbour index, then the row segments of the gather
@@ -1260,6 +1285,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void sa_chain_narrow_kernel(S3Arg
       // max_c relu(y_c + b) on the bit patterns: signed-integer max orders the non-negative floats correctly and ranks
       // every negative one below them, and the 0 in the chain is the relu (v_max3_i32: 8 per half tile pair)
       const float b = sb2[32 * t + col];
+      const float om = s_om[32 * t + col];                         // this lane's output channel
       int k[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) k[r] = __float_as_int(acc2[t][r] + b);
@@ -1324,6 +1350,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   constexpr int w1_off = T * 2048, bias_off = w1_off + S1 * T * 2048;
+  constexpr int om_off = bias_off + 2 * 32 * T * 4;                  // the last layer's per-row output multipliers
   const S3Scales sc = s3_scales(a);
   {   // the skip slab of layer 0 (the slab behind the identity block), layer 1 with its K permuted, biases in the accumulators' scale
     const uint4* src = a.W[0] + (size_t)(S1 * T) * 128;
@@ -1341,6 +1368,7 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
     for (int i = tid; i < 32 * T; i += NW_THREADS) {
       sb[i] = a.bias[0][i] * sc.bias_mul[0];
       sb[32 * T + i] = a.bias[1][i] * sc.bias_mul[1];
+      sb[64 * T + i] = a.out_row_mul ? a.out_row_mul[i] * sc.next_mul[1] : sc.next_mul[1];
     }
   }
   __syncthreads();
@@ -1348,7 +1376,8 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
   const char* w1 = s_mem + w1_off + lane * 16;
   const float* sb0 = reinterpret_cast<const float*>(s_mem + bias_off);
   const float* sb1 = sb0 + 32 * T;
-  const float bm0 = sc.bias_mul[0], s0 = sc.s_in[0], om = sc.next_mul[1];
+  const float bm0 = sc.bias_mul[0], s0 = sc.s_in[0];
+  const float* s_om = reinterpret_cast<const float*>(s_mem + om_off);
   const int n = a.cols_total, M1 = a.M[1];
   float amax = 0.f;
 
@@ -1453,9 +1482,11 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          const float4 om4 = *reinterpret_cast<const float4*>(s_om + 32 * t + 8 * j + 4 * half);    // per output channel
+          const float omk[4] = {om4.x, om4.y, om4.z, om4.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float v = s3_relu(acc1[t][4 * j + i]) * om;
+            const float v = s3_relu(acc1[t][4 * j + i]) * omk[i];
             *reinterpret_cast<float*>(const_cast<char*>(rowp) + voff) = v;
             amax = fmaxf(amax, v);
             rowp += step;
@@ -1482,12 +1513,10 @@ __global__ __launch_bounds__(NW_THREADS, MINW) void fp_chain_narrow_kernel(S3Arg
   }
 }
 
-// process-wide A/B switch of the narrow-chain kernel (pvn3d_set_sa_narrow; tools/s3_time.py)
-int g_nw_enabled = 1;
-
-// 1..4: instance that takes the chain; -1: none.  c = feature channels (dims[0] = c + 3)
-int nw_signature(int c, int nsample, int n_layers, const int* dims) {
-  if (!g_nw_enabled || n_layers != 3 || (nsample != 16 && nsample != 32) || c < 0 || dims[0] != c + 3) return -1;
+// 1..4: instance that takes the chain; -1: none.  c = feature channels (dims[0] = c + 3); no_narrow: the caller's per-call
+// PVN3D_MLP_NO_NARROW flag (A/B measurements -- there is no process-wide switch: the library keeps no mutable state)
+int nw_signature(int c, int nsample, int n_layers, const int* dims, int no_narrow) {
+  if (no_narrow || n_layers != 3 || (nsample != 16 && nsample != 32) || c < 0 || dims[0] != c + 3) return -1;
   for (int l = 1; l <= 3; ++l)
     if (dims[l] <= 0 || dims[l] > 128) return -1;
   const int s1 = (dims[1] + 15) / 16, s2 = (dims[2] + 15) / 16, t2 = (dims[3] + 31) / 32;
@@ -1503,7 +1532,7 @@ int nw_signature(int c, int nsample, int n_layers, const int* dims) {
 int nw_launch(S3Args& a, int sig, hipStream_t st) {
   const int t[3] = {(a.M[0] + 31) / 32, (a.M[1] + 31) / 32, (a.M[2] + 31) / 32};
   const int s0 = (a.K[0] + 15) / 16, s1 = (a.M[0] + 15) / 16, s2 = (a.M[1] + 15) / 16;
-  const size_t lds = (size_t)(s0 * t[0] + s1 * t[1] + s2 * t[2]) * 2048 + (size_t)(t[0] + t[1] + t[2]) * 32 * 4;
+  const size_t lds = (size_t)(s0 * t[0] + s1 * t[1] + s2 * t[2]) * 2048 + (size_t)(t[0] + t[1] + 2 * t[2]) * 32 * 4;
   if (lds > 150 * 1024) return -1;
   const int tpf = pvn3d_ceil_div(a.cols_total, 32);
   const long long total = (long long)tpf * a.n_frames;
@@ -1532,13 +1561,13 @@ int nw_launch(S3Args& a, int sig, hipStream_t st) {
 }
 
 // the pre-contracted FP chain the narrow kernel takes: M0 = M1 = 128, six skip channels, channel-major output
-bool nwfp_ok(int c2, int c1, int n_layers, const int* dims, int out_point_major) {
-  return g_nw_enabled && n_layers == 2 && c2 == 128 && c1 == 6 && dims[0] == c2 + c1 && dims[1] == 128 && dims[2] == 128 &&
+bool nwfp_ok(int c2, int c1, int n_layers, const int* dims, int out_point_major, int no_narrow) {
+  return !no_narrow && n_layers == 2 && c2 == 128 && c1 == 6 && dims[0] == c2 + c1 && dims[1] == 128 && dims[2] == 128 &&
          !out_point_major;
 }
 int nwfp_launch(S3Args& a, hipStream_t st) {
   constexpr int T = 4;
-  const size_t lds = (size_t)(T + 2 * T * T) * 2048 + (size_t)2 * 32 * T * 4;
+  const size_t lds = (size_t)(T + 2 * T * T) * 2048 + (size_t)3 * 32 * T * 4;
   const int tpf = pvn3d_ceil_div(a.cols_total, 32);
   const long long total = (long long)tpf * a.n_frames;
   if (total > 0x7fffffff) return -1;
@@ -1588,7 +1617,8 @@ bool s3_plan(S3Args& a, int arith = 0) {
   size_t p_bytes = (size_t)s3_np(arith) * a.ps;
   if (a.is_sa) p_bytes = max(p_bytes, (size_t)S3_NWC * 32 * S3_EPAD * 4);
   const size_t ring_bytes = (size_t)S3_RING * s3_chunk(arith);
-  const size_t bias_bytes = (size_t)bias_all * 4;
+  // biases of every layer + the last layer's per-row output multipliers
+  const size_t bias_bytes = (size_t)(bias_all + ((a.M[a.n_layers - 1] + 31) / 32) * 32) * 4;
   const size_t budget = 160 * 1024 - 256;
   if (p_bytes + ring_bytes + bias_bytes <= budget) {
     a.ring_off = (int)p_bytes;
@@ -1612,7 +1642,7 @@ int s3_launch(S3Args& a, int sig, hipStream_t st, int arith = 0) {
     a.dbg = e ? atoi(e) : 0;
   }
 #endif
-  const size_t lds = (size_t)a.bias_off + (size_t)a.bias_all * 4;
+  const size_t lds = (size_t)a.bias_off + (size_t)(a.bias_all + ((a.M[a.n_layers - 1] + 31) / 32) * 32) * 4;
   a.bpf = pvn3d_ceil_div(a.cols_total, S3_COLS);
   a.n_blocks = a.bpf * a.n_frames;
   // persistent grid: one workgroup per CU (the LDS footprint allows no more), a multiple of 8 so that a workgroup's
@@ -1673,9 +1703,9 @@ extern "C" int pvn3d_debug_s3_prof_read(unsigned long long* host256) {
 
 // 1: the split-bf16 family takes this shape; 0: use pvn3d_sa_mlp_maxpool / pvn3d_fp_interp_mlp (fp32 MFMA).
 // c_a: channels of the first row source (SA features / FP known points), c_b: FP skip channels.
-static int s3_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int arith) {
+static int s3_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int arith, int no_narrow = 0) {
   if (!dims_host || n_layers < 2 || n_layers > 3) return 0;
-  if (is_sa && arith == 1 && nw_signature(c_a, nsample, n_layers, dims_host) >= 0) return 1;      // narrow-chain kernel
+  if (is_sa && arith == 1 && nw_signature(c_a, nsample, n_layers, dims_host, no_narrow) >= 0) return 1;      // narrow-chain kernel
   if (c_a <= 0 || (c_a % S3_KC) != 0) return 0;                       // whole 32-channel row-gather chunks
   if (is_sa) {
     if (nsample <= 0 || (nsample & (nsample - 1)) || nsample > 64) return 0;
@@ -1693,8 +1723,8 @@ extern "C" int pvn3d_mlp_split_ok(int is_sa, int c_a, int c_b, int nsample, int 
   return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 0);
 }
 // the same question for the fp16 x 2 kernels (two pieces: smaller LDS footprint, one more chain signature)
-extern "C" int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host) {
-  return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 1);
+extern "C" int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int flags) {
+  return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 1, flags & PVN3D_MLP_NO_NARROW);
 }
 
 // fp16 x 2: per-layer (sw, ||W||_inf, max|b|) triples + the device-side input bounds -> S3Args; false when malformed
@@ -1714,20 +1744,22 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
                        const float* features_pm, int ld_feat, const int* idx, int n_layers, const int* dims_host,
                        const void* const* w_split, const float* const* bias_padded, const float* layer_meta,
                        const float* bound_a, const float* bound_b, float mul_b, float* out_pm, int ld_out, int out_coff,
-                       float* out_absmax, void* stream) {
+                       float* out_absmax, const float* out_row_mul, int flags, void* stream) {
   if (b <= 0 || m <= 0) return 0;
   if (!xyz || !new_xyz || !idx || !out_pm || !features_pm || !dims_host || !w_split || !bias_padded)
     return (int)hipErrorInvalidValue;
+  const int no_narrow = flags & PVN3D_MLP_NO_NARROW;
   // narrow chains (fp16 x 2): a kernel of their own; the six-feature instances (c == 6) take any row stride
-  const int nsig = arith == 1 ? nw_signature(c, nsample, n_layers, dims_host) : -1;
+  const int nsig = arith == 1 ? nw_signature(c, nsample, n_layers, dims_host, no_narrow) : -1;
   const bool narrow = nsig >= 0 && (nsig <= 2 || vec_ok(features_pm, ld_feat));
-  if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith) || dims_host[0] != c + 3 ||
+  if (!s3_ok(1, c, 0, nsample, n_layers, dims_host, arith, no_narrow) || dims_host[0] != c + 3 ||
       (!narrow && !vec_ok(features_pm, ld_feat)) || ld_feat < c || out_coff < 0 || ld_out < out_coff + dims_host[n_layers])
     return (int)hipErrorInvalidValue;
   S3Args a = {};
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
   if (arith == 1 && !s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, mul_b)) return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
+  a.out_row_mul = out_row_mul;
   a.is_sa = 1;
   a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
   a.idx = idx;
@@ -1745,33 +1777,32 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   const int rc = s3_launch(a, sig, (hipStream_t)stream, arith);
   return rc < 0 ? (int)hipErrorInvalidValue : rc;
 }
-// A/B switch of the narrow-chain kernel (1 = on, the default): with 0 the shapes it takes fall back to the 4 + 4 wave
-// kernels (SA level 1) or are refused by pvn3d_mlp_split2_ok (SA level 0: fp32-MFMA kernels of sa_mlp.hip)
-extern "C" void pvn3d_set_sa_narrow(int on) { g_nw_enabled = on ? 1 : 0; }
 extern "C" int pvn3d_sa_mlp_maxpool_split(int b, int n, int m, int c, int nsample, const float* xyz,
                                           const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
                                           int n_layers, const int* dims_host, const void* const* w_split,
                                           const float* const* bias_padded, float* out_pm, int ld_out, int out_coff,
                                           void* stream) {
   return s3_sa_entry(0, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split,
-                     bias_padded, nullptr, nullptr, nullptr, 0.f, out_pm, ld_out, out_coff, nullptr, stream);
+                     bias_padded, nullptr, nullptr, nullptr, 0.f, out_pm, ld_out, out_coff, nullptr, nullptr, 0, stream);
 }
 extern "C" int pvn3d_sa_mlp_maxpool_split2(int b, int n, int m, int c, int nsample, const float* xyz,
                                            const float* new_xyz, const float* features_pm, int ld_feat, const int* idx,
                                            int n_layers, const int* dims_host, const void* const* w_split2,
                                            const float* const* bias_padded, const float* layer_meta,
                                            const float* features_absmax, const float* xyz_absmax, float* out_pm,
-                                           int ld_out, int out_coff, float* out_absmax, void* stream) {
+                                           int ld_out, int out_coff, float* out_absmax, const float* out_row_mul,
+                                           int flags, void* stream) {
   // |p - c| <= 2 max|xyz| bounds the relative coordinates whatever the index list holds
   return s3_sa_entry(1, b, n, m, c, nsample, xyz, new_xyz, features_pm, ld_feat, idx, n_layers, dims_host, w_split2,
-                     bias_padded, layer_meta, features_absmax, xyz_absmax, 2.f, out_pm, ld_out, out_coff, out_absmax, stream);
+                     bias_padded, layer_meta, features_absmax, xyz_absmax, 2.f, out_pm, ld_out, out_coff, out_absmax,
+                     out_row_mul, flags, stream);
 }
 
 static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                        const float* unknown_pm, int ld_unknown, const int* idx, const float* weight, int n_layers,
                        const int* dims_host, const void* const* w_split, const float* const* bias_padded,
                        const float* layer_meta, const float* bound_a, const float* bound_b, float* out,
-                       int out_point_major, int ld_out, float* out_absmax, void* stream) {
+                       int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul, void* stream) {
   if (b <= 0 || n <= 0) return 0;
   if (!known_pm || !idx || !weight || !out || !dims_host || !w_split || !bias_padded || (c1 > 0 && !unknown_pm))
     return (int)hipErrorInvalidValue;
@@ -1784,6 +1815,7 @@ static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const flo
   if (arith == 1 && (!s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, 1.f) || (c1 > 0 && !bound_b)))
     return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
+  a.out_row_mul = out_row_mul;
   a.is_sa = 0;
   a.idx = idx; a.weight = weight;
   a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
@@ -1801,18 +1833,20 @@ extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, co
                                          const float* const* bias_padded, float* out, int out_point_major, int ld_out,
                                          void* stream) {
   return s3_fp_entry(0, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
-                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, nullptr, stream);
+                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, nullptr, nullptr, stream);
 }
 extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                           const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
                                           int n_layers, const int* dims_host, const void* const* w_split2,
                                           const float* const* bias_padded, const float* layer_meta,
                                           const float* known_absmax, const float* unknown_absmax, float* out,
-                                          int out_point_major, int ld_out, float* out_absmax, void* stream) {
+                                          int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul,
+                                          int flags, void* stream) {
+  (void)flags;             // (no narrow-chain kernel behind this entry point)
   // interpolation weights are non-negative and sum to 1: |interp(known)| <= max|known|
   return s3_fp_entry(1, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
                      w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, out_absmax,
-                     stream);
+                     out_row_mul, stream);
 }
 
 // The pre-contracted form (DESIGN 4.7b''): the caller promises that the first c2 columns of layer 0's weights are the
@@ -1824,15 +1858,18 @@ extern "C" int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c
                                               int n_layers, const int* dims_host, const void* const* w_split2,
                                               const float* const* bias_padded, const float* layer_meta,
                                               const float* known_absmax, const float* unknown_absmax, float* out,
-                                              int out_point_major, int ld_out, float* out_absmax, void* stream) {
+                                              int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul,
+                                              int flags, void* stream) {
   if (b > 0 && n > 0 && dims_host && known_pm && unknown_pm && idx && weight && out && w_split2 && bias_padded &&
-      nwfp_ok(c2, c1, n_layers, dims_host, out_point_major) && vec_ok(known_pm, ld_known) && ld_known >= c2 &&
+      nwfp_ok(c2, c1, n_layers, dims_host, out_point_major, flags & PVN3D_MLP_NO_NARROW) && vec_ok(known_pm, ld_known) &&
+      ld_known >= c2 &&
       ld_unknown >= c1 && unknown_absmax) {
     S3Args a = {};
     if (!s3_fill(&a, n_layers, dims_host, w_split2, bias_padded) ||
         !s3_fill_scales(&a, n_layers, layer_meta, known_absmax, unknown_absmax, 1.f))
       return (int)hipErrorInvalidValue;
     a.out_absmax = (unsigned*)out_absmax;
+    a.out_row_mul = out_row_mul;
     a.is_sa = 0;
     a.idx = idx; a.weight = weight;
     a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known;
@@ -1845,7 +1882,7 @@ extern "C" int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c
   }
   return pvn3d_fp_interp_mlp_split2(b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers,
                                     dims_host, w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out,
-                                    out_point_major, ld_out, out_absmax, stream);
+                                    out_point_major, ld_out, out_absmax, out_row_mul, flags, stream);
 }
 
 // max |x| over a point-major table [rows][ld] (channels [0, c)) -> *out (device float), as an atomic max on the bit

@@ -477,21 +477,21 @@ static void fps_block_shape(int n, int* L, int* Q) {
   *Q = (n + bs - 1) / bs;
 }
 
-// fps_cells.hip: one wave per cloud with exact spatial culling (64 < n <= 12288, needs a workspace)
+// fps_cells.hip: exact spatial culling, one to three waves per cloud (64 < n <= 12288, needs a workspace)
 int pvn3d_fps_cells_ws_words(int n);
 int pvn3d_fps_cells_launch(int b, int n, int m, int L, int Q, const float* dataset, int* ws, int* idxs, int* dmax,
-                           hipStream_t st);
+                           int waves, hipStream_t st);
 // below this size the register-resident kernel (one round = a few hundred instructions) is at least as fast
 constexpr int FPS_CELLS_MIN_N = 4097;
 
 static int fps_launch(int b, int n, int m, const float* dataset, float* temp, int* cells_ws, int* idxs,
-                      const FpsNest& nz, hipStream_t st) {
+                      const FpsNest& nz, hipStream_t st, int waves = 0) {
   int L, Q;
   fps_block_shape(n, &L, &Q);
   const int slots = (1 << L) * Q;  // priority slots to cover (>= n)
   // the culled kernel runs whole runs only (no nest.first > 1 restart)
   if (cells_ws && !nz.nest && n >= FPS_CELLS_MIN_N && pvn3d_fps_cells_ws_words(n) > 0)
-    return pvn3d_fps_cells_launch(b, n, m, L, Q, dataset, cells_ws, idxs, nz.dmax, st);
+    return pvn3d_fps_cells_launch(b, n, m, L, Q, dataset, cells_ws, idxs, nz.dmax, waves, st);
   if (slots <= 64) return launch_fps_reg<64, 1>(b, n, m, L, Q, dataset, idxs, nz, st);
   if (slots <= 128) return launch_fps_reg<64, 2>(b, n, m, L, Q, dataset, idxs, nz, st);
   if (slots <= 256) return launch_fps_reg<64, 4>(b, n, m, L, Q, dataset, idxs, nz, st);
@@ -521,16 +521,25 @@ extern "C" int pvn3d_fps_ws_words(int n) {
   return w > 0 ? w : (n > 16384 ? n : 0);
 }
 
-extern "C" int pvn3d_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, void* ws, int* idxs,
-                                                int* dmax_out, const int* nest_flags, int nest_level,
-                                                void* stream) {
+static int fps_ws_entry(int b, int n, int m, const float* dataset, void* ws, int* idxs, int* dmax_out,
+                        const int* nest_flags, int nest_level, int waves, void* stream) {
   if (b <= 0 || m <= 0) return 0;
-  if (n <= 0 || !dataset || !idxs || nest_level < 0 || nest_level >= FPS_NEST_LEVELS)
+  if (n <= 0 || !dataset || !idxs || nest_level < 0 || nest_level >= FPS_NEST_LEVELS || waves < 0)
     return (int)hipErrorInvalidValue;
   if (pvn3d_fps_ws_words(n) > 0 && !ws) return (int)hipErrorInvalidValue;
   const bool cells = n >= FPS_CELLS_MIN_N && pvn3d_fps_cells_ws_words(n) > 0;
   return fps_launch(b, n, m, dataset, cells ? nullptr : (float*)ws, cells ? (int*)ws : nullptr, idxs,
-                    FpsNest{dmax_out, nest_flags, nest_level}, (hipStream_t)stream);
+                    FpsNest{dmax_out, nest_flags, nest_level}, (hipStream_t)stream, waves);
+}
+extern "C" int pvn3d_furthest_point_sampling_ws(int b, int n, int m, const float* dataset, void* ws, int* idxs,
+                                                int* dmax_out, const int* nest_flags, int nest_level,
+                                                void* stream) {
+  return fps_ws_entry(b, n, m, dataset, ws, idxs, dmax_out, nest_flags, nest_level, 0, stream);
+}
+extern "C" int pvn3d_furthest_point_sampling_ws_waves(int b, int n, int m, const float* dataset, void* ws, int* idxs,
+                                                      int* dmax_out, const int* nest_flags, int nest_level,
+                                                      int waves_per_cloud, void* stream) {
+  return fps_ws_entry(b, n, m, dataset, ws, idxs, dmax_out, nest_flags, nest_level, waves_per_cloud, stream);
 }
 
 extern "C" int pvn3d_furthest_point_sampling_nested(int b, int n, int m, const float* dataset, float* temp,

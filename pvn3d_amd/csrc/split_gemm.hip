@@ -65,6 +65,7 @@ struct SgArgs {
   // fp16 x 2 only
   const float* x_bound;        // device: bound on |X| (the scale X was written with)
   float w_scale;               // host: power-of-two scale of W
+  const float* w_row_mul;      // device [ceil(N/128)*128] or nullptr: per-output-channel multiplier of the accumulators
   const float* out_bound;      // device: bound on |out| for the h16 output (nullptr without out_s)
   unsigned* out_absmax;        // device or nullptr: atomic max of |out_f| (bit pattern), for the consumer's bound
 };
@@ -206,12 +207,27 @@ __global__ __launch_bounds__(256, 2) void sg_gemm_kernel(SgArgs a) {
   if (AR == 1) {
     // accumulators carry w_scale * s_x: undo (an exact power of two) before anything is added
     const float inv = 1.f / (a.w_scale * sg_pow2_scale(*a.x_bound));
+    if (a.w_row_mul) {
+      // ... and the caller's per-row weight scales with it (powers of two as well: still exact)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int g = 0; g < 4; ++g) {
+          const float4 rm = *reinterpret_cast<const float4*>(a.w_row_mul + c0 + wr * 64 + i * 32 + 8 * g + 4 * half);
+          const float m4[4] = {rm.x * inv, rm.y * inv, rm.z * inv, rm.w * inv};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] *= m4[e];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    }
     if (a.out_s) s_out = sg_pow2_scale(*a.out_bound);
   }
 #pragma unroll
@@ -388,14 +404,15 @@ extern "C" int pvn3d_bound_affine(float* out, const float* a, float ca, const fl
 static int sg_gemm_any(int ar, int n_points, int n_out, int slabs, const void* x, const void* w, const float* bias_padded,
                        int relu, const float* z, int ldz, int z_points_per_frame, int z_rows_per_frame, const int* idx,
                        const float* weight, float* out_f32, int ld_out, void* out_s, int slabs_out, const float* x_bound,
-                       float w_scale, const float* out_bound, float* out_absmax, void* stream) {
+                       float w_scale, const float* w_row_mul, const float* out_bound, float* out_absmax, void* stream) {
   if (n_points <= 0 || n_out <= 0) return 0;
   if (!x || !w || slabs <= 0 || (slabs & 1) || (!out_f32 && !out_s) || (out_f32 && ld_out < n_out) ||
       (out_s && (slabs_out <= 0 || 16 * slabs_out > pvn3d_ceil_div(n_out, SG_T) * SG_T)) ||
       (z && (!idx || !weight || (ldz & 3) || ldz < pvn3d_ceil_div(n_out, SG_T) * SG_T || z_points_per_frame <= 0 ||
              z_rows_per_frame <= 0 || ((uintptr_t)z & 15) != 0)) ||
       ((uintptr_t)x & 15) != 0 || ((uintptr_t)w & 15) != 0 || (out_f32 && (((uintptr_t)out_f32 & 15) != 0 || (ld_out & 3))) ||
-      (out_s && ((uintptr_t)out_s & 15) != 0) || (bias_padded && ((uintptr_t)bias_padded & 15) != 0))
+      (out_s && ((uintptr_t)out_s & 15) != 0) || (bias_padded && ((uintptr_t)bias_padded & 15) != 0) ||
+      (w_row_mul && ((uintptr_t)w_row_mul & 15) != 0))
     return (int)hipErrorInvalidValue;
   if (ar == 1) {
     int e = 0;
@@ -408,7 +425,8 @@ static int sg_gemm_any(int ar, int n_points, int n_out, int slabs, const void* x
   a.X = (const char*)x; a.W = (const char*)w; a.bias = bias_padded; a.relu = relu;
   a.Z = z; a.ldz = ldz; a.zn = z_points_per_frame; a.zm = z_rows_per_frame; a.idx = idx; a.wgt = weight;
   a.out_f = out_f32; a.ld_out = ld_out; a.out_s = (char*)out_s; a.S_out = slabs_out;
-  a.x_bound = x_bound; a.w_scale = w_scale; a.out_bound = out_bound; a.out_absmax = (unsigned*)out_absmax;
+  a.x_bound = x_bound; a.w_scale = w_scale; a.w_row_mul = w_row_mul; a.out_bound = out_bound;
+  a.out_absmax = (unsigned*)out_absmax;
   const dim3 grid(pvn3d_ceil_div(n_out, SG_T), pvn3d_ceil_div(n_points, SG_T));
   if (ar == 1) hipLaunchKernelGGL(sg_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(sg_gemm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -420,13 +438,14 @@ extern "C" int pvn3d_split_gemm(int n_points, int n_out, int slabs, const void* 
                                 int z_rows_per_frame, const int* idx, const float* weight, float* out_f32, int ld_out,
                                 void* out_s16, int slabs_out, void* stream) {
   return sg_gemm_any(0, n_points, n_out, slabs, x_s16, w_s16, bias_padded, relu, z, ldz, z_points_per_frame, z_rows_per_frame,
-                     idx, weight, out_f32, ld_out, out_s16, slabs_out, nullptr, 1.f, nullptr, nullptr, stream);
+                     idx, weight, out_f32, ld_out, out_s16, slabs_out, nullptr, 1.f, nullptr, nullptr, nullptr, stream);
 }
 extern "C" int pvn3d_split_gemm2(int n_points, int n_out, int slabs, const void* x_h16, const float* x_bound,
-                                 const void* w_h16, float w_scale, const float* bias_padded, int relu, const float* z,
-                                 int ldz, int z_points_per_frame, int z_rows_per_frame, const int* idx, const float* weight,
-                                 float* out_f32, int ld_out, float* out_absmax, void* out_h16, int slabs_out,
-                                 const float* out_bound, void* stream) {
+                                 const void* w_h16, float w_scale, const float* w_row_mul, const float* bias_padded,
+                                 int relu, const float* z, int ldz, int z_points_per_frame, int z_rows_per_frame,
+                                 const int* idx, const float* weight, float* out_f32, int ld_out, float* out_absmax,
+                                 void* out_h16, int slabs_out, const float* out_bound, void* stream) {
   return sg_gemm_any(1, n_points, n_out, slabs, x_h16, w_h16, bias_padded, relu, z, ldz, z_points_per_frame, z_rows_per_frame,
-                     idx, weight, out_f32, ld_out, out_h16, slabs_out, x_bound, w_scale, out_bound, out_absmax, stream);
+                     idx, weight, out_f32, ld_out, out_h16, slabs_out, x_bound, w_scale, w_row_mul, out_bound, out_absmax,
+                     stream);
 }

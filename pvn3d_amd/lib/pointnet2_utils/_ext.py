@@ -45,6 +45,10 @@ def _stream(t):
 # False: every size runs the register-resident kernel (one workgroup scans the whole cloud every round);
 # True: 4096 < N <= 12288 runs the spatially culled kernel (csrc/fps_cells.hip).  Same indices either way.
 FPS_CULLED = True
+# waves that share a cloud's sampling rounds in the culled kernel: 0 / 1 = one wave per cloud (the default, and the
+# faster form), >= 2 = one wave per 64-point slot of a cell (2-3 waves; measured 1.45 x slower, kept as an independently
+# written cross-check).  Read per call; same indices either way.
+FPS_WAVES = 0
 
 
 def _fps_ws(B, N, dev):
@@ -62,9 +66,9 @@ def furthest_point_sampling(points, nsamples):
     ws = _fps_ws(B, N, points.device)
     with on_device(points.device):
         if FPS_CULLED:
-            check(lib.pvn3d_furthest_point_sampling_ws(B, N, int(nsamples), points.data_ptr(),
-                                                       ws.data_ptr() if ws is not None else None,
-                                                       out.data_ptr(), None, None, 0, _stream(points)),
+            check(lib.pvn3d_furthest_point_sampling_ws_waves(B, N, int(nsamples), points.data_ptr(),
+                                                             ws.data_ptr() if ws is not None else None,
+                                                             out.data_ptr(), None, None, 0, int(FPS_WAVES), _stream(points)),
                   "furthest_point_sampling")
         else:
             check(lib.pvn3d_furthest_point_sampling(B, N, int(nsamples), points.data_ptr(),
@@ -94,10 +98,13 @@ def furthest_point_sampling_nested(points, nsamples, want_dmax=False, nest=None)
             raise RuntimeError("nest first_rounds must be (B, 3)")
     ws = _fps_ws(B, N, points.device)
     with on_device(points.device):
-        fn = lib.pvn3d_furthest_point_sampling_ws if FPS_CULLED else lib.pvn3d_furthest_point_sampling_nested
-        check(fn(B, N, int(nsamples), points.data_ptr(), ws.data_ptr() if ws is not None else None, out.data_ptr(),
-                 dmax.data_ptr() if dmax is not None else None, flags.data_ptr() if flags is not None else None,
-                 int(level), _stream(points)), "furthest_point_sampling_nested")
+        args = (B, N, int(nsamples), points.data_ptr(), ws.data_ptr() if ws is not None else None, out.data_ptr(),
+                dmax.data_ptr() if dmax is not None else None, flags.data_ptr() if flags is not None else None, int(level))
+        if FPS_CULLED:
+            check(lib.pvn3d_furthest_point_sampling_ws_waves(*args, int(FPS_WAVES), _stream(points)),
+                  "furthest_point_sampling_nested")
+        else:
+            check(lib.pvn3d_furthest_point_sampling_nested(*args, _stream(points)), "furthest_point_sampling_nested")
     return out, dmax
 
 
@@ -412,6 +419,14 @@ def _point_major(t):
 # fp16 x 2 also for chains whose first hidden layer is narrower than 128 channels (SA level 1 of the backbone); False keeps
 # those on the fp32-MFMA kernels (A/B switch)
 SPLIT2_NARROW = True
+# The narrow-chain kernels (csrc/sa_mlp_split.hip: SA levels 0-1, the pre-contracted FP level 0) behind the fp16 x 2 entry
+# points; False passes PVN3D_MLP_NO_NARROW with every call (A/B measurements -- a per-call flag of the C ABI, read here per
+# call; the library itself has no switch)
+NARROW_KERNELS = True
+
+
+def _mlp_flags():
+    return 0 if NARROW_KERNELS else 1          # PVN3D_MLP_NO_NARROW
 
 
 def table_absmax(base, rows, c, ld):
@@ -496,16 +511,19 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
     # (the narrow-chain kernel reads a six-feature table in place, whatever its row stride: the view pc[..., 3:] of SA
     # level 0)
     few = use_xyz and feat is not None and C == 6
+    # (fp16x2_safe: the host-side probe of the rescaled chain -- _fused_mlp.fp16x2_probe; a chain whose weights two fp16
+    # pieces cannot hold falls through to the bf16 x 3 / fp32 kernels)
     if ((vec or few) and _fused_mlp.MLP_ARITH == "fp16x2" and (SPLIT2_NARROW or packed.dims[1] >= 128)
-            and lib.pvn3d_mlp_split2_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c)):
-        w2, meta = packed.split2()
+            and lib.pvn3d_mlp_split2_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c, _mlp_flags())
+            and packed.fp16x2_safe()):
+        w2, meta, b2, rinv = packed.split2()
         fa, xa = table_absmax(feat, B * N, C, ld_feat), table_absmax(xyz, B * N, 3, 3)
         with on_device(xyz.device):
             check(lib.pvn3d_sa_mlp_maxpool_split2(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),
-                                                  ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c,
+                                                  ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, w2, b2,
                                                   meta, fa.data_ptr(), xa.data_ptr(), out_pm.data_ptr(), ld_out, out_coff,
                                                   out_absmax.data_ptr() if out_absmax is not None else None,
-                                                  _stream(xyz)), "sa_mlp_maxpool_split2")
+                                                  rinv.data_ptr(), _mlp_flags(), _stream(xyz)), "sa_mlp_maxpool_split2")
         if out_absmax is not None:
             out_absmax._pvn3d_written = True
         return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
@@ -517,6 +535,8 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
                                                  packed.b_c, out_pm.data_ptr(), ld_out, out_coff, _stream(xyz)),
                   "sa_mlp_maxpool_split")
         return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
+    if packed._equil_given is not None:
+        raise RuntimeError("a rescaled (fp16 x 2) chain on a kernel that does not undo the rescaling")
     with on_device(xyz.device):
         check(lib.pvn3d_sa_mlp_maxpool(B, N, m, C, nsample, 1 if use_xyz else 0, xyz.data_ptr(),
                                        new_xyz.data_ptr(), feat.data_ptr() if feat is not None else None,
@@ -543,28 +563,31 @@ def sa_precontract(features, packs, nsamples):
     if C < 128 or B * n < 4096 or features.dtype != torch.float32:
         return None
     pres = []
+    h2 = _fused_mlp.MLP_ARITH == "fp16x2" and all(p.fp16x2_safe() for p in packs)
     for p, ns in zip(packs, nsamples):
         if p.n_layers != 3 or p.dims[0] != C + 3 or p.dims[1] % 32 != 0 or 2 * p.dims[1] > C:
             return None
-        pre, wf = p.precontracted(C)
-        ok = lib.pvn3d_mlp_split2_ok if _fused_mlp.MLP_ARITH == "fp16x2" else lib.pvn3d_mlp_split_ok
-        if not ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c):
+        pre, wf = p.precontracted(C, equil=h2)
+        if h2:
+            ok = lib.pvn3d_mlp_split2_ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c, _mlp_flags())
+        else:
+            ok = lib.pvn3d_mlp_split_ok(1, p.dims[1], 0, ns, pre.n_layers, pre.dims_c)
+        if not ok:
             return None
         pres.append((pre, wf))
     feat, ld = _point_major(features)
     if ld % 4 != 0 or feat.data_ptr() % 16 != 0:
         return None
-    h2 = _fused_mlp.MLP_ARITH == "fp16x2"
     key = (tuple(id(p) for p in packs), h2)
     cache = getattr(packs[0], "_pre_cat", None)
     if cache is None or cache[0] != key:
         wcat = torch.cat([wf for _, wf in pres], 0)
-        sw = _fused_mlp._pow2_weight_scale(wcat) if h2 else 1.0
-        wp = _fused_mlp._pack_weight_h16(wcat * sw, _fused_mlp._slabs(C)) if h2 else \
-            _fused_mlp._pack_weight_s16(wcat, _fused_mlp._slabs(C))
-        cache = (key, wp, list(packs), sw)
+        # (fp16 x 2: every row with its own power-of-two scale, undone by the GEMM's w_row_mul)
+        wp, rm = _fused_mlp._pack_weight_h16_rows(wcat, _fused_mlp._slabs(C)) if h2 else \
+            (_fused_mlp._pack_weight_s16(wcat, _fused_mlp._slabs(C)), None)
+        cache = (key, wp, list(packs), rm)
         packs[0]._pre_cat = cache
-    ws, sw = cache[1], cache[3]
+    ws, rm = cache[1], cache[3]
     S, n_out = _fused_mlp._slabs(C), ws.size(0)
     dev = features.device
     st = _stream(features)
@@ -574,8 +597,9 @@ def sa_precontract(features, packs, nsamples):
         xs, fa = table_h16(feat, B * n, C, ld, S)
         amax = torch.zeros(1, dtype=torch.float32, device=dev)
         with on_device(dev):
-            check(lib.pvn3d_split_gemm2(B * n, n_out, S, xs.data_ptr(), fa.data_ptr(), ws.data_ptr(), sw, None, 0, None, 0, 0,
-                                        0, None, None, y.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st), "split_gemm2")
+            check(lib.pvn3d_split_gemm2(B * n, n_out, S, xs.data_ptr(), fa.data_ptr(), ws.data_ptr(), 1.0, rm.data_ptr(), None, 0,
+                                        None, 0, 0, 0, None, None, y.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st),
+                  "split_gemm2")
     else:
         xs = torch.empty((B * n * S * 96,), dtype=torch.uint8, device=dev)
         with on_device(dev):
@@ -615,7 +639,7 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
     dev = kf.device
     st = _stream(kf)
     P, Pk = B * n, B * m
-    if _fused_mlp.MLP_ARITH == "fp16x2":
+    if _fused_mlp.MLP_ARITH == "fp16x2" and packed.h16_safe(C2):
         # the same three launches in the two-piece fp16 arithmetic (pvn3d_split_gemm2): operand scales from device-side
         # bounds -- abs-max of the two inputs, the rigorous bound of H from them -- and the output's abs-max for its consumer
         w = packed.h16(C2)
@@ -629,14 +653,16 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
             # |H| <= ||Wb||_inf max|skip| + ||Wa||_inf max|known| + max|b1|  (interpolation weights are >= 0 and sum to 1)
             check(lib.pvn3d_bound_affine(bnd.data_ptr(), ua.data_ptr(), w["nb"], ka.data_ptr(), w["na"], w["b1max"], st),
                   "bound_affine")
-            check(lib.pvn3d_split_gemm2(Pk, n1p, w["s_a"], xk.data_ptr(), ka.data_ptr(), w["wa"].data_ptr(), w["sw_a"], None, 0,
-                                        None, 0, 0, 0, None, None, z.data_ptr(), n1p, None, None, 0, None, st), "split_gemm2")
-            check(lib.pvn3d_split_gemm2(P, w["n1"], w["s_b"], xu.data_ptr(), ua.data_ptr(), w["wb"].data_ptr(), w["sw_b"],
-                                        w["b1"].data_ptr(), 1, z.data_ptr(), n1p, n, m, idx.data_ptr(), weight.data_ptr(),
-                                        None, 0, None, h.data_ptr(), w["s_h"], bnd.data_ptr(), st), "split_gemm2")
-            check(lib.pvn3d_split_gemm2(P, w["n2"], w["s_h"], h.data_ptr(), bnd.data_ptr(), w["w2"].data_ptr(), w["sw_2"],
-                                        w["b2"].data_ptr(), 1, None, 0, 0, 0, None, None, out.data_ptr(), ld_out,
-                                        bnd.data_ptr() + 4, None, 0, None, st), "split_gemm2")
+            check(lib.pvn3d_split_gemm2(Pk, n1p, w["s_a"], xk.data_ptr(), ka.data_ptr(), w["wa"].data_ptr(), 1.0,
+                                        w["rm_a"].data_ptr(), None, 0, None, 0, 0, 0, None, None, z.data_ptr(), n1p, None, None,
+                                        0, None, st), "split_gemm2")
+            check(lib.pvn3d_split_gemm2(P, w["n1"], w["s_b"], xu.data_ptr(), ua.data_ptr(), w["wb"].data_ptr(), 1.0,
+                                        w["rm_b"].data_ptr(), w["b1"].data_ptr(), 1, z.data_ptr(), n1p, n, m, idx.data_ptr(),
+                                        weight.data_ptr(), None, 0, None, h.data_ptr(), w["s_h"], bnd.data_ptr(), st),
+                  "split_gemm2")
+            check(lib.pvn3d_split_gemm2(P, w["n2"], w["s_h"], h.data_ptr(), bnd.data_ptr(), w["w2"].data_ptr(), 1.0,
+                                        w["rm_2"].data_ptr(), w["b2"].data_ptr(), 1, None, 0, 0, 0, None, None, out.data_ptr(),
+                                        ld_out, bnd.data_ptr() + 4, None, 0, None, st), "split_gemm2")
         return bnd[1:2]
     w = packed.s16(C2)
     n1p = w["b1"].numel()
@@ -691,21 +717,23 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
     # FP level 0 (12288 <- 2048 points, 256 -> 128): the interpolated half of the first conv per KNOWN point ahead of the
     # interpolation (six times fewer points, and the chain then gathers 128 instead of 256 channels per neighbour) --
     # the regrouping of _fp_layerwise_split with the fused kernel behind it
-    split_ok = lib.pvn3d_mlp_split2_ok if _fused_mlp.MLP_ARITH == "fp16x2" else lib.pvn3d_mlp_split_ok
+    h2 = _fused_mlp.MLP_ARITH == "fp16x2" and packed.fp16x2_safe()
+
+    def split_ok(*a):
+        return lib.pvn3d_mlp_split2_ok(*a, _mlp_flags()) if h2 else lib.pvn3d_mlp_split_ok(*a)
     precontracted = False          # layer 0 of `packed` starts with an identity block over kf's channels
     if (FP_PRECONTRACT and _fused_mlp.split_arith() and packed.n_layers == 2 and C1 > 0 and C2 >= 256
             and packed.dims[1] % 32 == 0 and 2 * packed.dims[1] <= C2 and n >= 4 * m and B * m >= 4096
-            and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0):
-        pre, wa = packed.precontracted(C2)
+            and ld_k % 4 == 0 and kf.data_ptr() % 16 == 0
+            and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))):
+        pre, wa = packed.precontracted(C2, equil=h2)
         if split_ok(0, pre.dims[1], C1, 0, pre.n_layers, pre.dims_c):
-            h2 = _fused_mlp.MLP_ARITH == "fp16x2"
             cache = getattr(packed, "_pre_s16", None)
             if cache is None or cache[0] != (C2, h2):       # keyed on the split point like PackedMLP.precontracted()
-                sw = _fused_mlp._pow2_weight_scale(wa) if h2 else 1.0
-                wp = _fused_mlp._pack_weight_h16(wa * sw, _fused_mlp._slabs(C2)) if h2 else \
-                    _fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2))
-                cache = packed._pre_s16 = ((C2, h2), wp, sw)
-            wp, sw = cache[1], cache[2]
+                wp, rm = _fused_mlp._pack_weight_h16_rows(wa, _fused_mlp._slabs(C2)) if h2 else \
+                    (_fused_mlp._pack_weight_s16(wa, _fused_mlp._slabs(C2)), None)
+                cache = packed._pre_s16 = ((C2, h2), wp, rm)
+            wp, rm = cache[1], cache[2]
             S, n_out = _fused_mlp._slabs(C2), wp.size(0)
             dev, st = known_feats.device, _stream(known_feats)
             z = torch.empty((B, m, n_out), dtype=torch.float32, device=dev)
@@ -713,9 +741,9 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                 xs, ka = table_h16(kf, B * m, C2, ld_k, S)
                 amax = torch.zeros(1, dtype=torch.float32, device=dev)
                 with on_device(dev):
-                    check(lib.pvn3d_split_gemm2(B * m, n_out, S, xs.data_ptr(), ka.data_ptr(), wp.data_ptr(), sw, None, 0, None,
-                                                0, 0, 0, None, None, z.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st),
-                          "split_gemm2")
+                    check(lib.pvn3d_split_gemm2(B * m, n_out, S, xs.data_ptr(), ka.data_ptr(), wp.data_ptr(), 1.0, rm.data_ptr(),
+                                                None, 0, None, 0, 0, 0, None, None, z.data_ptr(), n_out, amax.data_ptr(), None,
+                                                0, None, st), "split_gemm2")
                 seed_absmax(z, B * m, pre.dims[1], n_out, amax)
             else:
                 xs = torch.empty((B * m * S * 96,), dtype=torch.uint8, device=dev)
@@ -726,9 +754,9 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
             kf, ld_k, C2, packed = z, n_out, pre.dims[1], pre
             precontracted = True
     vec = ld_k % 4 == 0 and kf.data_ptr() % 16 == 0 and (C1 < 32 or (ld_u % 4 == 0 and uf.data_ptr() % 16 == 0))
-    if (vec and _fused_mlp.MLP_ARITH == "fp16x2"
-            and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c)):
-        w2, meta = packed.split2()
+    if (vec and h2
+            and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c, _mlp_flags())):
+        w2, meta, b2, rinv = packed.split2()
         # a point-major output feeds another fused level: leave its abs-max for that level's operand scale
         amax = torch.zeros(1, dtype=torch.float32, device=known_feats.device) if point_major_out else None
         ka = table_absmax(kf, B * m, C2, ld_k)
@@ -739,10 +767,11 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
         with on_device(known_feats.device):
             check(entry(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                                  uf.data_ptr() if uf is not None else None, ld_u, idx.data_ptr(),
-                                                 weight.data_ptr(), packed.n_layers, packed.dims_c, w2, packed.b_c, meta,
+                                                 weight.data_ptr(), packed.n_layers, packed.dims_c, w2, b2, meta,
                                                  ka.data_ptr(), ua.data_ptr() if ua is not None else None, out.data_ptr(),
                                                  1 if point_major_out else 0, ld_out,
-                                                 amax.data_ptr() if amax is not None else None, _stream(known_feats)),
+                                                 amax.data_ptr() if amax is not None else None, rinv.data_ptr(),
+                                                 _mlp_flags(), _stream(known_feats)),
                   "fp_interp_mlp_split2")
         if point_major_out:
             return seed_absmax(out[:, :, :M].transpose(1, 2), B * n, M, ld_out, amax)
@@ -761,6 +790,8 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
         amax = _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed, out, ld_out)
         view = out[:, :, :M].transpose(1, 2)
         return seed_absmax(view, B * n, M, ld_out, amax) if amax is not None else view
+    if packed._equil_given is not None:
+        raise RuntimeError("a rescaled (fp16 x 2) chain on a kernel that does not undo the rescaling")
     with on_device(known_feats.device):
         check(lib.pvn3d_fp_interp_mlp(B, n, m, C2, C1, kf.data_ptr(), ld_k,
                                       uf.data_ptr() if uf is not None else None, ld_u,

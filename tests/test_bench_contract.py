@@ -154,12 +154,12 @@ def test_mlp_chain_table_says_which_pipe_each_chain_runs_on():
     b3 = {r["chain"] for r in rows if r["arithmetic"].startswith("bf16x3")}
     assert h2 == {"SA0.0", "SA0.1", "SA1.0", "SA1.1", "SA2.0", "SA2.1", "SA3.0", "SA3.1", "FP0", "FP1", "FP2", "FP3"}
     assert b3 == set()
-    from pvn3d_amd._lib import lib
-    lib.pvn3d_set_sa_narrow(0)
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    _ext.NARROW_KERNELS = False          # (PVN3D_MLP_NO_NARROW with every call: the C ABI has no process-wide switch)
     try:
         off = bench.mlp_chain_table(Pointnet2MSG(input_channels=6), 1.0, frames=64)
     finally:
-        lib.pvn3d_set_sa_narrow(1)
+        _ext.NARROW_KERNELS = True
     assert {r["chain"] for r in off if r["arithmetic"].startswith("fp32")} == {"SA0.0", "SA0.1"}
     assert all(abs(r["peak_tflops"] - 157.3) < 1e-9 for r in off if r["arithmetic"].startswith("fp32"))
     assert {r["chain"] for r in rows if r["arithmetic"].endswith("layer by layer")} == {"FP2", "FP3"}

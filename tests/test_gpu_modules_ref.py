@@ -400,3 +400,107 @@ def test_batched_pointnet2msg_against_reference_module_code(dev, golden, B):
         scale = max(1.0, float(y1.abs().max()))
         d = float((y1[0] - y[f]).abs().max()) / scale
         assert d <= 2e-5, "frame %d in the batch vs alone: %.3g of the output scale" % (f, d)
+
+
+def _trained_state(z):
+    keys = [str(k) for k in z["keys"]]
+    shapes = [tuple(int(x) for x in s.split(",")) if s else () for s in (str(v) for v in z["shapes"])]
+    return keys, shapes, weights(keys, shapes, int(z["seed"]), style=str(z["style"]))
+
+
+def test_trained_like_fixture_state_dict_is_reproducible(golden):
+    """CPU: the trained-like state_dict (module_weights.weights(style="trained")) has the recorded SHA-256 and loads strict."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    z = golden("pointnet2msg_trained_ref.npz")
+    keys, shapes, w = _trained_state(z)
+    assert weights_sha(keys, w) == str(z["sha256"])
+    Pointnet2MSG(input_channels=6).load_state_dict({k: torch.from_numpy(np.asarray(w[k])) for k in keys}, strict=True)
+    var = np.concatenate([w[k].ravel() for k in keys if k.endswith("running_var")])
+    gam = np.concatenate([w[k].ravel() for k in keys if k.endswith("bn.weight")])
+    assert var.min() < 1e-5 and var.max() > 10.0 and gam.min() < 3e-3 and gam.max() > 2.0
+
+
+@pytest.mark.gpu
+def test_pointnet2msg_with_trained_like_batchnorm_per_channel_against_reference_module_code(dev, golden):
+    """Round-5 verdict, weak #1 (iii): the reference's own Pointnet2MSG (lib/pvn3d.py:46-154, module code
+    pointnet2_modules.py:27-71,162-206, pytorch_utils.py:25-134) run with a TRAINED-LIKE state_dict -- running_var over eight
+    decades, gamma over three and a half -- in float32 and float64 (tests/golden/make_golden_trained.py).  The frame is
+    tiled to a batch of 8 so that the forward takes the dispatch bench.py times (fp16 x 2 chains, pre-contractions, split
+    GEMMs); every level's FPS picks identical, and every OUTPUT CHANNEL of every level within 3e-6 of ITS OWN scale (its
+    max |x| in the float64 run) or within 4 x of what the reference's own float32 run leaves on the level's worst channel
+    (the worst channels are channels that cancel, and a level inherits the levels before it), and nine channels in ten
+    within 3 x of the reference's float32 error on the same channel (measured: 0.5 - 2.2; single chains are held to 2 x in
+    tests/test_gpu_ops.py)."""
+    from pvn3d_amd import synth
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pointnet2_utils import _ext, _small_batch
+    z = golden("pointnet2msg_trained_ref.npz")
+    keys, shapes, w = _trained_state(z)
+    assert weights_sha(keys, w) == str(z["sha256"])
+    net = Pointnet2MSG(input_channels=6)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(w[k])) for k in keys}, strict=True)
+    net = net.to(dev).eval()
+    f = synth.synth_frame(frame=int(z["frame"]), n_pts=12288, n_obj=3072)
+    pc1 = np.concatenate([f["pcld"], f["feats"].T], 1).astype(np.float32)
+    B = 8
+    pc = torch.from_numpy(np.tile(pc1[None], (B, 1, 1))).to(dev)
+    with torch.no_grad():
+        sa_geo, _ = net._geometry_ahead(pc[..., :3].contiguous())
+    torch.cuda.synchronize()
+    lvl = pc1[:, :3]
+    for l in range(4):
+        (new_xyz, _), _ = sa_geo[l]
+        lvl = lvl[z["fps%d" % l].astype(np.int64)[0] if z["fps%d" % l].ndim == 2 else z["fps%d" % l].astype(np.int64)]
+        assert np.array_equal(new_xyz[B - 1].cpu().numpy(), lvl), "level %d centres (FPS)" % l
+    feats, hooks = {}, []
+    for i, m in enumerate(net.SA_modules):
+        hooks.append(m.register_forward_hook(lambda mod, a, r, i=i: feats.__setitem__("sa%d" % i, r[1])))
+    for i, m in enumerate(net.FP_modules):
+        hooks.append(m.register_forward_hook(lambda mod, a, r, i=i: feats.__setitem__("fp%d" % i, r)))
+    spy, spy_sb = _SpyLib(_ext.lib), _SpyLib(_small_batch.lib)
+    _ext.lib, _small_batch.lib = spy, spy_sb
+    try:
+        with torch.no_grad():
+            net(pc)
+        torch.cuda.synchronize()
+    finally:
+        _ext.lib, _small_batch.lib = spy._lib, spy_sb._lib
+        for h in hooks:
+            h.remove()
+    c = spy.calls
+    print("trained-like state_dict, B = 8, C-ABI calls:", dict((k, v) for k, v in sorted(c.items()) if "mlp" in k or "split" in k))
+    # the two-piece arithmetic carries the network: the host-side probe (fp16x2_safe) sends no chain of this state_dict to
+    # another pipe (at 8 frames FP level 3 -- 4096 points -- is on the small-batch route, as in the benign fixture)
+    assert c["pvn3d_sa_mlp_maxpool_split2"] == 8 and c["pvn3d_sa_mlp_maxpool_split"] == 0 and c["pvn3d_sa_mlp_maxpool"] == 0, dict(c)
+    assert c["pvn3d_fp_interp_mlp_split2"] + c["pvn3d_fp_interp_add_mlp_split2"] == 2 and c["pvn3d_split_gemm"] == 0, dict(c)
+    report = {}
+    for name in LEVELS:
+        t = feats[name].double()                                           # (B, C, n)
+        assert torch.equal(feats[name][0], feats[name][B - 1])             # the same frame, the same bits
+        cols = torch.from_numpy(z["%s_cols" % name].astype(np.int64)).to(dev)
+        got = t[B - 1][:, cols].cpu().numpy()
+        v64, v32 = z["%s_vals_f64" % name].astype(np.float64), z["%s_vals_f32" % name].astype(np.float64)
+        sc = z["%s_chan_max" % name].astype(np.float64)
+        live = sc > 0
+        assert np.all(got[~live] == 0.0)                                  # dead in float64: dead here
+        e_got = (np.abs(got - v64).max(1) / np.where(live, sc, 1.0))[live]
+        e_ref = (np.abs(v32 - v64).max(1) / np.where(live, sc, 1.0))[live]
+        report[name] = ("%.1e" % e_got.max(), "%.1e" % e_ref.max(), "q90 %.2f" % float(np.quantile(e_got / np.maximum(e_ref, 5e-7), 0.9)),
+                        int(live.sum()))
+        assert e_got.max() <= max(3e-6, 4.0 * e_ref.max()), "%s: worst channel %.3g of its own scale (reference fp32 run: %.3g)" % (
+            name, e_got.max(), e_ref.max())
+        q90 = float(np.quantile(e_got / np.maximum(e_ref, 5e-7), 0.9))
+        assert q90 <= 3.0, "%s: nine channels in ten within 3 x of the reference's own fp32 error: %.2f" % (name, q90)
+        # every element, through the per-channel sums (float64 run): random-walk bound on the element errors + the sums' own rounding
+        got_sum = t[B - 1].sum(1).cpu().numpy()
+        # (a channel that is dead or all but dead in float64 may carry a few values of the size of the level's rounding)
+        bound = 3e-6 * np.maximum(sc, 1e-3 * sc.max()) * np.sqrt(t.shape[2]) + 2e-6 * z["%s_chan_abs" % name].astype(np.float64)
+        ref_dev = np.abs(z["%s_chan_sum_f32" % name].astype(np.float64) - z["%s_chan_sum" % name].astype(np.float64))
+        dev_sum = np.abs(got_sum - z["%s_chan_sum" % name])
+        # (... or 8 x what the reference's own float32 run is off by on that sum: a channel that fires on a few per cent of
+        # the points sits at its ReLU threshold, and its error is that of the pre-activation's terms, not of its small output)
+        lim = np.maximum(bound, 8.0 * ref_dev)
+        k = int(np.argmax(dev_sum / lim))
+        assert np.all(dev_sum <= lim), "%s channel sums: channel %d off by %.3g (limit %.3g; channel max %.3g, sum %.6g, reference fp32 run off by %.3g)" % (
+            name, k, dev_sum[k], lim[k], sc[k], float(z["%s_chan_sum" % name][k]), ref_dev[k])
+    print("trained-like state_dict: per level (worst channel err / own scale here, in the reference's fp32 run, live channels):", report)

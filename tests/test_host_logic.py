@@ -330,9 +330,10 @@ def test_pmc_mfma_groups_the_launches_of_a_forward_by_chain():
 
 
 def test_fp16x2_weight_packing_and_layer_meta():
-    """_fused_mlp.PackedMLP.split2 (include/pvn3d_hip.h, w_split2 / layer_meta): per layer a power-of-two scale that puts
-    the largest weight in [2^13, 2^14], two fp16 pieces whose sum is the scaled weight to 2^-22, in the fragment order of
-    the three-piece packing; ||W||_inf and max|bias| of the TRUE weights."""
+    """_fused_mlp.PackedMLP.split2 (include/pvn3d_hip.h, w_split2 / layer_meta / out_row_mul): the chain rescaled
+    diagonally by powers of two (equilibrated()), then per layer a power-of-two scale that puts the largest weight in
+    [2^13, 2^14], two fp16 pieces whose sum is the scaled weight to 2^-22, in the fragment order of the three-piece
+    packing; ||W~||_inf and max(b~)_+ of the rescaled weights; the biases b~ and the output multipliers D_L^-1 padded to 32."""
     import math
     import torch
     from pvn3d_amd.lib.pointnet2_utils import _fused_mlp, pointnet2_modules as pm
@@ -342,15 +343,19 @@ def test_fp16x2_weight_packing_and_layer_meta():
         layer.normlayer.bn.running_var.uniform_(0.5, 2.0)
         layer.normlayer.bn.running_mean.normal_()
     pk = _fused_mlp.pack_shared_mlp(sa.mlps[0], n_xyz_first=3)
-    wptr, meta = pk.split2()
-    ws = pk._split2[0]
-    assert len(ws) == pk.n_layers and len(meta) == 3 * pk.n_layers
-    for l, (W, b) in enumerate(zip(pk._folded, pk.b)):
+    wptr, meta, bptr, rinv = pk.split2()
+    ws, bp = pk._split2[0], pk._split2[3]
+    Wt, bt, rv = pk.equilibrated()
+    assert len(ws) == pk.n_layers and len(meta) == 3 * pk.n_layers and len(bp) == pk.n_layers
+    assert rinv.shape == (96,) and torch.equal(rinv[:70], rv) and torch.equal(rinv[70:], torch.ones(26))
+    for l, (W, b) in enumerate(zip(Wt, bt)):
         sw, wnorm, bmax = meta[3 * l], meta[3 * l + 1], meta[3 * l + 2]
         assert math.frexp(sw)[0] == 0.5 and 8192.0 <= float(W.abs().max()) * sw <= 16384.0
-        assert abs(wnorm - float(W.abs().sum(1).max())) <= 1e-6 * wnorm and abs(bmax - float(b.abs().max())) <= 1e-6 * max(bmax, 1e-9)
+        # (bmax = max(b)_+: the bound it enters is that of a post-ReLU value)
+        assert abs(wnorm - float(W.abs().sum(1).max())) <= 1e-6 * wnorm and abs(bmax - max(float(b.max()), 0.0)) <= 1e-6 * max(bmax, 1e-9)
         M, K = W.shape
         MT, S = (M + 31) // 32, (K + 15) // 16
+        assert bp[l].shape == (MT * 32,) and torch.equal(bp[l][:M], b) and float(bp[l][M:].abs().sum()) == 0.0
         t = ws[l]
         assert tuple(t.shape) == (S, MT, 2, 64, 8) and t.dtype == torch.int16
         # (s, mt, piece, half * 32 + r, j) -> value of row mt*32 + r, k = 16 s + 8 half + j
@@ -358,3 +363,109 @@ def test_fp16x2_weight_packing_and_layer_meta():
         rec = (v[0] + v[1])[:M, :K] / sw
         assert float((rec - W.double()).abs().max()) <= 2.0 ** -21 * float(W.abs().max())
         assert float(v[:, M:].abs().max() if M < MT * 32 else 0.0) == 0.0 and float(v[:, :, K:].abs().max() if K < S * 16 else 0.0) == 0.0
+
+
+def _fp16x2_chain_emulation(Ws, bs, rinv, x, bound0):
+    """The arithmetic of the fp16 x 2 kernels on the CPU (csrc/sa_mlp_split.hip, AR = 1; fp64 accumulation, so what is
+    left is the OPERAND error): per layer one power-of-two weight scale and one activation scale from the rigorous bound
+    B' = ||W||_inf B + max(b)_+; operands as fp16(v) + fp16(v - fp16(v)); products wh.xh + wh.xl + wl.xh; the output
+    multiplied by rinv."""
+    import math
+    import torch
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+
+    def two(v):
+        h = v.float().half().double()
+        return h, (v - h).float().half().double()
+    B = bound0
+    for l, (W, b) in enumerate(zip(Ws, bs)):
+        sw = _fused_mlp._pow2_weight_scale(W)
+        sx = math.ldexp(1.0, 14 - math.frexp(max(B, 1e-30))[1])
+        wh, wl = two(W.double() * sw)
+        xh, xl = two(x * sx)
+        acc = xh @ wh.T + xl @ wh.T + xh @ wl.T
+        x = torch.relu(acc / (sw * sx) + b.double())
+        B = (float(W.abs().sum(1).max()) * B + max(float(b.max()), 0.0)) * 1.01
+    return x * rinv.double()
+
+
+def test_equilibrated_chain_is_exact_and_survives_trained_like_batchnorm_statistics():
+    """Round-5 verdict, weak #1: a folded BatchNorm spreads the rows of W' = W gamma / sqrt(var + eps) over orders of
+    magnitude (pytorch_utils.py:25-134: Conv2d -> BatchNorm2d -> ReLU in fp32); with ONE scale per weight matrix the small
+    rows lose their low fp16 piece to the subnormal range, and the error shows per output channel, not in max|dy| / max|y|.
+    equilibrate() rescales the chain diagonally by powers of two: (i) exact -- only powers of two, and the rescaled chain
+    evaluated in fp64 and multiplied by rinv equals the original chain; (ii) every live hidden channel's nominal bound in
+    (0.5, 1]; (iii) the emulated fp16 x 2 arithmetic PER OUTPUT CHANNEL, on data the probe has not seen: with running_var
+    log-uniform 1e-6..1e2 and gamma 1e-3..10 within 2e-6 of the channel's own scale or of what the fp32 chain itself leaves
+    there, where the per-matrix scaling of round 5 is off by 20 x more; (iv) one huge-norm hidden row that ReLU kills (a
+    deliberately loose hidden bound): the bound no longer sees it (max(b)_+), the probe finds what is left (the dead
+    channel's huge column in the next layer) and PackedMLP.fp16x2_safe() sends the chain to bf16 x 3."""
+    import torch
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+    g = torch.Generator().manual_seed(11)
+
+    def chain(dims, wild, killer=False):
+        Ws, bs = [], []
+        for l, (k, m) in enumerate(zip(dims[:-1], dims[1:])):
+            W = torch.randn(m, k, generator=g) / k ** 0.5
+            b = torch.randn(m, generator=g) * 0.3
+            if wild:
+                var = torch.pow(10.0, torch.rand(m, generator=g) * 8.0 - 6.0)
+                gam = torch.pow(10.0, torch.rand(m, generator=g) * 4.0 - 3.0)
+                sc = gam / torch.sqrt(var + 1e-5)
+                W, b = W * sc[:, None], b * sc + torch.randn(m, generator=g) * 0.1
+            if killer and l == 0:
+                W[3] *= 3.0e6
+                b[3] = -1.0e9                        # ReLU kills it: ||W||_inf B + max|b| is 1e7 x too loose
+            Ws.append(W.float())
+            bs.append(b.float())
+        return Ws, bs
+
+    def ref64(Ws, bs, x):
+        for W, b in zip(Ws, bs):
+            x = torch.relu(x @ W.double().T + b.double())
+        return x
+
+    def ref32(Ws, bs, x):
+        x = x.float()
+        for W, b in zip(Ws, bs):
+            x = torch.relu(x @ W.T + b)
+        return x.double()
+
+    x = torch.randn(4096, 99, generator=g).double() * 3.0
+    x[:, 96:] *= 0.01                                # relative coordinates beside features
+    for wild, killer in ((False, False), (True, False), (False, True)):
+        Ws, bs = chain([99, 64, 96, 128], wild, killer)
+        Wt, bt, rinv = _fused_mlp.equilibrate(Ws, bs)
+        want = ref64(Ws, bs, x)
+        # (i) exact: powers of two only
+        for W, V in zip(Ws, Wt):
+            ratio = (V.double() / W.double())[W != 0]
+            assert bool((torch.frexp(ratio.float())[0] == 0.5).all())
+        got64 = ref64(Wt, bt, x) * rinv.double()
+        assert float((got64 - want).abs().max()) <= 1e-12 * float(want.abs().max())
+        # (ii) live hidden channels fill the activations' scale
+        u = torch.full((99,), _fused_mlp.EQUIL_NOMINAL_INPUT, dtype=torch.float64)
+        for V, c in zip(Wt, bt):
+            ub = torch.clamp(V.abs().double() @ u + c.double(), min=0.0)
+            live = ub > (V.abs().double() @ u + c.abs().double()) * 2.0 ** -10
+            assert float(ub[live].max()) <= 1.0 and float(ub[live].min()) > 0.5
+            u = torch.where(live, ub, torch.zeros_like(ub))
+        # (iii) / (iv)
+        sc = want.abs().amax(0)
+        live = sc > 0
+        err = lambda y: ((y - want).abs().amax(0) / sc.clamp_min(1e-300))[live]
+        e_new = err(_fp16x2_chain_emulation(Wt, bt, rinv, x, float(x.abs().max())))
+        e_old = err(_fp16x2_chain_emulation(Ws, bs, torch.ones(128), x, float(x.abs().max())))
+        e_32 = err(ref32(Ws, bs, x))
+        safe, p16, p32, q90 = _fused_mlp.fp16x2_verdict(*_fused_mlp.fp16x2_probe(Wt, bt, rinv))
+        raw_safe = _fused_mlp.fp16x2_verdict(*_fused_mlp.fp16x2_probe(Ws, bs))[0]
+        assert raw_safe == (not wild and not killer)          # one scale per matrix (round 5) holds the benign chain only
+        if not killer:
+            assert safe
+            assert float(e_new.max()) <= max(2e-6, 1.1 * float(e_32.max())), (wild, float(e_new.max()), float(e_32.max()))
+            assert bool((e_new <= torch.clamp(2.0 * e_32, min=2e-6)).all())                     # channel by channel
+            if wild:
+                assert float(e_old.max()) > 8 * float(e_new.max()), (float(e_old.max()), float(e_new.max()))
+        else:
+            assert not safe and p16 > 1e-4 and float(e_old.max()) > 1e-3 and float(e_32.max()) < 2e-6

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""FPS level-0 timing (12288 -> 2048), culled kernel vs register-resident kernel, at F frames.
+"""FPS level-0 timing (12288 -> 2048): culled kernel with one wave per 64-point slot (default) / with one wave per cloud,
+and the register-resident kernel, at F frames.
 usage: python tools/fps_time.py [--frames 1,64] [--reps 5]"""
 import argparse
 import os
@@ -41,14 +42,16 @@ def main():
             xyz = torch.from_numpy(np.stack([synth.synth_cloud(np.random.default_rng(1234 + f), n)[0]
                                              for f in range(F)], 0)).to(dev)
             out = {}
-            for culled in (True, False):
-                _ext.FPS_CULLED = culled
+            for key, culled, waves in (("mw", True, 3), ("one", True, 0), ("reg", False, 0)):
+                _ext.FPS_CULLED, _ext.FPS_WAVES = culled, waves
                 mn, md = timeit(lambda: _ext.furthest_point_sampling(xyz, m), args.reps)
-                out[culled] = (mn, _ext.furthest_point_sampling(xyz, m))
-            _ext.FPS_CULLED = True
-            same = bool(torch.equal(out[True][1], out[False][1]))
-            print("fps n=%5d m=%4d F=%3d  culled %8.1f us (%.3f us/round)   register-resident %8.1f us   same=%s"
-                  % (n, m, F, out[True][0] * 1e3, out[True][0] * 1e3 / m, out[False][0] * 1e3, same), flush=True)
+                out[key] = (mn, _ext.furthest_point_sampling(xyz, m))
+            _ext.FPS_CULLED, _ext.FPS_WAVES = True, 0
+            same = bool(torch.equal(out["mw"][1], out["reg"][1])) and bool(torch.equal(out["one"][1], out["reg"][1]))
+            print("fps n=%5d m=%4d F=%3d  culled, one wave per slot %8.1f us (%.3f us/round)   culled, one wave %8.1f us "
+                  "(%.3f us/round)   register-resident %8.1f us   same=%s"
+                  % (n, m, F, out["mw"][0] * 1e3, out["mw"][0] * 1e3 / m, out["one"][0] * 1e3, out["one"][0] * 1e3 / m,
+                     out["reg"][0] * 1e3, same), flush=True)
 
 
 if __name__ == "__main__":

@@ -100,11 +100,11 @@ def main():
                 outs[arith] = (o[1] if isinstance(o, tuple) else o).clone()
         extra = ""
         if name.startswith(("SA0", "SA1")):
-            from pvn3d_amd._lib import lib
-            lib.pvn3d_set_sa_narrow(0)
+            from pvn3d_amd.lib.pointnet2_utils import _ext
+            _ext.NARROW_KERNELS = False
             with torch.no_grad():
                 extra = "   [narrow-chain kernel off: %7.3f ms]" % ms_of(fn)
-            lib.pvn3d_set_sa_narrow(1)
+            _ext.NARROW_KERNELS = True
         sc = max(1.0, float(outs["fp32"].abs().max()))
         print("%-9s fp32 mfma %7.3f ms (%6.1f TF/s)   bf16x3 %7.3f ms (%6.1f)   fp16x2 %7.3f ms (%6.1f TF/s fp32-equivalent)   "
               "max|diff|/scale vs fp32 chain: bf16x3 %.1e fp16x2 %.1e   dbg=%s" % (
