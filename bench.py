@@ -406,6 +406,53 @@ def device_copy_bandwidth(dev):
                 unit="GB/s", bytes=1 << 30, note="copy counts read + write bytes")
 
 
+def per_rank_share_entry(net, dev, poll_every, frames=8, steps=20, warm=5):
+    """What one rank of BASELINE config 4 runs: `frames` frames per step through the headline's pipelined step (MLP feature
+    path on a side stream with the NEXT step's xyz-only geometry enqueued ahead of it, vote -> cluster -> pose on the
+    current stream), plus the serial stage times of the same step.  At 8 frames the step is latency-bound: FPS level 0 is
+    one wave per cloud (1.53 ms whatever the frame count) and the MeanShift iterations are a handful of waves."""
+    off = StageTimer(False)
+    inp = make_inputs(frames, 12288, 3072, dev, seed_base=7050)
+    inp["pc"] = torch.cat([inp["pcld"], inp["feats"].transpose(1, 2)], 2).contiguous()
+    side = torch.cuda.Stream(device=dev)
+    geo_next = [None]
+
+    def step():
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            with torch.no_grad():
+                geo = geo_next[0] if geo_next[0] is not None else net.geometry_ahead(inp["pc"])
+                geo_next[0] = net.geometry_ahead(inp["pc"])
+            keep = run_net(net, inp, off, geometry=geo)
+        res = run_postproc(inp, off, poll_every)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return keep, res
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        keep, res = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    timer = StageTimer(True)
+    for _ in range(steps):
+        run_net(net, inp, timer)
+        run_postproc(inp, timer, poll_every)
+    torch.cuda.synchronize()
+    stage = {k: v / steps for k, v in timer.totals_ms().items()}
+    p = res["poses"].cpu().numpy()
+    err = float(max(max(np.abs(p[i][:, :3] - f["R"]).max(), np.abs(p[i][:, 3] - f["t"]).max()) for i, f in enumerate(inp["frames"])))
+    return dict(name="config4_per_rank_share", workload="BASELINE config 4 as ONE of its 8 ranks runs it: %d frames per step "
+                "(64 frames sharded 8-way), N=12288, n_obj=3072, K=8; the headline's three-stream pipelined step" % frames,
+                frames_per_step=frames, ms_per_step=ms, frames_per_s=frames * 1e3 / ms, stage_ms_per_step_serial=stage,
+                implied_8_gpu_frames_per_s_if_ranks_do_not_interfere=8 * frames * 1e3 / ms,
+                note="the 8-GPU figure is arithmetic on a 1-GPU measurement (the driver measures the real curve); the only "
+                     "cross-rank step is one all-gather of 48 floats per frame",
+                pose_err_vs_ground_truth=err)
+
+
 def extra_configs(net, dev, poll_every, with_cpu):
     """The BASELINE configurations next to the headline one, each on a few steps (rank 0, N = 1)."""
     from pvn3d_amd import synth
@@ -461,6 +508,12 @@ def extra_configs(net, dev, poll_every, with_cpu):
                                       vote_cluster_pose_graph=ms_bg, both_serial_both_graphs=ms_gg),
                     frames_per_s=1e3 / ms_ab, meanshift_iters_max=int(res["iters"].max().item()),
                     pose_err_vs_ground_truth=pose_err(res, inp["frames"])))
+
+    # (i') BASELINE config 4's per-rank share: 64 frames sharded 8-way = 8 frames per GPU per step
+    # (TorchEval.eval_pose_parallel, pvn3d_eval_utils.py:345-387, is the contract the step replaces): the same three-stream
+    # step as the headline (feature path || geometry of the next batch || vote-cluster-pose), 8 frames
+    if net is not None:
+        out.append(per_rank_share_entry(net, dev, poll_every, frames=8))
 
     # (ii) the n_obj = 12 288 stress case (every point of the cloud votes), 8 frames per call
     fr = [synth.synth_frame(frame=7100 + i, n_pts=12288, n_obj=12288) for i in range(8)]
@@ -601,6 +654,20 @@ def extra_configs(net, dev, poll_every, with_cpu):
     return out
 
 
+def mlp_arithmetic_field():
+    """config.arithmetic: what the SA / FP contractions compute in."""
+    from pvn3d_amd.lib.pointnet2_utils import _fused_mlp
+    a = _fused_mlp.MLP_ARITH
+    return {"name": a,
+            "meaning": {"fp16x2": "fp32 operands as two fp16 pieces each, three exact partial products per multiply on "
+                                  "v_mfma_f32_32x32x16_f16, fp32 accumulation; every chain rescaled diagonally by powers of "
+                                  "two on the host (per-row weight scales, per-channel hidden bounds), activations scaled from "
+                                  "device-side bounds; a chain the host-side probe finds unsafe runs bf16x3",
+                        "bf16x3": "three bf16 pieces per operand, six partial products on v_mfma_f32_32x32x16_bf16",
+                        "fp32": "v_mfma_f32_32x32x2_f32"}.get(a, a),
+            "operand_bits": {"fp16x2": 22, "bf16x3": 24, "fp32": 24}.get(a)}
+
+
 def distributed_train_entry(dev, rank, world, steps=5, warm=2, frames=24, bucket_bytes=4 << 20, standin=False):
     """BASELINE config 5 at N > 1 (weak: `frames` frames per GPU): the bf16 training step of the voting branch with its
     gradient buckets all-reduced from inside backward (sharding.OverlappedGradientReducer over RCCL / xGMI) -- what
@@ -641,8 +708,9 @@ def distributed_train_entry(dev, rank, world, steps=5, warm=2, frames=24, bucket
         model = ts.PointVoteNet().to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         batch = ts.synthetic_batch(frames, 12288, dev, seed_base=7500 + 1000 * rank, n_obj=3072)
-        one_step = lambda g: ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16, group=g,
-                                           bucket_bytes=bucket_bytes)
+        # (g None = the baseline leg: exchange switched off explicitly -- group=None alone would mean "the default group")
+        one_step = lambda g: ts.train_step(model, opt, batch, autocast_dtype=torch.bfloat16, group=group,
+                                           bucket_bytes=bucket_bytes, exchange=g is not None)
         sync = lambda: torch.cuda.synchronize(dev)
         net = model
         what = ("Pointnet2MSG + offset heads, forward + vote loss + backward + Adam step, bf16 autocast, SA/FP SharedMLP "
@@ -677,12 +745,17 @@ def distributed_train_entry(dev, rank, world, steps=5, warm=2, frames=24, bucket
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     in_sync = bool(torch.equal(lo, hi))
+    issued_before = red.collectives_issued if red is not None else 0
     ms_0, _ = timed(None)                                    # the same steps, no exchange
+    baseline_collectives = (red.collectives_issued if red is not None else 0) - issued_before
+    if baseline_collectives != 0:
+        raise RuntimeError("the no-exchange leg issued %d gradient all-reduces" % baseline_collectives)
     return dict(name="train_step", n_gpus=world, scaling="weak", frames_per_gpu_per_step=frames,
                 workload="config 5 at %d ranks: %s; gradients bucketed (%.1f MiB) and all-reduced from inside backward "
                          "(RCCL over xGMI), one process per GPU" % (world, what, bucket_bytes / 2 ** 20),
                 ms_per_step=ms_x, frames_per_s=world * frames * 1e3 / ms_x,
                 ms_per_step_without_exchange=ms_0, exposed_allreduce_ms=max(0.0, ms_x - ms_0),
+                gradient_allreduces_in_the_no_exchange_leg=int(baseline_collectives),
                 gradient_buckets=n_buckets, gradient_bytes_per_step=int(sum(bytes_buckets)), bucket_bytes=bytes_buckets,
                 buckets_issued_inside_backward_total=int(during), steps=steps, warmup=warm,
                 weights_identical_across_ranks_after_steps=in_sync, loss_first=losses[0], loss_last=losses[-1],
@@ -1009,7 +1082,10 @@ def main():
                     if all(p in sb for p in parts):
                         rooflines[name]["traffic"] = sum(sb[p]["total_bytes"] for p in parts)
                         rooflines[name]["traffic_source"] = "profiles/%s_pmc_traffic.json" % pmc.get("tag")
+                        # (PMC passes are separate rocprofv3 --pmc runs of the same command in another gpurun session, i.e.
+                        # on another MI355X of the same pool: bytes per step are a property of the launches, not of the box)
                         rooflines[name]["traffic_measured_in_run"] = False
+                        rooflines[name]["traffic_box"] = "separate gpurun session (another MI355X of the pool), same command"
         except (OSError, ValueError, KeyError):
             pass
         # dominant stage: the fused SA / FP MLP chains are ONE kernel family on the matrix pipe (their two event brackets are
@@ -1034,8 +1110,8 @@ def main():
                       "fp32 operands and results throughout; the contraction runs as three exact fp16 x fp16 partial products "
                       "per multiply on fp16 MFMA with two fp16 pieces per operand (every SA level and FP levels 0-1 in one fused "
                       "kernel per chain -- SA levels 0-1 and FP level 0 the narrow-chain kernels with the chain's weights in LDS; "
-                      "FP levels 2-3 and the pre-contractions layer by layer; power-of-two range scaling from device-side "
-                      "bounds; PVN3D_MLP_ARITH=bf16x3 selects six bf16 x bf16 partial products with three bf16 pieces, fp32 the "
+                      "FP levels 2-3 and the pre-contractions layer by layer; every chain rescaled diagonally by powers of two "
+                      "on the host (per-row weight scales), activations scaled from device-side bounds; PVN3D_MLP_ARITH=bf16x3 selects six bf16 x bf16 partial products with three bf16 pieces, fp32 the "
                       "fp32-MFMA kernels); all of them are as close "
                       "to an fp64 evaluation as the fp32 FMA chain (tests: 2e-5 of the output scale, measured 5e-7 - 1e-6)")
         out = {
@@ -1054,13 +1130,20 @@ def main():
                                       "(one geometry + one MLP + one vote pass per step inside the timed region; "
                                       "--no-geometry-ahead: every step alone, see value_self_contained_steps)") if geo_ahead
                        else "none (every step stands alone)",
-                       "meanshift_kernel": args.ms_kernel},
+                       "meanshift_kernel": args.ms_kernel,
+                       # the arithmetic of the SA / FP contractions, as its own field (PVN3D_MLP_ARITH)
+                       "arithmetic": mlp_arithmetic_field() if net is not None else None},
             "op_chain_stage_ms_per_step": op_step if net is not None else None,
             "stage_ms_per_step": per_step,
             "dominant_stage": dominant,
-            # the contract's `roofline` is an HBM or MFMA roofline: the largest stage that has one (the fused SA / FP chain
-            # family).  The vote stage -- as long as it, round 5 -- is VALU-issue bound: `roofline_valu` (and `rooflines`)
-            "roofline": rooflines.get(dominant_hm if dominant_hm in rooflines else "ball_query+group"),
+            # Two fixed keys.  `roofline` (the contract's: bound "hbm" | "mfma") = the largest stage that HAS such a roofline,
+            # named in roofline.stage -- the fused SA / FP chain family on the matrix pipe.  `roofline_dominant_stage` = the
+            # roofline of `dominant_stage` whatever bounds it: the vote stage is fp32-VALU / v_exp bound (16 flop per (seed,
+            # point) pair), which is neither of the contract's two bounds; the same object is also under
+            # `roofline_valu` (older readers) and in `rooflines`.
+            "roofline": dict(rooflines.get(dominant_hm if dominant_hm in rooflines else "ball_query+group") or {},
+                             stage=dominant_hm if dominant_hm in rooflines else "ball_query+group"),
+            "roofline_dominant_stage": dict(rooflines.get(dominant) or {}, stage=dominant),
             "roofline_valu": rooflines.get("vote_cluster_pose"),
             "roofline_hbm": rooflines.get("ball_query+group"),
             "rooflines": rooflines,

@@ -108,9 +108,11 @@ class OverlappedGradientReducer(object):
 
     The hooks stay on the parameters but only act between ``arm()`` and ``finalize()``: a backward outside a training
     step (eval-time gradients, a loop that exchanges with ``all_reduce_gradients``) issues no collective, so ranks
-    cannot be left with unmatched all-reduces.  A second backward inside one armed window (gradient accumulation) is
-    supported: a bucket whose all-reduce had already been issued when more gradient arrived is exchanged again from
-    the accumulated ``.grad`` at ``finalize()`` (the early copy is waited for and dropped).
+    cannot be left with unmatched all-reduces.  Gradient accumulation: ``arm(n_backward=k)`` announces k backward
+    passes inside the window; a bucket is issued once, when its parameters have accumulated their k-th gradient (from
+    inside the LAST micro-batch's backward), so every bucket crosses the wire once and the overlap is kept.  More backward
+    passes than announced raise (a rank-local "this bucket is stale" decision would let ranks issue different numbers of
+    collectives -- a deadlock, not an error message).
     """
 
     def __init__(self, parameters, bucket_bytes=64 << 20, group=None, average=True):
@@ -133,19 +135,24 @@ class OverlappedGradientReducer(object):
                 self._bucket_of[id(p)] = bi
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self.launched_during_backward = 0
+        self.collectives_issued = 0         # all-reduces issued over the reducer's life (bench: a run without exchange adds 0)
         self._armed = False
+        self._n_backward = 1
         self._reset()
 
     def _reset(self):
         self._ready = [0] * len(self.buckets)
         self._issued = [False] * len(self.buckets)
-        self._dirty = [False] * len(self.buckets)
         self._pending = []                  # (work, flat, params with a gradient, bucket index)
         self._in_backward = True
 
-    def arm(self):
-        """The next backward() exchanges its buckets as they complete; ``finalize()`` ends the window."""
+    def arm(self, n_backward=1):
+        """The next `n_backward` backward() calls accumulate; buckets are exchanged as they complete in the last of them;
+        ``finalize()`` ends the window."""
+        if n_backward < 1:
+            raise ValueError("n_backward must be >= 1")
         self._reset()
+        self._n_backward = int(n_backward)
         self._armed = True
         return self
 
@@ -156,6 +163,7 @@ class OverlappedGradientReducer(object):
             return
         flat = torch.cat([p.grad.reshape(-1) for p in bk])
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.collectives_issued += 1
         self._pending.append((work, flat, bk, bi))
         if self._in_backward:
             self.launched_during_backward += 1
@@ -166,8 +174,9 @@ class OverlappedGradientReducer(object):
         bi = self._bucket_of[id(p)]
         self._ready[bi] += 1
         if self._issued[bi]:
-            self._dirty[bi] = True          # more gradient arrived after the bucket's copy was sent (accumulation)
-        elif self._ready[bi] == len(self.buckets[bi]):
+            self._armed = False             # (no further collective from this window)
+            raise RuntimeError("more backward passes inside one armed window than announced: arm(n_backward=k)")
+        if self._ready[bi] == len(self.buckets[bi]) * self._n_backward:
             self._issue(bi)
 
     def finalize(self):
@@ -184,10 +193,6 @@ class OverlappedGradientReducer(object):
         n = len(self._pending)
         for work, flat, bk, bi in self._pending:
             work.wait()
-            if self._dirty[bi]:             # the copy predates the last accumulation: exchange the accumulated gradient
-                bk = [p for p in self.buckets[bi] if p.grad is not None]
-                flat = torch.cat([p.grad.reshape(-1) for p in bk])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
                 flat.div_(ws)
             off = 0

@@ -59,9 +59,11 @@ def vote_loss(pred_kp_of, pred_ctr_of, kp_targ_ofst, ctr_targ_ofst, labels):
     return crit(pred_kp_of, kp_targ_ofst, labels).sum() + crit(pred_ctr_of, ctr_targ_ofst, labels).sum()
 
 
-def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_bytes=4 << 20, prefetch=None):
+def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_bytes=4 << 20, prefetch=None, exchange=True):
     """forward + vote loss + backward + gradient all-reduce + optimizer step.  batch: dict(pc (B,N,3+C),
     kp_targ_ofst (B,N,K,3), ctr_targ_ofst (B,N,1,3), labels (B,N,1)).  Returns the (detached) loss.
+    exchange=False: no gradient exchange at all, whatever process group exists (the baseline leg of bench.py's
+    distributed training entry; group=None alone means "the default group", which still exchanges).
     bucket_bytes: gradient all-reduce bucket size.  The voting branch has 14 MB of fp32 gradients, so 4 MiB gives four
     buckets to overlap with backward (the FP levels' -- produced first -- fly while the SA levels are computed); with
     the reference's full model (CNN included: ~160 MB) 32-64 MiB buckets amortise the per-collective latency better.
@@ -94,7 +96,7 @@ def train_step(model, optimizer, batch, autocast_dtype=None, group=None, bucket_
             net._geometry_prefetched = (prefetch, prefetch._version, net.backbone.geometry_ahead(prefetch))
     # gradient buckets are all-reduced from inside backward (post-accumulate-grad hooks): the late layers' buckets are
     # on the wire while the early layers' gradients are still being computed (None: a single process, nothing to do)
-    reducer = sharding.overlapped_reducer(net, bucket_bytes=bucket_bytes, group=group)
+    reducer = sharding.overlapped_reducer(net, bucket_bytes=bucket_bytes, group=group) if exchange else None
     if reducer is not None:
         reducer.arm()                    # the hooks act for this backward only
     try:

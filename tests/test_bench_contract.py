@@ -73,6 +73,15 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     names = {c["name"] for c in d["configs"]}
     assert {"b1_latency", "ycb_multi_instance", "config1_n2048", "train_step", "heavy_tail_votes"} <= names
+    if os.path.basename(lines[-1]) >= "r06":
+        # round 6: the contract's roofline names its stage; the dominant stage's roofline has a fixed key of its own (the
+        # vote stage is VALU-bound: neither "hbm" nor "mfma"); the arithmetic is a field; config 4's per-rank share is a line
+        assert r["stage"] in d["rooflines"] and d["roofline_dominant_stage"]["stage"] == d["dominant_stage"]
+        assert d["roofline_dominant_stage"]["bound"] in ("hbm", "mfma", "valu", "valu_fp32")
+        assert d["config"]["arithmetic"]["name"] in ("fp16x2", "bf16x3", "fp32")
+        assert "config4_per_rank_share" in names
+        c4 = next(c for c in d["configs"] if c["name"] == "config4_per_rank_share")
+        assert c4["frames_per_step"] == 8 and abs(c4["frames_per_s"] - 8e3 / c4["ms_per_step"]) < 1e-6 * c4["frames_per_s"]
 
 
 def test_bench_self_launches_its_ranks_when_asked_for_more_than_one_gpu():

@@ -191,14 +191,31 @@ def _overlap_worker(rank, ws, port, q):
     backward()                                                  # a second step reuses the reducer
     n2 = red.finalize()
     same2 = all(torch.equal(p.grad, b) for p, b in zip(net.parameters(), want))
-    # gradient accumulation inside one armed window: two backward passes, then ONE exchange of the accumulated gradient
+    # gradient accumulation inside one armed window: two ANNOUNCED backward passes, every bucket on the wire ONCE, issued
+    # from inside the second pass
+    for p in params:
+        p.grad = None
+    issued0, during0 = red.collectives_issued, red.launched_during_backward
+    red.arm(n_backward=2)
+    ((net(x) - y) ** 2).mean().backward()
+    after_first = red.collectives_issued - issued0
+    ((net(x) - y) ** 2).mean().backward()
+    n_acc = red.finalize()
+    acc_ok = all(torch.allclose(p.grad, 2 * b, rtol=1e-6, atol=1e-7) for p, b in zip(net.parameters(), want))
+    acc_ok = acc_ok and after_first == 0 and red.collectives_issued - issued0 == n_acc == n and \
+        red.launched_during_backward - during0 >= 1
+    # an unannounced second backward is an error on every rank alike (never a rank-local extra collective)
     for p in params:
         p.grad = None
     red.arm()
     ((net(x) - y) ** 2).mean().backward()
-    ((net(x) - y) ** 2).mean().backward()
+    try:
+        ((net(x) - y) ** 2).mean().backward()
+        acc_ok = False
+    except RuntimeError:
+        pass
+    red._armed = True                                           # (end the window properly: every rank waits for its buckets)
     red.finalize()
-    acc_ok = all(torch.allclose(p.grad, 2 * b, rtol=1e-6, atol=1e-7) for p, b in zip(net.parameters(), want))
     try:
         red.finalize()
         unarmed_raises = False
