@@ -432,6 +432,18 @@ int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst, int v_fir
                        const float* pred_kp_of, const int* inst_frame, const int* inst_cls,
                        const uint8_t* sel, long long sel_inst_stride, float* votes,
                        int* seg_off, int* seg_cnt, void* stream);
+/* The same with the rows per segment as an argument (round 6): segment s starts at row s * seg_stride_rows
+ * (seg_stride_rows >= n_pts; a multiple of 32 keeps the PVN3D_MS_ALIGNED32 promise).  A stride of n_pts = 12288 rows puts
+ * every segment 3 * 2^16 bytes after the previous one, and the iteration kernels' waves -- one fit each, walking their
+ * points at the same pace -- then hit the same memory channels at the same time: 1.26 ms per iteration of the headline
+ * batch against 1.00 ms with 12288 + 32 rows per segment (tools/ms_rate.py).  The host side (_vote_engine.seg_stride_rows)
+ * adds 32 rows whenever the natural stride is a multiple of 1024 rows.  sel / sel_inst_stride: rows of the labels of an
+ * earlier fit batch on the same layout, i.e. sel_inst_stride = (n_kps + 1) * seg_stride_rows. */
+int pvn3d_vote_compact_strided(int n_frames, int n_pts, int seg_stride_rows, int n_kps, int n_inst, int v_first,
+                               int v_count, const float* pcld, const int* mask, const float* ctr_of,
+                               const float* pred_kp_of, const int* inst_frame, const int* inst_cls,
+                               const uint8_t* sel, long long sel_inst_stride, float* votes, int* seg_off,
+                               int* seg_cnt, void* stream);
 
 /* Batched best_fit_transform (pvn3d/lib/utils/basic_utils.py:47-80): for each of n_sets,
  * A (npts,3) -> B (npts,3), T (3,4) float64 row-major [R|t].  valid (n_sets) int or NULL:

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pvn3d_meanshift_workspace_bytes": (_sz, [_i, _i, _i]),
     "pvn3d_meanshift_fit_batch": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _sz, _p, _i, _i, _p]),
     "pvn3d_vote_compact": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p]),
+    "pvn3d_vote_compact_strided": (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p]),
     "pvn3d_best_fit_transform": (_i, [_i, _i, _p, _p, _p, _p, _p]),
     "pvn3d_three_nn_weights": (_i, [ctypes.c_longlong, _p, _p, _p]),
     "pvn3d_three_nn_grid_workspace_bytes": (_sz, [_i, _i]),

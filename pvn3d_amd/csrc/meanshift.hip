@@ -111,7 +111,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
 // workgroup's latency, 22-29 us of a 0.7 ms single-frame call).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void vote_compact_kernel(
-    int n_pts, int n_kps, int v_first, const float* __restrict__ pcld,
+    int n_pts, int seg_stride, int n_kps, int v_first, const float* __restrict__ pcld,
     const int* __restrict__ mask, const float* __restrict__ ctr_of,
     const float* __restrict__ pred_kp_of, const int* __restrict__ inst_frame,
     const int* __restrict__ inst_cls, const uint8_t* __restrict__ sel, long long sel_inst_stride,
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
   const float* O = (v < n_kps) ? pred_kp_of + ((size_t)f * n_kps + v) * n_pts * 3
                                : ctr_of + (size_t)f * n_pts * 3;
   const uint8_t* S = sel ? sel + (size_t)inst * sel_inst_stride : nullptr;
-  float4* out = votes + (size_t)seg * n_pts;
+  float4* out = votes + (size_t)seg * seg_stride;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int span = ((n_pts + 15) / 16 + 63) & ~63;          // points per wave
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void vote_compact_kernel(
     pos += __builtin_popcountll(bal2);
   }
   if (tid == 0) {
-    seg_off[seg] = seg * n_pts;
+    seg_off[seg] = seg * seg_stride;
     seg_cnt[seg] = kept;
   }
 }
@@ -366,9 +366,14 @@ __global__ __launch_bounds__(MS_THREADS) void ms_iter_kernel(
   __shared__ float4 s_pts[MS_CHUNK];
   __shared__ float s_red[3][MS_THREADS / 64];
   __shared__ MsAcc s_part[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
-  const int seg = blockIdx.y;
+  // grid (fits, tiles): the fit index is the FAST one.  The grid is sized for the host's bound on the vote count (all N points
+  // of a cloud); with (tiles, fits) every fit's real tiles were followed by its empty ones -- 24 real + 72 empty at 3072 of
+  // 12288 votes -- and that periodic pattern left a quarter of the chip without real workgroups (the dispatcher deals
+  // consecutive workgroups round-robin over XCDs and shader engines: 1.16 ms per iteration against 0.92 ms with 97 tiles
+  // per fit, tools/ms_rate_real2.py).  Tile-major, the empty workgroups are the tail of the grid.
+  const int seg = blockIdx.x;
   const int n = seg_cnt[seg];
-  const int tile0 = blockIdx.x * (LANES * S);
+  const int tile0 = blockIdx.y * (LANES * S);
   if (tile0 >= n) return;
   unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
   if (t > 1) {
@@ -686,9 +691,13 @@ __global__ __launch_bounds__(64) void ms_iter_sgpr_kernel(
     int* __restrict__ win_it, int stop_on_win) {
   constexpr int S = 2;
   const int sl = threadIdx.x;
+  // item -> (tile, fit), the fit index fast: the tiles beyond a fit's vote count (the grid is sized for the host's bound,
+  // all N points of a cloud) are the TAIL of the grid instead of a periodic pattern inside it (see ms_iter_kernel)
+  const int n_seg = n_items / tiles_per_seg;
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int seg = item / tiles_per_seg;
-    const int tile0 = (item - seg * tiles_per_seg) * (64 * S);
+    const int tile = item / n_seg;
+    const int seg = item - tile * n_seg;
+    const int tile0 = tile * (64 * S);
     const int n = seg_cnt[seg];
     if (tile0 >= n) continue;
     unsigned* ms = maxshift + (size_t)seg * (max_iter + 2);
@@ -1098,6 +1107,22 @@ extern "C" size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_
   return ms_layout(n_seg, total, max_iter, nullptr, nullptr);
 }
 
+static int vote_compact_any(int n_pts, int seg_stride, int n_kps, int n_inst, int v_first, int v_count, const float* pcld,
+                            const int* mask, const float* ctr_of, const float* pred_kp_of, const int* inst_frame,
+                            const int* inst_cls, const uint8_t* sel, long long sel_inst_stride, float* votes,
+                            int* seg_off, int* seg_cnt, void* stream) {
+  if (n_inst <= 0 || v_count <= 0) return 0;
+  if (n_pts <= 0 || seg_stride < n_pts || n_kps < 0 || v_first < 0 || v_first + v_count > n_kps + 1 || !pcld ||
+      !mask || !ctr_of || !votes || !seg_off || !seg_cnt || (v_first < n_kps && !pred_kp_of) ||
+      (long long)seg_stride * n_inst * (n_kps + 1) > 0x7fffffffLL)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(vote_compact_kernel, dim3(n_inst, v_count), dim3(1024), 0,
+                     (hipStream_t)stream, n_pts, seg_stride, n_kps, v_first, pcld, mask, ctr_of, pred_kp_of,
+                     inst_frame, inst_cls, sel, sel_inst_stride, (float4*)votes, seg_off,
+                     seg_cnt);
+  PVN3D_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst, int v_first,
                                   int v_count, const float* pcld, const int* mask,
                                   const float* ctr_of, const float* pred_kp_of,
@@ -1105,16 +1130,21 @@ extern "C" int pvn3d_vote_compact(int n_frames, int n_pts, int n_kps, int n_inst
                                   const uint8_t* sel, long long sel_inst_stride, float* votes,
                                   int* seg_off, int* seg_cnt, void* stream) {
   (void)n_frames;
-  if (n_inst <= 0 || v_count <= 0) return 0;
-  if (n_pts <= 0 || n_kps < 0 || v_first < 0 || v_first + v_count > n_kps + 1 || !pcld ||
-      !mask || !ctr_of || !votes || !seg_off || !seg_cnt || (v_first < n_kps && !pred_kp_of))
-    return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(vote_compact_kernel, dim3(n_inst, v_count), dim3(1024), 0,
-                     (hipStream_t)stream, n_pts, n_kps, v_first, pcld, mask, ctr_of, pred_kp_of,
-                     inst_frame, inst_cls, sel, sel_inst_stride, (float4*)votes, seg_off,
-                     seg_cnt);
-  PVN3D_LAUNCH_CHECK();
-  return 0;
+  return vote_compact_any(n_pts, n_pts, n_kps, n_inst, v_first, v_count, pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls,
+                          sel, sel_inst_stride, votes, seg_off, seg_cnt, stream);
+}
+// Rows per segment as an argument.  With one segment of n_pts = 12288 rows per (instance, keypoint) every segment starts
+// 3 * 2^16 bytes after the previous one: the iteration kernels' waves -- one fit each, all walking their fit's points at
+// the same pace -- then ask the SAME memory channels for their next block at the same time (measured, tools/ms_rate.py:
+// 576 fits of 3072 votes, 1.26 ms per iteration at 12288 rows per segment, 1.00 ms at 12288 + 32, 0.95 ms packed tight).
+extern "C" int pvn3d_vote_compact_strided(int n_frames, int n_pts, int seg_stride_rows, int n_kps, int n_inst, int v_first,
+                                          int v_count, const float* pcld, const int* mask, const float* ctr_of,
+                                          const float* pred_kp_of, const int* inst_frame, const int* inst_cls,
+                                          const uint8_t* sel, long long sel_inst_stride, float* votes, int* seg_off,
+                                          int* seg_cnt, void* stream) {
+  (void)n_frames;
+  return vote_compact_any(n_pts, seg_stride_rows, n_kps, n_inst, v_first, v_count, pcld, mask, ctr_of, pred_kp_of,
+                          inst_frame, inst_cls, sel, sel_inst_stride, votes, seg_off, seg_cnt, stream);
 }
 
 extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
@@ -1158,7 +1188,7 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
   if (flags & PVN3D_MS_FORCE_WHOLE) split = false;
   if (flags & PVN3D_MS_FORCE_SPLIT) split = true;
   const int tile = (split ? 64 : MS_THREADS) * (packed ? 2 : 1);
-  const dim3 grid_it(pvn3d_ceil_div(max_cnt_host, tile), n_seg);
+  const dim3 grid_it(n_seg, pvn3d_ceil_div(max_cnt_host, tile));
   // LDS-free iteration kernel (one wave per 64 S seeds, points as SGPR operands)
   const bool sgpr = (flags & PVN3D_MS_SGPR_POINTS) != 0;
   if (sgpr && !(flags & PVN3D_MS_ALIGNED32)) return (int)hipErrorInvalidValue;   // it reads rows up to roundup32(cnt)

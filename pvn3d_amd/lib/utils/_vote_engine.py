@@ -98,25 +98,36 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     return ctr, labels, iters
 
 
+def seg_stride_rows(n_pts):
+    """Rows a vote segment occupies: n_pts rounded up to 32 (the PVN3D_MS_ALIGNED32 promise), plus 32 when that is a
+    multiple of 1024 rows (16 KiB): segments that start a multiple of 2^14 .. 2^16 bytes apart make the iteration
+    kernels' waves -- one fit each, walking their points at the same pace -- hit the same memory channels at the same time
+    (measured on the headline batch, tools/ms_rate.py: 1.26 ms per iteration at 12288 rows per segment, 1.00 ms at 12320)."""
+    s = (int(n_pts) + 31) // 32 * 32
+    return s + 32 if s % 1024 == 0 else s
+
+
 def vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, v_first, v_count,
                  sel=None, sel_inst_stride=0, out=None):
-    """pvn3d_vote_compact wrapper.  Returns (votes (n_seg*n_pts,4), seg_off, seg_cnt) where
-    n_seg = n_inst*(n_kps+1); only segments v_first..v_first+v_count-1 of each instance are
-    (re)written."""
+    """pvn3d_vote_compact_strided wrapper.  Returns (votes (n_seg*stride,4), seg_off, seg_cnt) where
+    n_seg = n_inst*(n_kps+1) and stride = seg_stride_rows(n_pts); only segments v_first..v_first+v_count-1 of each
+    instance are (re)written.  sel / sel_inst_stride: labels of an earlier fit batch on this layout
+    (sel_inst_stride = (n_kps + 1) * stride)."""
     dev = pcld.device
     F, n_pts = pcld.size(0), pcld.size(1)
     n_kps = pred_kp_of.size(1)
     n_inst = int(inst_frame.numel())
     n_seg = n_inst * (n_kps + 1)
+    stride = seg_stride_rows(n_pts)
     if out is None:
-        votes = torch.empty((n_seg * n_pts, 4), dtype=torch.float32, device=dev)
+        votes = torch.empty((n_seg * stride, 4), dtype=torch.float32, device=dev)
         seg = torch.zeros((2, n_seg), dtype=torch.int32, device=dev)      # one fill; rows = offsets, counts
         seg_off, seg_cnt = seg[0], seg[1]
     else:
         votes, seg_off, seg_cnt = out
     with on_device(dev):
-        check(lib.pvn3d_vote_compact(
-            F, n_pts, n_kps, n_inst, int(v_first), int(v_count), pcld.data_ptr(), mask.data_ptr(),
+        check(lib.pvn3d_vote_compact_strided(
+            F, n_pts, stride, n_kps, n_inst, int(v_first), int(v_count), pcld.data_ptr(), mask.data_ptr(),
             ctr_of.data_ptr(), pred_kp_of.data_ptr(), inst_frame.data_ptr(), inst_cls.data_ptr(),
             sel.data_ptr() if sel is not None else None, int(sel_inst_stride), votes.data_ptr(),
             seg_off.data_ptr(), seg_cnt.data_ptr(), _stream(dev)), "vote_compact")
@@ -177,7 +188,7 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         votes, seg_off, seg_cnt = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame,
                                                inst_cls, 0, K + 1)
         ctr, _, iters = meanshift_fit_batch(votes, seg_off, seg_cnt, N, radius, max_iter,
-                                            poll_every=poll_every, aligned32=(N % 32 == 0), enqueue_limit=async_limit)
+                                            poll_every=poll_every, aligned32=True, enqueue_limit=async_limit)
     else:
         out = vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1)
         votes, seg_off, seg_cnt = out
@@ -185,15 +196,15 @@ def frames_pose_single_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps, cls_id=1,
         sc = seg_cnt.view(F, K + 1)
         c_ctr, labels, it_ctr = meanshift_fit_batch(votes, so[:, K].contiguous(),
                                                     sc[:, K].contiguous(), N, radius, max_iter,
-                                                    poll_every=poll_every, aligned32=(N % 32 == 0),
+                                                    poll_every=poll_every, aligned32=True,
                                                     enqueue_limit=async_limit)
         # keypoint votes filtered by the centre fit's inlier labels (rows of segment K)
-        sel = labels[K * N:]
+        sel = labels[K * seg_stride_rows(N):]
         vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
-                     sel_inst_stride=(K + 1) * N, out=out)
+                     sel_inst_stride=(K + 1) * seg_stride_rows(N), out=out)
         c_kp, _, it_kp = meanshift_fit_batch(votes, so[:, :K].contiguous().view(-1),
                                              sc[:, :K].contiguous().view(-1), N, radius, max_iter,
-                                             poll_every=poll_every, aligned32=(N % 32 == 0),
+                                             poll_every=poll_every, aligned32=True,
                                              enqueue_limit=async_limit)
         ctr = torch.cat([c_kp.view(F, K, 3), c_ctr.view(F, 1, 3)], 1).view(-1, 3)
         iters = torch.cat([it_kp.view(F, K), it_ctr.view(F, 1)], 1).view(-1)
@@ -279,7 +290,7 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     ctr_kernel = "scalar" if single and DEFAULT_KERNEL is None else None
 
     n_seg = n_inst * (K + 1)
-    votes = torch.empty((n_seg * N, 4), dtype=torch.float32, device=dev)
+    votes = torch.empty((n_seg * seg_stride_rows(N), 4), dtype=torch.float32, device=dev)
     seg = torch.zeros((2, n_seg), dtype=torch.int32, device=dev)          # segment offsets, counts
     out = (votes, seg[0], seg[1])
 
@@ -293,7 +304,7 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
         vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
         o_c, n_c = seg_slices(K, K + 1)
         c0, _, it0 = meanshift_fit_batch(votes, o_c, n_c, N, radius, max_iter, poll_every=poll_every,
-                                         aligned32=(N % 32 == 0), enqueue_limit=async_limit, kernel=ctr_kernel)
+                                         aligned32=True, enqueue_limit=async_limit, kernel=ctr_kernel)
         thr = _device_const(("ycb_thr", tuple(np.asarray(radius_lst, np.float64).tolist())), dev,
                             lambda: torch.from_numpy((np.asarray(radius_lst, np.float64) * 0.8).astype(np.float32)))
         if single:
@@ -306,13 +317,13 @@ def frames_pose_multi_class(pcld, mask, ctr_of, pred_kp_of, mesh_kps_all, n_cls,
     vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, K, 1, out=out)
     o_c, n_c = seg_slices(K, K + 1)
     c_ctr, labels, it_ctr = meanshift_fit_batch(votes, o_c, n_c, N, radius, max_iter, poll_every=poll_every,
-                                                aligned32=(N % 32 == 0), enqueue_limit=async_limit, kernel=ctr_kernel)
-    sel = labels[K * N:] if use_ctr_clus_flter else None
+                                                aligned32=True, enqueue_limit=async_limit, kernel=ctr_kernel)
+    sel = labels[K * seg_stride_rows(N):] if use_ctr_clus_flter else None
     vote_compact(pcld, mask, ctr_of, pred_kp_of, inst_frame, inst_cls, 0, K, sel=sel,
-                 sel_inst_stride=(K + 1) * N, out=out)
+                 sel_inst_stride=(K + 1) * seg_stride_rows(N), out=out)
     o_k, n_k = seg_slices(0, K)
     c_kp, _, it_kp = meanshift_fit_batch(votes, o_k, n_k, N, radius, max_iter,
-                                         poll_every=poll_every, aligned32=(N % 32 == 0), enqueue_limit=async_limit)
+                                         poll_every=poll_every, aligned32=True, enqueue_limit=async_limit)
     cls_kps = torch.cat([c_kp.view(n_inst, K, 3), c_ctr.view(n_inst, 1, 3)], 1)
     # iteration counts of every fit batch of the call in one table: columns 0..K are `iters`; the filter pass (whose
     # centres only re-label the mask) is the last column.  Under async_limit a negative count marks a fit that did not
