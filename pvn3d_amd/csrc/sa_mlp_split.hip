@@ -371,9 +371,19 @@ struct WSrc {
 
 // the partial products of one slab (six bf16 / three fp16), smallest terms first; consecutive MFMAs hit different
 // accumulators.  Fragments travel as uint4 (eight 16-bit pieces of consecutive k).
-template <int AR, int NTC, int NT, int NR>
+// TR: the transposed product (activation fragment as the A operand, weight fragment as B -- the two fragment layouts of
+// v_mfma_f32_32x32x16 are the same, so the registers are simply swapped in the instruction): the accumulator then holds
+// lane = output channel, registers = the tile's 32 columns.
+template <int AR, int NTC, int NT, int NR, bool TR = false>
 __device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][s3_np(AR)], const uint4 (&b)[2][s3_np(AR)]) {
-  if (AR == 1) {
+  if (AR == 1 && TR) {
+#define S3_MM(PA, PB)                                                                                                  \
+  _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
+      acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[c][PB]),                          \
+                                                         __builtin_bit_cast(f16x8, a[t][PA]), acc[t][c], 0, 0, 0)
+    S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
+#undef S3_MM
+  } else if (AR == 1) {
 #define S3_MM(PA, PB)                                                                                                  \
   _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
       acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t][PA]),                          \
@@ -404,7 +414,9 @@ __device__ __forceinline__ void acc_bias(f32x16& acc, const float* __restrict__ 
 // PASSES: the last layer's row tiles are worked off in PASSES rounds of 4 * NLAST tiles (512-wide last layers: the
 // accumulators of all 16 tiles would not fit); its input P is only read, so the rounds need no barrier between them,
 // and their max-pool runs on DPP lane shifts instead of LDS patches (P is still being read by the other waves).
-template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR>
+// TRL: the last layer transposed with the max-pool in registers (pool_tr; fp16 x 2 set abstraction, nsample 16 / 32 / 64) --
+// an instantiation of its own, so that neither form carries the other's epilogue in its register budget
+template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR, bool TRL = false>
 struct S3Consumer {
   static constexpr int NP = s3_np(AR);
   static constexpr int CHUNK = s3_chunk(AR);
@@ -584,7 +596,9 @@ struct S3Consumer {
 #pragma unroll
     for (int u = 0; u < RD - 1; ++u) a_load<NTC, NMAX>(R[u], w, u);
   }
-  template <int NTC>
+  // TR (fp16 x 2, the last layer of a set-abstraction chain): the transposed product -- accumulators start at zero (an
+  // inline constant of the first MFMA) and the bias, one value per lane there, is added by pool_tr
+  template <int NTC, bool TR = false>
   __device__ __forceinline__ void layerN(f32x16 (&acc)[NMAX][2], uint4 (&R)[4][NMAX][NP], int l, int boff, int lane,
                                          int tile_base = 0) {
     const int half = lane >> 5, col = lane & 31;
@@ -593,7 +607,16 @@ struct S3Consumer {
     // used to recompute the last tile and drop the result -- matrix-pipe, LDS and L2 traffic for nothing
     if (tile_base + wave >= ((a.M[l] + 31) >> 5)) return;
     const WSrc<NTC> w = wsrc<NTC>(l, slabs, lane, tile_base);
-    init_acc<NTC>(acc, l, boff, half, tile_base);
+    if (TR) {
+#pragma unroll
+      for (int t = 0; t < NTC; ++t)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][c2][r] = 0.f;
+    } else {
+      init_acc<NTC>(acc, l, boff, half, tile_base);
+    }
     BSrc bs = bsrc(P + (size_t)col * a.rs + half * 16, a.ps, 32 * a.rs);
     constexpr int RD = NTC >= 3 ? 2 : 4;
     uint4 b[2][2][NP];
@@ -604,7 +627,7 @@ struct S3Consumer {
     a_load<NTC, NMAX>(R[((U) + RD - 1) % RD], w, (S) + RD - 1);                                        \
     b_ld<(OFFN)>(b[((U) + 1) & 1], bs);                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<AR, NTC, NMAX>(acc, R[(U) % RD], b[(U) & 1]);                                           \
+    mm_slab<AR, NTC, NMAX, NMAX, TR>(acc, R[(U) % RD], b[(U) & 1]);                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
     // (the layer's slab count is padded: P holds zero rows up to a multiple of 32 k, and the fragment reads of the
@@ -702,6 +725,50 @@ struct S3Consumer {
       }
     }
   }
+  // Max over the nsample (16 / 32 / 64) columns of each centre for one row tile of a TRANSPOSED last layer (lane = output
+  // channel 32 mt + (lane & 31), registers = columns 8 j + 4 half + i of the tile, both column tiles): fifteen integer
+  // max per tile in registers -- signed-integer max orders the non-negative floats correctly and ranks every negative one
+  // below them, the 0 in the chain is the ReLU -- one exchange between the two halves of the wave, no LDS, no barrier
+  // (the [32][S3_EPAD] patch round trip it replaces: 4.1 of the 26.6 k cycles of a SA level 2 column block); a centre's
+  // 32 channels of the tile leave as one 128-byte row segment.
+  __device__ __forceinline__ void pool_tr(const f32x16 (&acc)[2], int mt, int boff, int bi, int col0, int lane) {
+    const int half = lane >> 5, col = lane & 31;
+    const int M = a.M[NL - 1], row = mt * 32 + col;
+    const float b = s_bias[boff + row];
+    const float om = s_om[row];
+    const int ns = a.ns;
+    int lo[2], hi[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int k[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) k[r] = __float_as_int(acc[c][r] + b);
+      lo[c] = max(max(max(max(k[0], k[1]), max(k[2], k[3])), max(max(k[4], k[5]), max(k[6], k[7]))), 0);        // columns 0..15
+      hi[c] = max(max(max(max(k[8], k[9]), max(k[10], k[11])), max(max(k[12], k[13]), max(k[14], k[15]))), 0);  // columns 16..31
+    }
+    float* const o = a.out + (size_t)bi * a.m * a.ld_out + a.coff + row;
+    if (ns == 16) {
+      // four centres per 64 columns: (tile c, columns 0..15 | 16..31); each half of the wave stores two of them
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l2 = max(lo[c], __shfl_xor(lo[c], 32, 64)), h2 = max(hi[c], __shfl_xor(hi[c], 32, 64));
+        const int centre = (col0 >> 4) + 2 * c + half;
+        const float v = __int_as_float(half ? h2 : l2) * om;
+        if (row < M && centre < a.m) { o[(size_t)centre * a.ld_out] = v; amax = fmaxf(amax, v); }
+      }
+    } else if (ns == 32) {
+      const int v0 = max(lo[0], hi[0]), v1 = max(lo[1], hi[1]);
+      const int w0 = max(v0, __shfl_xor(v0, 32, 64)), w1 = max(v1, __shfl_xor(v1, 32, 64));
+      const int centre = (col0 >> 5) + half;
+      const float v = __int_as_float(half ? w1 : w0) * om;
+      if (row < M && centre < a.m) { o[(size_t)centre * a.ld_out] = v; amax = fmaxf(amax, v); }
+    } else {
+      const int v0 = max(max(lo[0], hi[0]), max(lo[1], hi[1]));
+      const float v = __int_as_float(max(v0, __shfl_xor(v0, 32, 64))) * om;
+      const int centre = col0 >> 6;
+      if (half == 0 && row < M && centre < a.m) { o[(size_t)centre * a.ld_out] = v; amax = fmaxf(amax, v); }
+    }
+  }
   __device__ __forceinline__ void pool_dpp(const f32x16 (&acc)[2], int mt, int bi, int col0, int lane) {
     if (a.ns == 16) pool_dpp_t<16>(acc, mt, bi, col0, lane);
     else if (a.ns == 32) pool_dpp_t<32>(acc, mt, bi, col0, lane);
@@ -750,7 +817,26 @@ struct S3Consumer {
     const int M = a.M[NL - 1];
     const int mt_total = (M + 31) >> 5;
     float* const out = a.out;
-    if (PASSES > 1) {
+    if constexpr (TRL) {
+      // ---- fp16 x 2 set abstraction with whole 16 / 32 / 64-column centres: the last layer TRANSPOSED, in PASSES rounds of
+      // 4 * NLAST row tiles, max-pool in registers (pool_tr).  P is only read: no barrier between the rounds or before
+      // the pool, and nothing is parked in P for the next block to wait for.
+#pragma unroll 1
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int lane = fresh_lane();
+        const int tile_base = pass * S3_NWC * NLAST;
+        layerN<NLAST, true>(acc, R, NL - 1, boff, lane, tile_base);
+        if (pass + 1 < PASSES) preloadA<NLAST>(R, NL - 1, lane, tile_base + S3_NWC * NLAST);   // under the pool below
+#pragma unroll
+        for (int t = 0; t < NLAST; ++t) {
+          const int mt = tile_base + wave + S3_NWC * t;
+          if (mt < mt_total) pool_tr(acc[t], mt, boff, bi, col0, lane);
+        }
+      }
+      ++blk_no;
+      S3_STAMP(pb + 7);
+      return;
+    } else if (PASSES > 1) {
       // ---- last layer in rounds of 4 * NLAST row tiles; max-pool on DPP, no LDS (set abstraction only)
 #pragma unroll 1
       for (int pass = 0; pass < PASSES; ++pass) {
@@ -869,7 +955,7 @@ struct S3Consumer {
   }
 };
 
-template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR>
+template <bool IS_SA, int N0, int N1, int N2, int PASSES, int AR, bool TRL = false>
 __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
   // 16-byte aligned dynamic LDS (every fragment read is a ds_read_b128: a base that is only 8-byte aligned -- what a
   // static __shared__ object in front of it produces -- turns each of them into a slow misaligned access); the control
@@ -945,7 +1031,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     return;
   }
   // ---------------------------------------------------- MFMA waves
-  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR> c{a, P, ring, s_bias, s_bias + a.bias_all, &ctl, sc, 0.f, lane, wave, 0u, 0u, 0};
+  S3Consumer<IS_SA, N0, N1, N2, PASSES, AR, TRL> c{a, P, ring, s_bias, s_bias + a.bias_all, &ctl, sc, 0.f, lane, wave, 0u, 0u, 0};
   for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x) {
     int bi, bx;
     s3_block_map(a, q, bi, bx);
@@ -1657,14 +1743,18 @@ int s3_launch(S3Args& a, int sig, hipStream_t st, int arith = 0) {
   const int wg_per_cu = (arith == 1 && sig == 111 && 2 * (lds + 512) <= 160 * 1024) ? 2 : 1;
   int grid = min(a.n_blocks, cus * wg_per_cu);
   if (grid >= 8) grid &= ~7;
-#define S3_GO1(SA, A0, A1, A2, PS, AR)                                                                            \
-  do {                                                                                                            \
-    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR>));            \
-    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR>), dim3(grid), dim3(S3_THREADS), lds, st, a);  \
+#define S3_GO2(SA, A0, A1, A2, PS, AR, TRL)                                                                            \
+  do {                                                                                                                 \
+    PVN3D_RETURN_IF_ERR((hipError_t)pvn3d_allow_big_lds(mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR, TRL>));            \
+    hipLaunchKernelGGL((mlp_chain_s3_kernel<SA, A0, A1, A2, PS, AR, TRL>), dim3(grid), dim3(S3_THREADS), lds, st, a);  \
   } while (0)
+#define S3_GO1(SA, A0, A1, A2, PS, AR) S3_GO2(SA, A0, A1, A2, PS, AR, false)
+  // fp16 x 2 set abstraction with whole 16 / 32 / 64-column centres: the instantiation with the transposed last layer
+  const bool trl = arith == 1 && a.is_sa && a.ns >= 16;
 #define S3_GO(SA, A0, A1, A2, PS)                                                                                 \
   do {                                                                                                            \
-    if (arith == 1) S3_GO1(SA, A0, A1, A2, PS, 1);                                                                \
+    if (arith == 1 && SA && trl) S3_GO2(SA, A0, A1, A2, PS, 1, SA);                                               \
+    else if (arith == 1) S3_GO1(SA, A0, A1, A2, PS, 1);                                                           \
     else S3_GO1(SA, A0, A1, A2, PS, 0);                                                                           \
   } while (0)
   if (a.is_sa && sig == 111 && arith == 1) S3_GO1(true, 1, 1, 1, 1, 1);
@@ -1676,6 +1766,7 @@ int s3_launch(S3Args& a, int sig, hipStream_t st, int arith = 0) {
   else return -1;
 #undef S3_GO
 #undef S3_GO1
+#undef S3_GO2
   PVN3D_LAUNCH_CHECK();
   return 0;
 }
