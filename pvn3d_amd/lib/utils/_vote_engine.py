@@ -43,6 +43,7 @@ MS_NO_WINNER_STOP = 128  # PVN3D_MS_NO_WINNER_STOP: run the reference's full ite
 # Iteration-kernel choice used when a call does not name one (None: the library default).  A pipelined evaluator
 # that runs the vote stage beside the fused-MLP kernels sets "sgpr+cap<waves>" here (bench.py does).
 DEFAULT_KERNEL = None
+SGPR_MIN_FITS = 128        # a default of "sgpr" is only followed for batches of more fits than this
 
 
 def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300, labels=None,
@@ -64,8 +65,12 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     flags = MS_ALIGNED32 if aligned32 else 0
     if kernel is None:
         kernel = DEFAULT_KERNEL
-        if kernel is not None and "sgpr" in kernel and not aligned32:
-            kernel = None                       # the default only applies where the layout allows it
+        # the LDS-free default only applies where the layout allows it, and where there are fits enough to fill the chip
+        # with one wave per 128 seeds: below ~128 fits the LDS kernel, whose four waves per tile split the points, is the
+        # shorter launch (tools/ms_rate.py: 64 fits of 3072 votes 0.131 vs 0.173 ms per iteration, 288 fits 0.530 vs 0.519)
+        if kernel is not None and "sgpr" in kernel and (not aligned32 or int(seg_off.numel()) <= SGPR_MIN_FITS):
+            rest = [k for k in kernel.split("+") if k != "sgpr" and not k.startswith("cap")]
+            kernel = "+".join(rest) if rest else None
     if kernel is not None:
         for k in kernel.split("+"):
             if k.startswith("cap"):
