@@ -356,6 +356,59 @@ __device__ __forceinline__ void loader_chunk(const S3Args& a, const LoaderCols<I
   }
 }
 
+// Set abstraction: a chunk in two steps, so that a loader wave can keep TWO chunks' gathers in flight (round 6).  Layer 0
+// of a column block is bound by the loaders' concurrency, not by bandwidth: a wave with one chunk -- eight 16-byte loads per
+// lane, 8 KB -- in flight per ~4.8 k-cycle L2 round trip moves 6.7 B per cycle and CU for all four loaders, which is
+// exactly the 5.4 k cycles the MFMA waves spend waiting in layer 0 of a SA level 2 block (r05_s3_prof.txt: 1.7 k of MFMAs).
+// sa_fetch issues the loads of one chunk into a register set, sa_store scales / splits / writes it; the loop alternates
+// two sets, so the second chunk's round trip runs under the first one's.
+struct SaChunk {
+  float4 v[8];       // full chunk: this lane's 16-byte row segment of eight columns
+  float x[3];        // tail chunk: this lane's column, relative coordinates
+};
+__device__ __forceinline__ void sa_fetch(const S3Args& a, const int (&id)[8], SaChunk& d, int bi, int col0, int lc, int lane) {
+  const int g = lane & 7;
+  if (lc < a.nA) {
+    const float* t = a.tabA + (size_t)bi * a.rowsA * a.ldA + lc * S3_KC + 4 * g;
+    if (S3_DBG(a, 1)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d.v[i] = make_float4(0.25f * id[i], 1.f, 2.f, 3.f);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d.v[i] = *reinterpret_cast<const float4*>(t + (size_t)id[i] * a.ldA);
+    }
+  } else {
+    d.x[0] = d.x[1] = d.x[2] = 0.f;
+    const int gc = col0 + lane;
+    if (gc < a.cols_total) {
+      const int pid = a.idx[(size_t)bi * a.cols_total + gc];
+      const float* p = a.xyz + ((size_t)bi * a.n + pid) * 3;
+      const float* c = a.new_xyz + ((size_t)bi * a.m + gc / a.ns) * 3;
+      d.x[0] = p[0] - c[0]; d.x[1] = p[1] - c[1]; d.x[2] = p[2] - c[2];      // grouped_xyz -= new_xyz
+    }
+  }
+}
+template <int AR>
+__device__ __forceinline__ void sa_store(const S3Args& a, const SaChunk& d, char* slot, int col0, int lc, int lane, float s0) {
+  const int g = lane & 7, cq = lane >> 3;
+  if (lc < a.nA) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cq + 8 * i;
+      const bool ok = col0 + c < a.cols_total;
+      const float x[4] = {ok ? d.v[i].x : 0.f, ok ? d.v[i].y : 0.f, ok ? d.v[i].z : 0.f, ok ? d.v[i].w : 0.f};
+      s3_put4<AR>(slot + c * S3_CS + 8 * g, S3_CPS, x, s0);
+    }
+  } else {
+    // tail chunk: one 16-k slab, rows 0..2 the relative coordinates, the rest zero.  lane -> column lane, rows 0..15
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float y[4] = {q == 0 ? d.x[0] : 0.f, q == 0 ? d.x[1] : 0.f, q == 0 ? d.x[2] : 0.f, 0.f};
+      s3_put4<AR>(slot + lane * S3_CS + 8 * q, S3_CPS, y, s0);
+    }
+  }
+}
+
 // ---- MFMA waves -------------------------------------------------------------------------------------------------------
 // A layer's packed weights as the MFMA loops address them: a wave-uniform (SGPR) base that advances by one slab, plus
 // one 32-bit per-lane byte offset per row tile; the three pieces of a tile sit 1 KiB apart (instruction offsets).
@@ -1006,6 +1059,64 @@ __global__ __launch_bounds__(S3_THREADS, 1) void mlp_chain_s3_kernel(S3Args a) {
     const int j = wave - S3_NWC;
     char* slot = ring + (size_t)j * s3_chunk(AR);
     unsigned uses = 0;                   // how often the slot has been filled
+    // (not for the one-tile-per-wave signature 111, whose 124 registers let two workgroups share a CU)
+    if constexpr (IS_SA && !(N0 == 1 && N1 == 1 && N2 == 1)) {
+      // set abstraction: two chunks of this wave's sequence in flight at any time (see SaChunk)
+      struct Item { int q; unsigned nblk; unsigned base; int lc; int bi; int bx; int ok; };   // (int ok: no padding bytes for struct copies to drag through scratch)
+      auto settle = [&](Item& it) {        // first chunk of this wave at or after block it.q
+        for (; it.q < a.n_blocks; it.q += gridDim.x, it.base += n_chunks, ++it.nblk) {
+          const int lc = (int)((j - it.base) & (S3_RING - 1));     // first local chunk with (base + lc) % 4 == j
+          if (lc < n_chunks) { it.lc = lc; s3_block_map(a, it.q, it.bi, it.bx); it.ok = 1; return; }
+        }
+        it.ok = 0;
+      };
+      auto advance = [&](Item& it) {
+        it.lc += S3_RING;
+        if (it.lc < n_chunks) return;
+        it.q += gridDim.x; it.base += n_chunks; ++it.nblk;
+        settle(it);
+      };
+      auto ids = [&](const Item& it, int (&id)[8]) {           // the gather indices of this lane's eight columns
+        const int cq = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int gc = min(it.bx * S3_COLS + cq + 8 * i, a.cols_total - 1);
+          id[i] = S3_DBG(a, 2) ? gc % a.rowsA : a.idx[(size_t)it.bi * a.cols_total + gc];
+        }
+      };
+      Item it0 = {(int)blockIdx.x, 0u, 0u, 0, 0, 0, 0}, it1;
+      int id0[8], id1[8];
+      int idq0 = -1, idq1 = -1;            // the block whose indices id0 / id1 hold
+      SaChunk dat0, dat1;
+      settle(it0);
+      it1 = it0;
+      if (it1.ok) advance(it1);
+      if (it0.ok) { ids(it0, id0); idq0 = it0.q; sa_fetch(a, id0, dat0, it0.bi, it0.bx * S3_COLS, it0.lc, lane); }
+      if (it1.ok) { ids(it1, id1); idq1 = it1.q; sa_fetch(a, id1, dat1, it1.bi, it1.bx * S3_COLS, it1.lc, lane); }
+      // store `me`'s chunk, then give its register set the chunk after `other`'s (which is still in flight)
+      auto step = [&](Item& me, const Item& other, int (&idm)[8], int& idqm, SaChunk& dm) {
+        if (!me.ok) return;
+        // ring overlaid on P: a block's chunks may only be written once the MFMA waves have left the previous block
+        if (a.ring_off == 0 && me.nblk > 0) lds_wait_ge(&ctl.blk, me.nblk);
+        lds_wait_ge(&ctl.fin[j], S3_NWC * uses);          // every MFMA wave is done with the slot's previous chunk
+        sa_store<AR>(a, dm, slot, me.bx * S3_COLS, me.lc, lane, sc.s_in[0]);
+        ++uses;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ctl.rdy[j], me.base + me.lc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        Item nx = other;
+        if (nx.ok) advance(nx);
+        me = nx;
+        if (nx.ok) {
+          if (idqm != nx.q) { ids(nx, idm); idqm = nx.q; }
+          sa_fetch(a, idm, dm, nx.bi, nx.bx * S3_COLS, nx.lc, lane);
+        }
+      };
+      while (it0.ok || it1.ok) {           // (the two sets alternate: it0 is the earlier chunk at the top of a pass)
+        step(it0, it1, id0, idq0, dat0);
+        step(it1, it0, id1, idq1, dat1);
+      }
+      return;
+    }
     unsigned base = 0;                   // chunk number of the current block's first chunk
     unsigned blocks_done = 0;
     for (int q = blockIdx.x; q < a.n_blocks; q += gridDim.x, base += n_chunks, ++blocks_done) {
