@@ -429,6 +429,22 @@ def _mlp_flags():
     return 0 if NARROW_KERNELS else 1          # PVN3D_MLP_NO_NARROW
 
 
+def invalidate_table_caches(t):
+    """Drop the abs-max bound and the h16 copy cached on tensor object `t` (table_absmax / table_h16 / seed_absmax).
+    The caches are keyed on (data_ptr, shape, t._version); _version only moves on torch in-place ops, so a table that is
+    REWRITTEN through a raw pointer -- a kernel of this library writing into a persistent buffer, a HIP-graph replay into a
+    static tensor -- while the same view object is reused keeps its old bound and its old h16 copy.  A bound that is too
+    small is not harmless: the scaled operand then exceeds fp16's range.  Pointnet2MSG builds fresh views every forward and
+    is not affected; callers of sa_mlp_maxpool / fp_interp_mlp that keep feeding one tensor object whose contents they
+    rewrite out of torch's sight call this after every rewrite."""
+    for name in ("_pvn3d_absmax", "_pvn3d_h16", "_pvn3d_bound"):
+        if hasattr(t, name):
+            try:
+                delattr(t, name)
+            except AttributeError:
+                pass
+
+
 def table_absmax(base, rows, c, ld):
     """Device float32[1] holding max|x| over the point-major table (rows, c) at `base` (row stride ld): the input bound
     the fp16 x 2 kernels scale by (include/pvn3d_hip.h).  One reduction per table: the result is cached on the tensor
