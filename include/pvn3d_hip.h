@@ -352,6 +352,15 @@ int pvn3d_split_gemm2(int n_points, int n_out, int slabs, const void* x_h16, con
                       float w_scale, const float* w_row_mul, const float* bias_padded, int relu, const float* z, int ldz,
                       int z_points_per_frame, int z_rows_per_frame, const int* idx, const float* weight, float* out_f32,
                       int ld_out, float* out_absmax, void* out_h16, int slabs_out, const float* out_bound, void* stream);
+/* pvn3d_split_gemm2 runs the LDS-DMA kernel (round 6: operands global -> LDS directly, three 16-k stages in a ring, tiles
+ * of 128 channels x 256 points when those still fill the chip, else x 128 points); pvn3d_split_gemm2_tile128 is the same
+ * product on the round-5 kernel (register-staged 128 x 128 tiles): the MFMA order per accumulator is the same, the results
+ * are bit-identical -- the cross-check of the DMA ordering (tests/test_gpu_ops.py). */
+int pvn3d_split_gemm2_tile128(int n_points, int n_out, int slabs, const void* x_h16, const float* x_bound, const void* w_h16,
+                              float w_scale, const float* w_row_mul, const float* bias_padded, int relu, const float* z,
+                              int ldz, int z_points_per_frame, int z_rows_per_frame, const int* idx, const float* weight,
+                              float* out_f32, int ld_out, float* out_absmax, void* out_h16, int slabs_out,
+                              const float* out_bound, void* stream);
 int pvn3d_bound_affine(float* out, const float* a, float ca, const float* b, float cb, float c0, void* stream);
 
 /* (b, c, n) -> (b, n, ld_out) with out[(b*n + j)*ld_out + ch] = in[(b*c + ch)*n + j]. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "pvn3d_absmax": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p]),
     "pvn3d_split_rows2": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _p, _i, _p]),
     "pvn3d_split_gemm2": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
+    "pvn3d_split_gemm2_tile128": (_i, [_i, _i, _i, _p, _p, _p, _f, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
     "pvn3d_bound_affine": (_i, [_p, _p, _f, _p, _f, _f, _p]),
     "pvn3d_split_rows": (_i, [ctypes.c_longlong, _i, _p, _i, _p, _i, _p]),
     "pvn3d_split_gemm": (_i, [_i, _i, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p]),
