@@ -1614,6 +1614,82 @@ def test_split_gemm2_c_abi(dev):
         assert lib.pvn3d_split_rows2(P, K, X.data_ptr(), K, None, xs.data_ptr(), S, st) != 0
 
 
+@pytest.mark.parametrize("P,N,K,zm,h16_out", [
+    (64 * 512, 512, 512, 0, False),        # 4 x 128 tiles of 256 points (the wide form), fp32 out + abs-max
+    (64 * 512, 512, 256, 128, True),       # wide form with the interpolated table and the h16 output
+    (64 * 128, 512, 1024, 0, False),       # 128-point tiles (too few wide tiles to fill the chip), 64 stages
+    (8 * 1024 - 77, 200, 96, 512, True),   # ragged points / channels / contraction, both outputs' edges
+    (1000, 384, 32, 0, False),             # two stages only: the ring's prologue and drain
+])
+def test_split_gemm_lds_dma_kernel_equals_the_register_staged_kernel_bit_for_bit(dev, P, N, K, zm, h16_out):
+    """pvn3d_split_gemm2 (round 6: operands global -> LDS by DMA, three stages in a ring, swizzle on the source side,
+    waits counted by hand) against pvn3d_split_gemm2_tile128 (the round-5 kernel: register-staged, compiler-counted
+    waits).  Both add the partial products of a slab to an accumulator in the same order, so every output BIT is the
+    same -- a stage read before its DMA landed, a stage overwritten before its last read or a wrong swizzle would show as
+    different bits.  Six fresh operand sets per shape, the later ones while a copy kernel on another stream competes for
+    the memory system (the DMA's landing times move); fp32 rows, h16 rows and abs-max compared byte for byte."""
+    import math
+    from pvn3d_amd._lib import lib
+    st = torch.cuda.current_stream(dev).cuda_stream
+    S = (K + 31) // 32 * 2
+    NP = (N + 127) // 128 * 128
+    side = torch.cuda.Stream(device=dev)
+    big = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    n_per = P // 8 if P % 8 == 0 else P
+    for rep in range(6):
+        g = torch.Generator(device=dev).manual_seed(100 * rep + K)
+        x = torch.randn(P, K, device=dev, generator=g) * 3.0
+        w = torch.randn(NP, K, device=dev, generator=g) / K ** 0.5
+        w[N:] = 0
+        xb, wb = x.abs().max().reshape(1).clone(), w.abs().max().reshape(1).clone()
+        xs = torch.empty(P * S * 64, dtype=torch.uint8, device=dev)
+        ws = torch.empty(NP * S * 64, dtype=torch.uint8, device=dev)
+        assert lib.pvn3d_split_rows2(P, K, x.data_ptr(), K, xb.data_ptr(), xs.data_ptr(), S, st) == 0
+        assert lib.pvn3d_split_rows2(NP, K, w.data_ptr(), K, wb.data_ptr(), ws.data_ptr(), S, st) == 0
+        w_scale = 2.0 ** (14 - math.frexp(float(wb))[1])
+        rm = (2.0 ** torch.randint(-3, 4, (NP,), device=dev, generator=g)).float()
+        bias = torch.randn(NP, device=dev, generator=g)
+        bias[N:] = 0
+        z = idx = wgt = None
+        if zm:
+            z = torch.randn((P + n_per - 1) // n_per * zm, NP, device=dev, generator=g)
+            z[:, N:] = 0
+            idx = torch.randint(0, zm, (P, 3), device=dev, dtype=torch.int32, generator=g)
+            wgt = torch.rand(P, 3, device=dev, generator=g)
+        S_out = NP // 16
+        ob = torch.full((1,), 256.0, device=dev)
+        res = {}
+        for key, fn in (("dma", lib.pvn3d_split_gemm2), ("tile128", lib.pvn3d_split_gemm2_tile128)):
+            out = torch.full((P, N), float("nan"), device=dev)
+            oh = torch.zeros(P * S_out * 64, dtype=torch.uint8, device=dev) if h16_out else None
+            am = torch.zeros(1, device=dev)
+            if rep >= 3:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big[: 32 << 20].copy_(big[32 << 20:])
+            assert fn(P, N, S, xs.data_ptr(), xb.data_ptr(), ws.data_ptr(), w_scale, rm.data_ptr(), bias.data_ptr(), 1,
+                      z.data_ptr() if zm else None, NP, n_per, zm, idx.data_ptr() if zm else None,
+                      wgt.data_ptr() if zm else None, out.data_ptr(), N, am.data_ptr(), oh.data_ptr() if h16_out else None,
+                      S_out, ob.data_ptr() if h16_out else None, st) == 0
+            torch.cuda.current_stream(dev).wait_stream(side)
+            res[key] = (out, oh, am)
+        torch.cuda.synchronize(dev)
+        a, b = res["dma"], res["tile128"]
+        assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), "fp32 rows differ in run %d" % rep
+        assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+        if h16_out:
+            assert torch.equal(a[1], b[1]), "h16 rows differ in run %d" % rep
+        if rep == 0:
+            ref = x.double() @ (w[:N].double() * rm[:N].double()[:, None]).T
+            if zm:
+                f = torch.arange(P, device=dev) // n_per
+                rows = z.double()[(f[:, None] * zm + idx.long())]
+                ref = ref + (rows[:, :, :N] * wgt.double()[:, :, None]).sum(1)
+            ref = torch.relu(ref + bias[:N].double())
+            assert float((a[0].double() - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-6
+
+
 @pytest.mark.parametrize("gain,outlier", [(2.0 ** 20, 0.0), (2.0 ** -20, 0.0), (1.0, 3.0e7), (1.0e-3, 5.0e4)])
 def test_fp16x2_chains_keep_fp32_accuracy_over_extreme_operand_ranges(dev, gain, outlier):
     """fp16 has 5 exponent bits: the two-piece fp16 chains scale every operand by an exact power of two taken from a
