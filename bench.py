@@ -406,6 +406,38 @@ def device_copy_bandwidth(dev):
                 unit="GB/s", bytes=1 << 30, note="copy counts read + write bytes")
 
 
+def graph_pipeline_ms(net, dev, frames, steps=40, seed_base=7100):
+    """A stream of `frames`-frame batches through lib/pipeline.py::GraphedPipeline (one HIP-graph replay per batch: feature
+    path of batch i || xyz-only geometry of batch i+1 || vote -> cluster -> pose of batch i).  Four different batches take
+    turns; the first round is checked against the eager calls (features and poses bit for bit).  -> dict."""
+    from pvn3d_amd.lib.pipeline import GraphedPipeline
+    off = StageTimer(False)
+    batches = []
+    for s in range(4):
+        b = make_inputs(frames, 12288, 3072, dev, seed_base=seed_base + 100 * s)
+        b["pc"] = torch.cat([b["pcld"], b["feats"].transpose(1, 2)], 2).contiguous()
+        batches.append(b)
+    post = lambda b: (b["pcld"], b["mask"], b["ctr_of"].unsqueeze(1) if b["ctr_of"].dim() == 3 else b["ctr_of"], b["pred_kp_of"])
+    pipe = GraphedPipeline(net, batches[0]["pc"], post=post(batches[0]), obj_id=1)
+    same = True
+    for s, b in enumerate(batches):
+        feats, res = pipe(b["pc"], pc_next=batches[(s + 1) % 4]["pc"], post=post(b))
+        feats, poses = feats.clone(), res["poses"].clone()
+        with torch.no_grad():
+            want = net(b["pc"])
+        same = same and bool(torch.equal(feats, want)) and bool(torch.equal(poses, run_postproc(b, off, 4)["poses"]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        b = batches[k % 4]
+        pipe(b["pc"], pc_next=batches[(k + 1) % 4]["pc"], post=post(b))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return dict(ms_per_step=ms, frames_per_s=frames * 1e3 / ms, identical_to_eager_calls=same, fallbacks=pipe.fallbacks,
+                note="lib/pipeline.py::GraphedPipeline: one graph replay per batch, the next batch's FPS / ball query / "
+                     "three_nn beside this batch's MLP kernels and vote stage; bounded MeanShift iterations, one host read")
+
+
 def per_rank_share_entry(net, dev, poll_every, frames=8, steps=20, warm=5):
     """What one rank of BASELINE config 4 runs: `frames` frames per step through the headline's pipelined step (MLP feature
     path on a side stream with the NEXT step's xyz-only geometry enqueued ahead of it, vote -> cluster -> pose on the
@@ -447,6 +479,7 @@ def per_rank_share_entry(net, dev, poll_every, frames=8, steps=20, warm=5):
     return dict(name="config4_per_rank_share", workload="BASELINE config 4 as ONE of its 8 ranks runs it: %d frames per step "
                 "(64 frames sharded 8-way), N=12288, n_obj=3072, K=8; the headline's three-stream pipelined step" % frames,
                 frames_per_step=frames, ms_per_step=ms, frames_per_s=frames * 1e3 / ms, stage_ms_per_step_serial=stage,
+                graph_pipeline=graph_pipeline_ms(net, dev, frames),
                 implied_8_gpu_frames_per_s_if_ranks_do_not_interfere=8 * frames * 1e3 / ms,
                 note="the 8-GPU figure is arithmetic on a 1-GPU measurement (the driver measures the real curve); the only "
                      "cross-rank step is one all-gather of 48 floats per frame",
@@ -507,6 +540,7 @@ def extra_configs(net, dev, poll_every, with_cpu):
                                       pointnet2_msg_graph=ms_g, both_serial_graph=ms_gab, fps_level0=ms_fps,
                                       vote_cluster_pose_graph=ms_bg, both_serial_both_graphs=ms_gg),
                     frames_per_s=1e3 / ms_ab, meanshift_iters_max=int(res["iters"].max().item()),
+                    stream_of_single_frames=graph_pipeline_ms(net, dev, 1, seed_base=7200) if net is not None else None,
                     pose_err_vs_ground_truth=pose_err(res, inp["frames"])))
 
     # (i') BASELINE config 4's per-rank share: 64 frames sharded 8-way = 8 frames per GPU per step

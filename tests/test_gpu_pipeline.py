@@ -1,0 +1,87 @@
+"""lib/pipeline.py::GraphedPipeline -- one HIP-graph replay per batch of a stream (feature path of batch i || xyz-only
+geometry of batch i+1 || vote -> cluster -> pose of batch i) -- against the eager calls it replaces: the reference's
+per-frame chain Pointnet2MSG forward (pvn3d/lib/pvn3d.py:46-154) and cal_frame_poses_lm
+(pvn3d/lib/utils/pvn3d_eval_utils.py:199-262).  Features and poses must be the same BITS as the eager calls for every
+batch of the stream, whatever the replay order, with and without the promise "the next call's batch is pc_next"."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(dev, frames, n, seeds, sig_out=None):
+    from pvn3d_amd import synth
+    out = []
+    for s in seeds:
+        kw = {} if sig_out is None else {"sig_out": sig_out}
+        fr = [synth.synth_frame(frame=s + i, n_pts=n, n_obj=n // 4, **kw) for i in range(frames)]
+        t = lambda k, dt: torch.from_numpy(np.stack([f[k] for f in fr]).astype(dt)).to(dev)
+        b = dict(pcld=t("pcld", np.float32), mask=t("mask", np.int32), pred_kp_of=t("pred_kp_of", np.float32))
+        c = t("ctr_of", np.float32)
+        b["ctr_of"] = c.unsqueeze(1) if c.dim() == 3 else c
+        feats = t("feats", np.float32)
+        b["pc"] = torch.cat([b["pcld"], feats.transpose(1, 2)], 2).contiguous()
+        out.append(b)
+    return out
+
+
+def _post(b):
+    return (b["pcld"], b["mask"], b["ctr_of"], b["pred_kp_of"])
+
+
+def _eager(net, b):
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    with torch.no_grad():
+        f = net(b["pc"])
+    r = ev.cal_batch_poses_lm(*_post(b), True, 2, False, 1, poll_every=4)
+    return f, r
+
+
+@pytest.mark.parametrize("frames", [1, 3])
+def test_graphed_pipeline_replays_equal_the_eager_calls_bit_for_bit(dev, frames):
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pipeline import GraphedPipeline
+    torch.manual_seed(3)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    bs = _batches(dev, frames, 12288, [8100, 8200, 8300])
+    want = [_eager(net, b) for b in bs]
+    want = [(f.clone(), r["poses"].clone(), r["cls_kps"].clone()) for f, r in want]
+    pipe = GraphedPipeline(net, bs[0]["pc"], post=_post(bs[0]), obj_id=1)
+    # a stream in order, twice round (the handle prepared by the previous replay is the one each replay uses) ...
+    order = [0, 1, 2, 0, 1, 2]
+    for k, i in enumerate(order):
+        nxt = bs[order[k + 1]]["pc"] if k + 1 < len(order) else None
+        f, r = pipe(bs[i]["pc"], pc_next=nxt, post=_post(bs[i]))
+        assert torch.equal(f, want[i][0]), "features of batch %d (call %d) differ from the eager forward" % (i, k)
+        assert torch.equal(r["poses"], want[i][1]) and torch.equal(r["cls_kps"], want[i][2])
+    # ... the last call named no successor: the next one computes its own geometry first ...
+    f, r = pipe(bs[2]["pc"], pc_next=bs[1]["pc"], post=_post(bs[2]))
+    assert torch.equal(f, want[2][0]) and torch.equal(r["poses"], want[2][1])
+    # ... and a caller that breaks the promise says so (primed=False) and still gets the right answer
+    f, r = pipe(bs[0]["pc"], pc_next=None, post=_post(bs[0]), primed=False)
+    assert torch.equal(f, want[0][0]) and torch.equal(r["poses"], want[0][1])
+    assert pipe.fallbacks == 0
+    with pytest.raises(RuntimeError):
+        pipe(bs[0]["pc"][:, :4096], post=_post(bs[0]))
+    with pytest.raises(RuntimeError):
+        pipe(bs[0]["pc"])                      # captured with a vote stage: its inputs are required
+
+
+def test_graphed_pipeline_falls_back_to_the_polled_vote_stage_when_fits_do_not_finish(dev):
+    """Votes with 10 % outliers of sigma = 30 cm keep some fits iterating far beyond the graph's bounded launch sequence:
+    the replay reports it (one host read) and the call repeats the vote stage through the polled path -- same poses as
+    the eager call."""
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pipeline import GraphedPipeline
+    torch.manual_seed(3)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    bs = _batches(dev, 2, 12288, [8400, 8500], sig_out=0.30)
+    want = [_eager(net, b) for b in bs]
+    assert max(int(r["iters"].max()) for _, r in want) > 8, "the fixture no longer exceeds the bounded launch sequence"
+    want = [(f.clone(), r["poses"].clone()) for f, r in want]
+    pipe = GraphedPipeline(net, bs[0]["pc"], post=_post(bs[0]), obj_id=1, async_limit=8)
+    for k, i in enumerate([0, 1, 0]):
+        f, r = pipe(bs[i]["pc"], pc_next=bs[1 - i]["pc"], post=_post(bs[i]))
+        assert torch.equal(f, want[i][0]) and torch.equal(r["poses"], want[i][1])
+    assert pipe.fallbacks == 3
