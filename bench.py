@@ -421,7 +421,7 @@ def graph_pipeline_ms(net, dev, frames, steps=40, seed_base=7100):
     pipe = GraphedPipeline(net, batches[0]["pc"], post=post(batches[0]), obj_id=1)
     same = True
     for s, b in enumerate(batches):
-        feats, res = pipe(b["pc"], pc_next=batches[(s + 1) % 4]["pc"], post=post(b))
+        feats, res = pipe(b["pc"], pc_next=batches[(s + 1) % 4]["pc"], pc_next2=batches[(s + 2) % 4]["pc"], post=post(b))
         feats, poses = feats.clone(), res["poses"].clone()
         with torch.no_grad():
             want = net(b["pc"])
@@ -430,12 +430,13 @@ def graph_pipeline_ms(net, dev, frames, steps=40, seed_base=7100):
     t0 = time.perf_counter()
     for k in range(steps):
         b = batches[k % 4]
-        pipe(b["pc"], pc_next=batches[(k + 1) % 4]["pc"], post=post(b))
+        pipe(b["pc"], pc_next=batches[(k + 1) % 4]["pc"], pc_next2=batches[(k + 2) % 4]["pc"], post=post(b))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return dict(ms_per_step=ms, frames_per_s=frames * 1e3 / ms, identical_to_eager_calls=same, fallbacks=pipe.fallbacks,
-                note="lib/pipeline.py::GraphedPipeline: one graph replay per batch, the next batch's FPS / ball query / "
-                     "three_nn beside this batch's MLP kernels and vote stage; bounded MeanShift iterations, one host read")
+                note="lib/pipeline.py::GraphedPipeline (depth 3): one graph replay per batch -- the first-level FPS run of the "
+                     "batch after next, the next batch's ball queries / three_nn and this batch's MLP kernels and vote stage "
+                     "beside each other; bounded MeanShift iterations, one host read per call")
 
 
 def per_rank_share_entry(net, dev, poll_every, frames=8, steps=20, warm=5):

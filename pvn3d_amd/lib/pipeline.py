@@ -1,18 +1,23 @@
 """GraphedPipeline -- ONE HIP-graph replay per batch for a stream of same-shaped batches (eval mode):
 
-    step i:   Pointnet2MSG feature path of batch i   (stream A; on the geometry batch i-1's replay prepared)
-            | xyz-only geometry of batch i+1          (geometry stream: FPS, ball query, three_nn of every level)
+    step i:   Pointnet2MSG feature path of batch i   (stream A; on the geometry the previous replay prepared)
+            | xyz-only geometry of batch i+1          (geometry stream: gathers, ball query, three_nn of every level,
+            |                                          on the FPS run the previous replay made)
+            | first-level FPS of batch i+2            (sampling stream; depth = 3 -- with depth = 2 the geometry of batch
+            |                                          i+1 includes its own FPS run)
             | vote -> MeanShift -> Kabsch of batch i   (stream B; the heads' outputs the caller hands in)
 
 The reference evaluates one frame per call (pvn3d/common.py:41 `test_mini_batch_size = 1`; the per-frame chain is
 pvn3d/lib/pvn3d.py:46-154 followed by lib/utils/pvn3d_eval_utils.py:199-262), and BASELINE config 4 gives each of 8 ranks
 8 frames per step.  At those sizes the eager three-stream step (bench.py) is bound by its ~110 launches, one host poll
 per MeanShift batch, and the FPS chain (one wave per cloud, 1.5 ms whatever the frame count) standing in front of the
-frame's own MLP kernels.  Here FPS of the NEXT batch runs beside the MLP kernels and the vote stage of THIS batch, and
-the launches are one graph: the step costs max(geometry, feature path + vote) instead of their sum plus launch time.
+frame's own MLP kernels.  Here the FPS run (1.5 of the geometry's 2.1 ms: serial in the samples, one wave per cloud) of
+the batch after next, the rest of the next batch's geometry, and this batch's MLP kernels and vote stage run beside each
+other, and the launches are one graph: the step costs max(FPS, rest of the geometry, feature path, vote) instead of
+their sum plus launch time.
 
     pipe = GraphedPipeline(net, pc0, post=(pcld, mask, ctr_of, pred_kp_of), obj_id=1)
-    feats, res = pipe(pc_i, pc_next=pc_i1, post=(...))     # every call; pc_next of call i must be pc of call i+1
+    feats, res = pipe(pc_i, pc_next=pc_i1, pc_next2=pc_i2, post=(...))    # every call; call i+1 must be for pc_i1
 
 The geometry handle lives in persistent buffers: the captured sequence computes batch i+1's handle into the graph's
 own memory and copies it over the persistent one after the feature path has read it.  `feats` is the captured output
@@ -41,34 +46,41 @@ def _with_event(h, ev):
 
 
 class GraphedPipeline(object):
-    def __init__(self, net, pc, post=None, obj_id=1, async_limit=8, warmup=2):
-        assert not net.training and pc.is_cuda
+    def __init__(self, net, pc, post=None, obj_id=1, async_limit=8, warmup=2, depth=3):
+        assert not net.training and pc.is_cuda and depth in (2, 3)
         dev = pc.device
-        self.net, self.obj_id, self.async_limit = net, obj_id, async_limit
-        self.pc_cur, self.pc_next = pc.clone(), pc.clone()
+        self.net, self.obj_id, self.async_limit, self.depth = net, obj_id, async_limit, depth
+        self.pc_cur, self.pc_next, self.pc_next2 = pc.clone(), pc.clone(), pc.clone()
         self.post = [t.clone() for t in post] if post is not None else None
         self.fallbacks = 0
-        self._have_geometry_of = None          # data_ptr-independent: the caller's promise is checked by value on demand
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
+        self._samp_stream = torch.cuda.Stream(device=dev)
+        self._vote_stream = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side), torch.no_grad():      # allocator pools, packed weights, LDS opt-ins: off the capture
             for _ in range(warmup):
-                net(self.pc_cur, geometry=net.geometry_ahead(self.pc_cur))
+                net(self.pc_cur, geometry=net.geometry_ahead(self.pc_cur, presampled=net.sampling_ahead(self.pc_cur)))
                 if self.post is not None:
                     self._vote(async_limit)
             self.handle = net.geometry_ahead(self.pc_cur)    # the persistent handle (ordinary allocations, kept alive here)
+            sel, dmax, _e = net.sampling_ahead(self.pc_next)
+            self.pre = [sel, dmax]                           # the persistent first-level FPS run (depth 3)
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
         self._persist = _handle_tensors(self.handle)
-        self._vote_stream = torch.cuda.Stream(device=dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             cap = torch.cuda.current_stream(dev)
             start = torch.cuda.Event()
             start.record(cap)
-            # (1) the next batch's geometry: forks from the capture stream here, runs on the network's geometry stream
-            nxt = net.geometry_ahead(self.pc_next)
+            # (1) geometry: the batch after next's FPS run on the sampling stream, the next batch's queries on the geometry
+            #     stream (both fork from the capture stream here)
+            if depth == 3:
+                pre_new = net.sampling_ahead(self.pc_next2, stream=self._samp_stream)
+                nxt = net.geometry_ahead(self.pc_next, presampled=(self.pre[0], self.pre[1], start))
+            else:
+                nxt = net.geometry_ahead(self.pc_next)
             # (2) this batch's vote stage on its own stream
             if self.post is not None:
                 self._vote_stream.wait_stream(cap)
@@ -77,14 +89,21 @@ class GraphedPipeline(object):
                     self.unfinished = self.res["unfinished_min"]
             # (3) this batch's feature path on the persistent handle
             self.out = net(self.pc_cur, geometry=_with_event(self.handle, start))
-            # (4) join; the next handle replaces the persistent one (the feature path is done with it: same stream)
+            # (4) join; the new handle / FPS run replace the persistent ones (their readers are done: the feature path ran
+            #     on this stream, the geometry stream's events have been waited for)
             for (_g, ev) in list(nxt["sa"]) + list(nxt["fp"]):
                 cap.wait_event(ev)
             for dst, src in zip(self._persist, _handle_tensors(nxt)):
                 dst.copy_(src)
+            if depth == 3:
+                cap.wait_event(pre_new[2])
+                for dst, src in zip(self.pre, pre_new[:2]):
+                    if dst is not None:
+                        dst.copy_(src)
             if self.post is not None:
                 cap.wait_stream(self._vote_stream)
-        self._next_valid = False
+        self._handle_valid = False
+        self._pre_valid = False
 
     def _vote(self, limit, poll_every=8):
         p, m, c, k = self.post
@@ -99,26 +118,43 @@ class GraphedPipeline(object):
                 cur.wait_event(ev)
             for dst, src in zip(self._persist, _handle_tensors(h)):
                 dst.copy_(src)
-        self._next_valid = True
+        self._handle_valid = True
 
-    def __call__(self, pc, pc_next=None, post=None, primed=None):
+    def prime_sampling(self, pc_next):
+        """Compute `pc_next`'s first-level FPS run into the persistent buffers (depth 3; first batch or after a gap)."""
+        with torch.no_grad():
+            sel, dmax, ev = self.net.sampling_ahead(pc_next)
+            torch.cuda.current_stream(pc_next.device).wait_event(ev)
+            for dst, src in zip(self.pre, (sel, dmax)):
+                if dst is not None:
+                    dst.copy_(src)
+        self._pre_valid = True
+
+    def __call__(self, pc, pc_next=None, pc_next2=None, post=None, primed=None):
         """-> (features (B, 128, N): the captured output buffer, vote result dict or None).
-        pc_next: the batch of the NEXT call (its geometry is prepared by this replay); None = this is the last batch
-        (the replay then prepares `pc` again, harmlessly).  primed: override the bookkeeping that decides whether the
-        persistent handle already belongs to `pc` (default: it does iff the previous call named a pc_next)."""
+        pc_next / pc_next2: the batches of the NEXT call and the one after (their geometry / FPS run are prepared by this
+        replay); None = the stream ends (the replay then prepares `pc` again, harmlessly).  primed: override the
+        bookkeeping that decides whether the persistent buffers already belong to `pc` / `pc_next` (default: they do iff
+        the previous call named them)."""
         if pc.shape != self.pc_cur.shape:
             raise RuntimeError("GraphedPipeline was captured for shape %s" % (tuple(self.pc_cur.shape),))
-        if not (self._next_valid if primed is None else primed):
+        if self.post is not None and post is None:
+            raise RuntimeError("this pipeline was captured with a vote stage: pass post=(pcld, mask, ctr_of, pred_kp_of)")
+        ok = primed if primed is not None else None
+        if not (self._handle_valid if ok is None else ok):
             self.prime(pc)
+        nxt = pc if pc_next is None else pc_next
+        if self.depth == 3 and not (self._pre_valid if ok is None else ok):
+            self.prime_sampling(nxt)
         self.pc_cur.copy_(pc)
-        self.pc_next.copy_(pc if pc_next is None else pc_next)
+        self.pc_next.copy_(nxt)
+        self.pc_next2.copy_(nxt if pc_next2 is None else pc_next2)
         if self.post is not None:
-            if post is None:
-                raise RuntimeError("this pipeline was captured with a vote stage: pass post=(pcld, mask, ctr_of, pred_kp_of)")
             for dst, src in zip(self.post, post):
                 dst.copy_(src)
         self.graph.replay()
-        self._next_valid = pc_next is not None
+        self._handle_valid = pc_next is not None
+        self._pre_valid = self.depth == 3 and pc_next is not None and pc_next2 is not None
         res = None
         if self.post is not None:
             res = self.res

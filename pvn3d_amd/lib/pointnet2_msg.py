@@ -124,7 +124,26 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def geometry_ahead(self, pointcloud):
+    def sampling_ahead(self, pointcloud, stream=None):
+        """The first level's FPS run of `pointcloud` alone, on `stream` (default: the geometry stream), ordered after
+        the current stream: -> (sel, dmax, event) for ``geometry_ahead(pointcloud, presampled=...)``.  A pipelined
+        evaluator runs it one batch further ahead than the rest of the geometry (lib/pipeline.py, depth 3)."""
+        xyz = pointcloud[..., 0:3].contiguous()
+        cur = torch.cuda.current_stream(xyz.device)
+        st = stream if stream is not None else _geo_stream(xyz.device)
+        xyz.record_stream(st)
+        st.wait_stream(cur)
+        plan = [m.npoint for m in list(self.SA_modules)[1:]]
+        with torch.cuda.stream(st):
+            sel, dmax = self.SA_modules[0].sample_first_level(xyz, plan=plan)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for t in (sel, dmax):
+            if t is not None:
+                t.record_stream(cur)
+        return sel, dmax, ev
+
+    def geometry_ahead(self, pointcloud, presampled=None):
         """Software pipelining across batches: enqueue the xyz-only work (FPS, ball query, three_nn of
         every level) of `pointcloud` on the geometry stream NOW and return a handle for a later
         ``forward(pointcloud, geometry=handle)``.  An evaluator calls this for batch s+1 before it runs
@@ -138,10 +157,10 @@ class Pointnet2MSG(nn.Module):
         # `xyz` is allocated on the current stream but read by kernels of the geometry stream after this
         # function has returned and dropped its reference: keep the allocator from recycling it early
         xyz.record_stream(_geo_stream(xyz.device))
-        sa_geo, fp_geo = self._geometry_ahead(xyz)
+        sa_geo, fp_geo = self._geometry_ahead(xyz, presampled=presampled)
         return {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device}
 
-    def _geometry_ahead(self, xyz):
+    def _geometry_ahead(self, xyz, presampled=None):
         """Run every level's xyz-only work on the geometry stream; returns per-level results and
         the events the feature path has to wait for."""
         cur = torch.cuda.current_stream(xyz.device)
@@ -157,13 +176,23 @@ class Pointnet2MSG(nn.Module):
                     t.record_stream(cur)      # allocated on `geo`, consumed on `cur`
             return ev
 
+        pre = None
+        if presampled is not None:
+            sel, dmax, pre_ev = presampled       # `pointcloud`'s first-level FPS run (sampling_ahead), made earlier
+            if pre_ev is not None:
+                geo.wait_event(pre_ev)
+            for t in (sel, dmax):
+                if t is not None:
+                    t.record_stream(geo)
+            pre = (sel, dmax)
         with torch.cuda.stream(geo):
             nest = None
             for li, sa in enumerate(self.SA_modules):
                 # every level samples the previous level's centres in the order they were picked: one FPS run
                 # (the first level's) plus one verification pass decide the whole pyramid
                 plan = [m.npoint for m in list(self.SA_modules)[1:]] if li == 0 else None
-                new_xyz, idxs, nest = sa.sample_and_query_nested(l_xyz[-1], nest=nest, plan=plan)
+                new_xyz, idxs, nest = sa.sample_and_query_nested(l_xyz[-1], nest=nest, plan=plan,
+                                                                 presampled=pre if li == 0 else None)
                 sa_geo.append(((new_xyz, idxs), hand_over([new_xyz] + list(idxs))))
                 l_xyz.append(new_xyz)
             for i in range(-1, -(len(self.FP_modules) + 1), -1):

@@ -89,7 +89,25 @@ class _PointnetSAModuleBase(nn.Module):
             idxs = self._shared_idx(xyz, new_xyz)
         return new_xyz, idxs
 
-    def sample_and_query_nested(self, xyz, nest=None, plan=None):
+    @staticmethod
+    def _nest_follow(npoint, plan):
+        follow = []
+        for m in (plan or [])[:3]:
+            if m is None or m > (follow[-1] if follow else npoint):
+                break
+            follow.append(int(m))
+        if follow and max(follow) > 8192:
+            follow = []        # fps_nest_verify stages at most 8192 picks in LDS: every level runs its own FPS
+        return follow
+
+    def sample_first_level(self, xyz, plan=None):
+        """The FPS run of a pyramid's first level alone: -> (sel, dmax or None), the `presampled` argument of
+        sample_and_query_nested.  (lib/pipeline.py runs it one batch further ahead than the rest of the geometry: it is
+        the one latency-bound kernel of the chain, 1.5 of its 2.1 ms.)"""
+        with _stage("fps"):
+            return _ext.furthest_point_sampling_nested(xyz, self.npoint, want_dmax=bool(self._nest_follow(self.npoint, plan)))
+
+    def sample_and_query_nested(self, xyz, nest=None, plan=None, presampled=None):
         """sample_and_query for the levels of a pyramid whose next level samples THIS level's centres in the
         order they were picked (Pointnet2MSG): FPS is greedy, so the next level's run is the identity prefix
         unless a tie breaks differently -- checked once, for up to three following levels, by
@@ -105,14 +123,11 @@ class _PointnetSAModuleBase(nn.Module):
                 sel, _ = _ext.furthest_point_sampling_nested(xyz, self.npoint, nest=(flags, level))
                 state = (flags, level + 1) if level + 1 < 3 else None
             else:
-                follow = []
-                for m in (plan or [])[:3]:
-                    if m is None or m > (follow[-1] if follow else self.npoint):
-                        break
-                    follow.append(int(m))
-                if follow and max(follow) > 8192:
-                    follow = []        # fps_nest_verify stages at most 8192 picks in LDS: every level runs its own FPS
-                sel, dmax = _ext.furthest_point_sampling_nested(xyz, self.npoint, want_dmax=bool(follow))
+                follow = self._nest_follow(self.npoint, plan)
+                if presampled is not None:
+                    sel, dmax = presampled       # (first level only) this cloud's FPS run, made earlier
+                else:
+                    sel, dmax = _ext.furthest_point_sampling_nested(xyz, self.npoint, want_dmax=bool(follow))
         with _stage("gather"):
             xyz_t = xyz.transpose(1, 2).contiguous()
             new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()

@@ -38,8 +38,8 @@ def _eager(net, b):
     return f, r
 
 
-@pytest.mark.parametrize("frames", [1, 3])
-def test_graphed_pipeline_replays_equal_the_eager_calls_bit_for_bit(dev, frames):
+@pytest.mark.parametrize("frames,depth", [(1, 3), (3, 3), (2, 2)])
+def test_graphed_pipeline_replays_equal_the_eager_calls_bit_for_bit(dev, frames, depth):
     from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
     from pvn3d_amd.lib.pipeline import GraphedPipeline
     torch.manual_seed(3)
@@ -47,12 +47,14 @@ def test_graphed_pipeline_replays_equal_the_eager_calls_bit_for_bit(dev, frames)
     bs = _batches(dev, frames, 12288, [8100, 8200, 8300])
     want = [_eager(net, b) for b in bs]
     want = [(f.clone(), r["poses"].clone(), r["cls_kps"].clone()) for f, r in want]
-    pipe = GraphedPipeline(net, bs[0]["pc"], post=_post(bs[0]), obj_id=1)
-    # a stream in order, twice round (the handle prepared by the previous replay is the one each replay uses) ...
-    order = [0, 1, 2, 0, 1, 2]
+    pipe = GraphedPipeline(net, bs[0]["pc"], post=_post(bs[0]), obj_id=1, depth=depth)
+    # a stream in order, twice round (each replay uses the handle the previous replay prepared, on the FPS run the one
+    # before that made); towards the end the stream names fewer successors ...
+    order = [0, 1, 2, 0, 1, 2, 2, 0]
     for k, i in enumerate(order):
         nxt = bs[order[k + 1]]["pc"] if k + 1 < len(order) else None
-        f, r = pipe(bs[i]["pc"], pc_next=nxt, post=_post(bs[i]))
+        nxt2 = bs[order[k + 2]]["pc"] if k + 2 < len(order) and k != 4 else None      # (call 4 names no batch after next)
+        f, r = pipe(bs[i]["pc"], pc_next=nxt, pc_next2=nxt2, post=_post(bs[i]))
         assert torch.equal(f, want[i][0]), "features of batch %d (call %d) differ from the eager forward" % (i, k)
         assert torch.equal(r["poses"], want[i][1]) and torch.equal(r["cls_kps"], want[i][2])
     # ... the last call named no successor: the next one computes its own geometry first ...
