@@ -31,5 +31,9 @@ timeout 200 python tools/ms_beside_mfma.py 4 > $O/ms_beside_mfma.txt 2>&1
 # FPS one wave per cloud vs one wave per slot
 (timeout 200 python tools/ms_rate.py sgpr; timeout 200 python tools/ms_rate_real2.py) > $O/ms_rate.txt 2>&1
 timeout 200 python tools/fps_time.py --frames 1,8,64 > $O/fps_time.txt 2>&1
+# split GEMM: LDS-DMA kernel vs the register-staged one (time, bits), its phases in cycles and the shader clock under load
+timeout 300 python tools/sg_time.py > $O/sg_time.txt 2>&1
+bash tools/sg_variants.sh 8 14 15 > /dev/null 2>&1
+(for n in 8 14 15; do echo "== PVN3D_SG_DBG=$n (8: stamps only; 14: + no operand loads, no stores; 15: + no MFMAs either)"; PVN3D_HIP_LIB=tools/sgv/libsg_$n.so timeout 200 python tools/sg_prof.py 2>&1 | grep -v amdgpu.ids; done) > $O/sg_prof.txt 2>&1
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -14 $O/pmc_mfma.log; tail -3 $O/pmc_train.log; head -c 300 $O/bench_default.json; echo; tail -2 $O/bench_default.err

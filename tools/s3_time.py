@@ -13,16 +13,21 @@ from pvn3d_amd import synth  # noqa: E402
 import numpy as np  # noqa: E402
 
 
-def ms_of(fn, reps=5):
+def ms_of(fn, reps=9):
+    """Median of `reps` single timed calls (a mean over a handful of calls showed 1.6 - 4.5 ms for a 0.3 ms kernel now and
+    then: one host hiccup between the launches of a module call lands in the average)."""
     fn(); fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    ts = []
     for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def main():

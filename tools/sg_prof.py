@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Cycle stamps of the LDS-DMA split GEMM (tuning build: bash tools/sg_variants.sh 8; run with
-PVN3D_HIP_LIB=tools/sgv/libsg_8.so): mean cycles per wave in each phase of a launch.
+PVN3D_HIP_LIB=tools/sgv/libsg_8.so): mean cycles per wave in each phase of a launch; wave lifetimes on the 100 MHz
+real-time counter, occupancy per CU (HW_ID / XCC_ID), and the shader clock the two counters imply.
 usage: PVN3D_HIP_LIB=tools/sgv/libsg_8.so python tools/sg_prof.py"""
 import ctypes
 import math
@@ -86,11 +87,11 @@ def main():
                 cur += d
                 mx = max(mx, cur)
             conc.append(mx)
-        print("   wave lifetimes: mean %.1f us, launch span %.1f us, last start %.1f us; CUs used %d, waves per CU %.1f, "
-              "max concurrent waves per CU: min %d mean %.1f max %d" % (
-                  float((end - start).mean()), float(end.max()), float(start.max()), len(per_cu), waves / len(per_cu),
-                  min(conc), sum(conc) / len(conc), max(conc)))
         tot = sum(buf)
+        print("   wave lifetimes: mean %.1f us, launch span %.1f us, last start %.1f us; CUs used %d, waves per CU %.1f, "
+              "max concurrent waves per CU: min %d mean %.1f max %d; shader clock = cycle stamps / real-time stamps = %.2f GHz"
+              % (float((end - start).mean()), float(end.max()), float(start.max()), len(per_cu), waves / len(per_cu),
+                 min(conc), sum(conc) / len(conc), max(conc), tot / waves / max(1e-9, float((end - start).mean())) / 1e3))
         print("%-28s %7.1f us  %6d waves, %d stages, tile x %d points: cycles per wave %8.0f = " % (
             name, e0.elapsed_time(e1) * 1e3, waves, S, 256 if wide else 128, tot / waves) +
             "  ".join("%s %.0f" % (PH[i], buf[i] / waves) for i in range(8)) +
