@@ -72,6 +72,30 @@ static inline int pvn3d_allow_big_lds(K kern) {
   return 0;
 }
 
+// Two fp16 pieces of two (already scaled) fp32 values: h = fp16(x) (round to nearest), l = fp16(x - h) -- the residual is
+// exact in fp32, |x - h - l| <= 2^-22 |x|.  The straightforward form costs five instructions per pair (v_cvt_pk_f16_f32,
+// two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32); v_fma_mixlo/hi_f16 read the fp16 halves of h in place, subtract
+// in fp32 and round the result to fp16 in one instruction each: three per pair, the same bits (tools/split_ab.py: equal
+// digests of pvn3d_split_rows2 over adversarial values and of a 16-frame forward against a -DPVN3D_SPLIT_PLAIN build,
+// tools/split_ab.sh).  Measured effect on the chain kernels: none (sa_mlp 2.61-2.65 ms either way) -- which retires the
+// round-5 reading that those kernels are bound by the COUNT of their vector instructions (the split was 40 % of them in
+// the narrow-chain kernels); kept for the instructions it saves.
+__device__ __forceinline__ void pvn3d_split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  const f2_t x = {x0, x1};
+  const h2_t hh = __builtin_convertvector(x, h2_t);
+  h = __builtin_bit_cast(unsigned, hh);
+#ifdef PVN3D_SPLIT_PLAIN
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(x - __builtin_convertvector(hh, f2_t), h2_t));
+#else
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l)
+      : "v"(h), "v"(x0), "v"(x1));
+#endif
+}
+
 // exclusive rank of this lane among the set bits of a wave64 ballot mask
 __device__ __forceinline__ int pvn3d_mbcnt(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),

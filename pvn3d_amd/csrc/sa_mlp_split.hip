@@ -212,12 +212,8 @@ __device__ __forceinline__ float s3_relu(float x) { return __int_as_float(max(__
 typedef __attribute__((ext_vector_type(2))) _Float16 s3_h2;
 typedef __attribute__((ext_vector_type(2))) float s3_f2;
 __device__ __forceinline__ void split4h(const float (&x)[4], uint2& h, uint2& l) {
-  const s3_f2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
-  const s3_h2 h01 = __builtin_convertvector(x01, s3_h2), h23 = __builtin_convertvector(x23, s3_h2);
-  const s3_h2 l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, s3_f2), s3_h2);
-  const s3_h2 l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, s3_f2), s3_h2);
-  h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
-  l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+  pvn3d_split2_f16(x[0], x[1], h.x, l.x);            // (common.h: three instructions per pair)
+  pvn3d_split2_f16(x[2], x[3], h.y, l.y);
 }
 // store four consecutive-k values as pieces: planes `plane` bytes apart
 template <int AR>

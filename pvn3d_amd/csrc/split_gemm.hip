@@ -107,12 +107,8 @@ __device__ __forceinline__ float sg_pow2_scale(float bound) {      // largest po
 }
 // two fp16 pieces (round to nearest) of four scaled values
 __device__ __forceinline__ void sg_split4h(const float (&x)[4], uint2& h, uint2& l) {
-  const sg_f2 x01 = {x[0], x[1]}, x23 = {x[2], x[3]};
-  const sg_h2 h01 = __builtin_convertvector(x01, sg_h2), h23 = __builtin_convertvector(x23, sg_h2);
-  const sg_h2 l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, sg_f2), sg_h2);
-  const sg_h2 l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, sg_f2), sg_h2);
-  h.x = __builtin_bit_cast(unsigned, h01); h.y = __builtin_bit_cast(unsigned, h23);
-  l.x = __builtin_bit_cast(unsigned, l01); l.y = __builtin_bit_cast(unsigned, l23);
+  pvn3d_split2_f16(x[0], x[1], h.x, l.x);            // (common.h: three instructions per pair)
+  pvn3d_split2_f16(x[2], x[3], h.y, l.y);
 }
 
 // exact 3-way split of four fp32 values (consecutive channels) into three packed bf16x4
