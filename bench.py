@@ -549,6 +549,15 @@ def extra_configs(net, dev, poll_every, with_cpu):
     # step as the headline (feature path || geometry of the next batch || vote-cluster-pose), 8 frames
     if net is not None:
         out.append(per_rank_share_entry(net, dev, poll_every, frames=8))
+        # (i'') frames per step against throughput on the graph pipeline (1 and 8 frames are in the two entries above, 64 is
+        # the headline's eager step): where the FPS chain stops and the two compute islands start to bound the step
+        sweep = {}
+        for fr_n in (16, 32):
+            r = graph_pipeline_ms(net, dev, fr_n, steps=20, seed_base=7300 + fr_n)
+            sweep[str(fr_n)] = dict(ms_per_step=r["ms_per_step"], frames_per_s=r["frames_per_s"],
+                                    identical_to_eager_calls=r["identical_to_eager_calls"])
+        out.append(dict(name="graph_pipeline_batch_sweep", workload="config 2 frames through lib/pipeline.py::GraphedPipeline, "
+                        "16 and 32 frames per step (N=12288, n_obj=3072, K=8)", frames_per_step=sweep))
 
     # (ii) the n_obj = 12 288 stress case (every point of the cloud votes), 8 frames per call
     fr = [synth.synth_frame(frame=7100 + i, n_pts=12288, n_obj=12288) for i in range(8)]
