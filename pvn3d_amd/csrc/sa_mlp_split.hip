@@ -109,13 +109,16 @@ struct S3Args {
 #endif
 
 // tuning probe (PVN3D_S3_DBG & 64): cycle stamps of workgroup 0 -- [0..63] MFMA wave 0 (8 stamps per column block),
-// [64..127] loader wave 0 (one stamp per chunk it staged, before / after)
+// [64..127] loader wave 0 (one stamp per chunk it staged, before / after); [128..255] the same stamps on the 100 MHz
+// real-time counter
 #ifdef PVN3D_S3_TUNING
 __device__ unsigned long long g_s3_prof[256];
 #define S3_STAMP(IDX)                                                                                   \
   do {                                                                                                  \
-    if ((a.dbg & 64) && blockIdx.x == 0 && (IDX) < 128 && (threadIdx.x & 63) == 0)                       \
+    if ((a.dbg & 64) && blockIdx.x == 0 && (IDX) < 128 && (threadIdx.x & 63) == 0) {                     \
       g_s3_prof[(IDX)] = __builtin_readcyclecounter();                                                  \
+      g_s3_prof[128 + (IDX)] = __builtin_amdgcn_s_memrealtime();   /* 100 MHz: the pair gives the shader clock */ \
+    }                                                                                                   \
   } while (0)
 #else
 #define S3_STAMP(IDX) do { } while (0)

@@ -54,6 +54,9 @@ for blk in range(4):
     row = t[blk * 8:blk * 8 + 8] - t0
     print("block %d:" % blk, "  ".join("%s %d" % (n, v) for n, v in zip(names, row)))
     print("        deltas:", np.diff(row))
+rt = t[128:256]
+dc, dr = float(t[3 * 8 + 7] - t[0]), float(rt[3 * 8 + 7] - rt[0])
+print("four blocks: %.0f cycles in %.2f us on the real-time counter -> shader clock %.2f GHz" % (dc, dr / 100.0, dc / max(dr, 1.0) / 10.0))
 print("loader wave 0 (wait-start, wait-end, chunk-done) x chunks, relative:")
 l = t[64:64 + 30].reshape(-1, 3) - t0
 print(l)
