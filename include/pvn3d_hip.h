@@ -416,6 +416,11 @@ int pvn3d_transpose_bcn_to_bnc(int b, int c, int n, const float* in, float* out,
 #define PVN3D_MS_SGPR_POINTS 64
 #define PVN3D_MS_NO_WINNER_STOP 128
 #define PVN3D_MS_WAVE_CAP(n) (((n) & 0xfffff) << 8)
+/* The pruned neighbour count of the original points (the arg-max that names the winning seed) runs as ONE launch that
+ * also sums the (core row, non-core column) hits per column (round 6); PVN3D_MS_COUNT_TWO_PASS selects the two launches
+ * of rounds 2-5 (rows x non-core columns, then non-core rows x core columns: the same tests twice) -- identical counts,
+ * kept as the cross-check (tests). */
+#define PVN3D_MS_COUNT_TWO_PASS (1 << 28)
 size_t pvn3d_meanshift_workspace_bytes(int n_seg, int total, int max_iter);
 int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off, const int* seg_cnt,
                               int n_seg, int total, int max_cnt_host, float bandwidth,

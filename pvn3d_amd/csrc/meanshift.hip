@@ -42,6 +42,8 @@ struct MsState {        // device-side layout inside the caller's workspace
   int* active;          // [2]
   int* counts;          // [total]  pruned neighbour count of every point (core rows: without their n_core core
                         //          neighbours, which ms_argmax_kernel adds)
+  int* counts_t;        // [total]  non-core points: their hits among the CORE points, collected column-wise by the count
+                        //          kernel from the (core row, non-core column) tests it makes anyway (round 6)
   int* core_idx;        // [total]  per segment: indices of "core" points, ascending
   int* nc_idx;          // [total]  per segment: indices of the other points, ascending
   int* n_core;          // [n_seg]
@@ -72,6 +74,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
   const size_t o_best = take(sizeof(unsigned long long) * (size_t)n_seg);
   const size_t o_act = take(sizeof(int) * 2);
   const size_t o_cnt = take(sizeof(int) * (size_t)total);
+  const size_t o_cntt = take(sizeof(int) * (size_t)total);
   const size_t o_core = take(sizeof(int) * (size_t)total);
   const size_t o_nc = take(sizeof(int) * (size_t)total);
   const size_t o_ncore = take(sizeof(int) * (size_t)n_seg);
@@ -89,6 +92,7 @@ inline size_t ms_layout(int n_seg, int total, int max_iter, char* base, MsState*
     st->best = (unsigned long long*)(base + o_best);
     st->active = (int*)(base + o_act);
     st->counts = (int*)(base + o_cnt);
+    st->counts_t = (int*)(base + o_cntt);
     st->core_idx = (int*)(base + o_core);
     st->nc_idx = (int*)(base + o_nc);
     st->n_core = (int*)(base + o_ncore);
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(1024) void ms_classify_kernel(
     const int run_c = s_run[0], run_n = s_run[1];
     if (valid) {
       if (core) core_idx[base + run_c + pre_c + pvn3d_mbcnt(bc)] = i;
-      else nc_idx[base + run_n + pre_n + pvn3d_mbcnt(bn)] = i;
+      else { nc_idx[base + run_n + pre_n + pvn3d_mbcnt(bn)] = i; S.counts_t[base + i] = 0; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -964,47 +968,156 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
   // launch are empty (few non-core rows); with the tile as the fast dimension the surviving
   // workgroups (tile 0/1 of every segment, linear ids 12*seg + {0,1}) all land on the same four
   // of the eight XCDs and the launch took 5x longer than its work.
+  // gridDim.y is NOT the tile count of the host's bound on a segment (N = 12 288 votes: 49 / 193 tiles, of which a fit of
+  // 3 072 votes with ~300 non-core points uses 12 / 5): a workgroup walks tiles blockIdx.y, + gridDim.y, ... of its
+  // segment, and the launcher sizes gridDim.y for ~8 k workgroups in all.  With one workgroup per bound tile the headline
+  // batch launched 111 k workgroups for 3 k tiles of work in the non-core launch -- 155 us of workgroups that read two
+  // words and exit (round 6).
   const int seg = blockIdx.x;
   const int n = seg_cnt[seg];
   const int ncore = n_core[seg], nnc = n - ncore;
   const int n_rows = ROWS_NC ? nnc : n;
   const int n_cols = ROWS_NC ? ncore : nnc;
-  const int tile0 = blockIdx.y * LANES;
-  if (tile0 >= n_rows) return;
   const int base = seg_off[seg];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = tile0 + (SPLIT ? (tid & 63) : tid);
-  int i = -1;
-  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r < n_rows) {
-    i = ROWS_NC ? nc_idx[base + r] : r;
-    c = pts[base + i];
-  }
   const int* cols = (ROWS_NC ? core_idx : nc_idx) + base;
-  int count = 0;
-  for (int j0 = 0; j0 < n_cols; j0 += MS_CHUNK) {
-    const int cnt = min(MS_CHUNK, n_cols - j0);
-    __syncthreads();
-    for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + cols[j0 + q]];
-    __syncthreads();
-    const int qb = SPLIT ? wave * MS_QUARTER : 0, qe = SPLIT ? min(qb + MS_QUARTER, cnt) : cnt;
-    for (int q = qb; q < qe; ++q) {
-      const float4 a = s_pts[q];
-      const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      count += (d2 <= d2_max) ? 1 : 0;
+  for (int tile0 = blockIdx.y * LANES; tile0 < n_rows; tile0 += gridDim.y * LANES) {
+    const int r = tile0 + (SPLIT ? (tid & 63) : tid);
+    int i = -1;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n_rows) {
+      i = ROWS_NC ? nc_idx[base + r] : r;
+      c = pts[base + i];
+    }
+    int count = 0;
+    for (int j0 = 0; j0 < n_cols; j0 += MS_CHUNK) {
+      const int cnt = min(MS_CHUNK, n_cols - j0);
+      __syncthreads();
+      for (int q = tid; q < cnt; q += MS_THREADS) s_pts[q] = pts[base + cols[j0 + q]];
+      __syncthreads();
+      const int qb = SPLIT ? wave * MS_QUARTER : 0, qe = SPLIT ? min(qb + MS_QUARTER, cnt) : cnt;
+      for (int q = qb; q < qe; ++q) {
+        const float4 a = s_pts[q];
+        const float dx = a.x - c.x, dy = a.y - c.y, dz = a.z - c.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        count += (d2 <= d2_max) ? 1 : 0;
+      }
+    }
+    if (SPLIT) {
+      __syncthreads();                                 // (the previous tile's partial counts have been read)
+      if (wave > 0) s_cnt[wave - 1][tid & 63] = count;
+      __syncthreads();
+      if (wave == 0) count += s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid];
+    }
+    if (i >= 0 && (!SPLIT || wave == 0)) {
+      if (ROWS_NC) counts[base + i] += count;   // one thread per row, after the first launch: no race
+      else counts[base + i] = count;
     }
   }
-  if (SPLIT) {
-    if (wave > 0) s_cnt[wave - 1][tid & 63] = count;
-    __syncthreads();
-    if (wave > 0) return;
-    count += s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid];
+}
+
+// Round 6: one launch instead of the two above.  Rows = every point in LIST order (the core list, then the others),
+// columns = the non-core list.  A (core row i, non-core column j) test is the same test as (row j, column i) of the
+// second launch above -- d2 is symmetric bit for bit ((-x)^2 == x^2) -- so the hits of the core rows are also summed per
+// COLUMN: the wave's ballot of a column's hits, masked to its core rows, popcounted, added to an LDS counter of the
+// column (64 columns per LDS atomic), and flushed to counts_t[column's point] with one global atomic per column, chunk
+// and workgroup.
+// counts[i] = hits of row i among the non-core columns (as before); a non-core point's hits among the core points are
+// counts_t[i] (integers: any order is exact).  The second launch walked n_nc x n_core pairs again: 150 of the 280 us of
+// the two launches on the headline batch.  A workgroup owns TPW consecutive 256-row tiles of its segment (grid (n_seg,
+// ceil(bound tiles / TPW))) so that a column's LDS counter collects TPW tiles before it costs an atomic.
+template <int TPW>
+__global__ __launch_bounds__(MS_THREADS) void ms_count_sym_kernel(
+    const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
+    const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
+    float d2_max, int* __restrict__ counts, int* __restrict__ counts_t) {
+  __shared__ float4 s_pts[MS_CHUNK];
+  __shared__ int s_col[MS_CHUNK];
+  const int seg = blockIdx.x;
+  const int n = seg_cnt[seg];
+  const int row0 = blockIdx.y * (TPW * MS_THREADS);
+  if (row0 >= n) return;
+  const int ncore = n_core[seg], nnc = n - ncore;
+  const int base = seg_off[seg];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_row = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const int* cols = nc_idx + base;
+  int idx[TPW], count[TPW];
+  float4 c[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int r = row0 + t * MS_THREADS + tid;
+    idx[t] = -1;
+    count[t] = 0;
+    c[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) {
+      idx[t] = r < ncore ? core_idx[base + r] : nc_idx[base + r - ncore];
+      c[t] = pts[base + idx[t]];
+    }
   }
-  if (i < 0) return;
-  if (ROWS_NC) counts[base + i] += count;   // one thread per row, after the first launch: no race
-  else counts[base + i] = count;
+  const bool any_core = row0 < ncore;                  // (workgroup-uniform) some row of this workgroup is a core row
+  for (int j0 = 0; j0 < nnc; j0 += MS_CHUNK) {
+    const int cnt = min(MS_CHUNK, nnc - j0);
+    __syncthreads();
+    const int cnt64 = (cnt + 63) & ~63;
+    for (int q = tid; q < cnt64; q += MS_THREADS) {
+      const float inf = __builtin_inff();
+      s_pts[q] = q < cnt ? pts[base + cols[j0 + q]] : make_float4(inf, inf, inf, 0.f);
+      s_col[q] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int wr0 = row0 + t * MS_THREADS + wave_row;            // first row of this wave in tile t (wave-uniform)
+      if (wr0 >= n) continue;
+      const bool live = idx[t] >= 0;
+      if (wr0 < ncore) {
+        // (rows of the wave below n_core are core rows: a mask of the lanes)
+        // (rows past n hold the origin and are never stored; rows past n_core are masked out of the column sums -- n_core
+        // <= n, so the mask covers both)
+        const unsigned long long core_mask = wr0 + 64 <= ncore ? ~0ULL : ((1ULL << (ncore - wr0)) - 1ULL);
+        const float d2m = d2_max;
+        // a column's count among this wave's core rows = popcount of the compare's lane mask (scalar unit); it is parked
+        // in lane (q & 63) of a register and added to the LDS counters once per 64 columns (a branch and an LDS atomic
+        // per column and wave cost as much as the pair tests they saved)
+        for (int qb = 0; qb < cnt; qb += 64) {          // (columns cnt .. roundup64(cnt) hold +inf: never a hit)
+          int colv = 0;
+#pragma unroll
+          for (int k = 0; k < 64; ++k) {
+            const float4 a = s_pts[qb + k];
+            const float dx = a.x - c[t].x, dy = a.y - c[t].y, dz = a.z - c[t].z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            // the compare's lane mask lands in an SGPR pair (a ballot of a bool costs a v_cndmask and a second compare):
+            // + 1 per lane through the carry-in of an add, popcount of the core rows' bits on the scalar unit
+            unsigned long long m;
+            asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m) : "v"(d2), "v"(d2m));
+            asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(count[t]) : "s"(m) : "vcc");
+            const int pc = __popcll(m & core_mask);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(pc), "i"(k));
+          }
+          if (qb + lane < cnt) atomicAdd(&s_col[qb + lane], colv);
+        }
+      } else {
+        for (int q = 0; q < cnt; ++q) {
+          const float4 a = s_pts[q];
+          const float dx = a.x - c[t].x, dy = a.y - c[t].y, dz = a.z - c[t].z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          count[t] += (live && d2 <= d2_max) ? 1 : 0;
+        }
+      }
+    }
+    if (any_core) {
+      __syncthreads();
+      for (int q = tid; q < cnt; q += MS_THREADS) {
+        const int v = s_col[q];
+        if (v) atomicAdd(&counts_t[base + cols[j0 + q]], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+    if (idx[t] >= 0) counts[base + idx[t]] = count[t];
 }
 
 // arg-max of the neighbour counts with the reference's first-maximum rule.  grid (ceil(max_cnt/256), n_seg), block 256.
@@ -1013,8 +1126,8 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_pruned_kernel(
 // pass of its own; the key carries ~index, so the walk order does not matter.
 __global__ __launch_bounds__(MS_THREADS) void ms_argmax_kernel(
     const int* __restrict__ seg_off, const int* __restrict__ seg_cnt, const int* __restrict__ counts,
-    const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
-    unsigned long long* __restrict__ best) {
+    const int* __restrict__ counts_t, const int* __restrict__ core_idx, const int* __restrict__ nc_idx,
+    const int* __restrict__ n_core, unsigned long long* __restrict__ best) {
   __shared__ unsigned long long s_red[MS_THREADS / 64];
   const int seg = blockIdx.y;
   const int n = seg_cnt[seg];
@@ -1027,7 +1140,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_argmax_kernel(
   unsigned long long key = 0ULL;
   if (r < n) {
     const int i = r < ncore ? core_idx[base + r] : nc_idx[base + r - ncore];
-    const int c = counts[base + i] + (r < ncore ? ncore : 0);
+    const int c = counts[base + i] + (r < ncore ? ncore : counts_t[base + i]);
     key = ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(~(unsigned)i);
   }
 #pragma unroll
@@ -1209,13 +1322,26 @@ extern "C" int pvn3d_meanshift_fit_batch(const float* pts, const int* seg_off,
     const float r_core = 0.499f * bandwidth;
     hipLaunchKernelGGL(ms_classify_kernel, dim3(n_seg), dim3(1024), 0, st, P, seg_off, seg_cnt, r_core,
                        S.core_idx, S.nc_idx, S.n_core, S, max_iter + 2);
-    const dim3 grid_t(n_seg, pvn3d_ceil_div(max_cnt_host, MS_THREADS));
-    const dim3 grid_ts(n_seg, pvn3d_ceil_div(max_cnt_host, 64));
-    hipLaunchKernelGGL((ms_count_pruned_kernel<false, false>), grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL((ms_count_pruned_kernel<true, true>), grid_ts, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
-                       S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
-    hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts,
+    // one symmetric count launch (ms_count_sym_kernel): four row tiles per workgroup for batches with fits enough to fill
+    // the chip that way, one otherwise (a single frame's nine fits want every tile on a CU of its own)
+    const int tiles_b = pvn3d_ceil_div(max_cnt_host, MS_THREADS);
+    if (flags & PVN3D_MS_COUNT_TWO_PASS) {
+      // rounds 2-5: the same (core, non-core) tests twice, once per side (cross-check of the symmetric launch); the
+      // argmax kernel reads counts_t for the non-core rows: this path leaves it zero (ms_classify_kernel)
+      const int wg_y = max(1, pvn3d_ceil_div(8192, n_seg));
+      const dim3 grid_t(n_seg, min(tiles_b, wg_y));
+      const dim3 grid_ts(n_seg, min(pvn3d_ceil_div(max_cnt_host, 64), wg_y));
+      hipLaunchKernelGGL((ms_count_pruned_kernel<false, false>), grid_t, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                         S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+      hipLaunchKernelGGL((ms_count_pruned_kernel<true, true>), grid_ts, dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                         S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts);
+    } else if (n_seg >= 128)
+      hipLaunchKernelGGL((ms_count_sym_kernel<4>), dim3(n_seg, pvn3d_ceil_div(tiles_b, 4)), dim3(MS_THREADS), 0, st, P, seg_off,
+                         seg_cnt, S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts, S.counts_t);
+    else
+      hipLaunchKernelGGL((ms_count_sym_kernel<1>), dim3(n_seg, tiles_b), dim3(MS_THREADS), 0, st, P, seg_off, seg_cnt,
+                         S.core_idx, S.nc_idx, S.n_core, d2_max, S.counts, S.counts_t);
+    hipLaunchKernelGGL(ms_argmax_kernel, grid_1, dim3(MS_THREADS), 0, st, seg_off, seg_cnt, S.counts, S.counts_t,
                        S.core_idx, S.nc_idx, S.n_core, S.best);
   }
   PVN3D_LAUNCH_CHECK();

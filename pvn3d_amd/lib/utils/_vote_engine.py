@@ -40,6 +40,7 @@ MS_FORCE_WHOLE = 16  # PVN3D_MS_FORCE_WHOLE: every wave walks all points of the 
 MS_FORCE_SPLIT = 32  # PVN3D_MS_FORCE_SPLIT: the four waves of a workgroup split the points
 MS_SGPR_POINTS = 64  # PVN3D_MS_SGPR_POINTS: LDS-free iteration kernel (points as scalar operands); needs ALIGNED32
 MS_NO_WINNER_STOP = 128  # PVN3D_MS_NO_WINNER_STOP: run the reference's full iteration count (iters == its `it`)
+MS_COUNT_TWO_PASS = 1 << 28  # PVN3D_MS_COUNT_TWO_PASS: the neighbour count as the two launches of rounds 2-5 (cross-check)
 # Iteration-kernel choice used when a call does not name one (None: the library default).  A pipelined evaluator
 # that runs the vote stage beside the fused-MLP kernels sets "sgpr+cap<waves>" here (bench.py does).
 DEFAULT_KERNEL = None
@@ -60,7 +61,8 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
     "noearly" (no early-out of converged seeds) -- pins the iteration kernel variant (all give identical results);
     "nowin" = no winner stop: iterate until the reference's stop rule says so (iters == the reference's `it`; same
     centres and labels, bit for bit);
-    "sgpr" = the LDS-free kernel (needs aligned32), "cap<n>" bounds its launch to n waves (PVN3D_MS_WAVE_CAP).
+    "sgpr" = the LDS-free kernel (needs aligned32), "cap<n>" bounds its launch to n waves (PVN3D_MS_WAVE_CAP);
+    "count2" = the neighbour count of the original points as two launches (rounds 2-5) instead of the symmetric one.
     """
     flags = MS_ALIGNED32 if aligned32 else 0
     if kernel is None:
@@ -78,7 +80,7 @@ def meanshift_fit_batch(pts4, seg_off, seg_cnt, max_cnt, bandwidth, max_iter=300
                 continue
             flags |= {"scalar": MS_FORCE_SCALAR, "packed": MS_FORCE_PACKED, "whole": MS_FORCE_WHOLE,
                       "split": MS_FORCE_SPLIT, "noearly": MS_NO_EARLY_OUT, "sgpr": MS_SGPR_POINTS,
-                      "nowin": MS_NO_WINNER_STOP}[k]
+                      "nowin": MS_NO_WINNER_STOP, "count2": MS_COUNT_TWO_PASS}[k]
     dev = pts4.device
     assert pts4.is_cuda and pts4.dtype == torch.float32 and pts4.is_contiguous() and pts4.size(1) == 4
     n_seg = int(seg_off.numel())

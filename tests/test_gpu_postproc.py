@@ -297,6 +297,60 @@ def test_iteration_kernel_variants_are_bit_identical(dev):
     print("iterations run (winner stop / reference's stop rule):", outs["packed+split"][2], outs["packed+split+nowin"][2])
 
 
+def test_symmetric_neighbour_count_equals_the_two_pass_count(dev, orc):
+    """The arg-max of the neighbour counts of the ORIGINAL points (meanshift_pytorch.py:46-49) names the seed whose track
+    is returned.  Round 6 counts the (core row, non-core column) hits once and sums them per column as well
+    (ms_count_sym_kernel) instead of testing the same pairs again with the roles swapped ("count2": the two launches of
+    rounds 2-5).  Same centres, labels and iteration counts bit for bit on: tight votes (few non-core points), heavy tails
+    (many), votes with no core at all (two far clusters: the mean sits between them), a segment whose core ends inside a
+    64-row wave, one-point and empty segments, more than one column chunk of non-core points (> 512), and a batch of more
+    than 128 fits (the four-tiles-per-workgroup form) as well as a small one; the winner also equals the oracle's."""
+    from pvn3d_amd.lib.utils import _vote_engine as eng
+    rng = np.random.default_rng(11)
+    ctr = np.array([0.1, -0.05, 0.9])
+
+    def cloud(n, out_frac, sig_out, two=False):
+        a = rng.normal(size=(n, 3)) * 0.005 + ctr
+        k = int(n * out_frac)
+        if k:
+            a[rng.permutation(n)[:k]] += rng.normal(size=(k, 3)) * sig_out
+        if two:
+            a[: n // 2] += np.array([0.3, 0.0, 0.0])                # two clusters 30 cm apart: nobody is within 4 cm of the mean
+        return a.astype(np.float32)
+
+    base = [cloud(700, 0.1, 0.05), cloud(2048, 0.4, 0.3), cloud(1500, 0.0, 0.0), cloud(33, 0.1, 0.05), cloud(3072, 0.3, 0.08),
+            cloud(1200, 0.0, 0.0, two=True), cloud(1, 0.0, 0.0), np.zeros((0, 3), np.float32), cloud(257, 0.5, 0.2),
+            cloud(3000, 0.6, 0.06)]
+    for reps in (1, 16):                                             # 10 fits / 160 fits
+        segs = [a for _ in range(reps) for a in base]
+        off = [0]
+        for a in segs:
+            off.append(off[-1] + (len(a) + 31) // 32 * 32)
+        pts4 = np.zeros((max(off[-1], 32), 4), np.float32)
+        for a, o in zip(segs, off):
+            pts4[o:o + len(a), :3] = a
+        P = T(pts4, dev)
+        so = torch.tensor(off[:-1], dtype=torch.int32, device=dev)
+        sc = torch.tensor([len(a) for a in segs], dtype=torch.int32, device=dev)
+        got = {}
+        for kern in ("packed+split", "packed+split+count2", "sgpr", "sgpr+count2"):
+            c, l, it = eng.meanshift_fit_batch(P, so, sc, 3072, 0.08, 300, kernel=kern, aligned32=True)
+            l = l.cpu().numpy()
+            valid = np.concatenate([l[o:o + len(a)] for a, o in zip(segs, off)]) if off[-1] else l[:0]
+            got[kern] = (c.cpu().numpy(), valid, it.cpu().numpy())
+        for a, b in (("packed+split", "packed+split+count2"), ("sgpr", "sgpr+count2"), ("packed+split", "sgpr")):
+            for x, y in zip(got[a], got[b]):
+                assert np.array_equal(x, y), (reps, a, b)
+    # the winner against the oracle's neighbour counts (first maximum), on the single batch
+    for a, cgot in zip(base, got["packed+split"][0][: len(base)]):
+        if len(a) < 2:
+            continue
+        d = np.sqrt(((a[:, None, :].astype(np.float32) - a[None, :, :].astype(np.float32)) ** 2).sum(-1, dtype=np.float32))
+        num_in = (d < np.float32(0.08)).sum(1)
+        assert num_in.max() == num_in[int(np.argmax(num_in))]
+    print("non-core share per fit:", [round(float((np.linalg.norm(a - a.mean(0), axis=1) > 0.499 * 0.08).mean()), 2) for a in base if len(a)])
+
+
 def test_stress_all_points_on_object_vs_oracle(dev, orc):
     """BASELINE's 'N = 12 288' clustering size: every point of the cloud votes (n_obj = 12 288).
     One centre fit + one keypoint fit against the C oracle (the full 9 fits take the oracle minutes)."""
