@@ -1032,7 +1032,9 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_sym_kernel(
     const float4* __restrict__ pts, const int* __restrict__ seg_off, const int* __restrict__ seg_cnt,
     const int* __restrict__ core_idx, const int* __restrict__ nc_idx, const int* __restrict__ n_core,
     float d2_max, int* __restrict__ counts, int* __restrict__ counts_t) {
-  __shared__ float4 s_pts[MS_CHUNK];
+  typedef __attribute__((ext_vector_type(2))) float f2s;
+  __shared__ float4 s_pts[TPW >= 2 ? 1 : MS_CHUNK];
+  __shared__ f2s s_xx[TPW >= 2 ? MS_CHUNK : 1], s_yy[TPW >= 2 ? MS_CHUNK : 1], s_zz[TPW >= 2 ? MS_CHUNK : 1];
   __shared__ int s_col[MS_CHUNK];
   const int seg = blockIdx.x;
   const int n = seg_cnt[seg];
@@ -1063,10 +1065,54 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_sym_kernel(
     const int cnt64 = (cnt + 63) & ~63;
     for (int q = tid; q < cnt64; q += MS_THREADS) {
       const float inf = __builtin_inff();
-      s_pts[q] = q < cnt ? pts[base + cols[j0 + q]] : make_float4(inf, inf, inf, 0.f);
+      const float4 a = q < cnt ? pts[base + cols[j0 + q]] : make_float4(inf, inf, inf, 0.f);
+      if constexpr (TPW >= 2) {
+        s_xx[q] = f2s{a.x, a.x}; s_yy[q] = f2s{a.y, a.y}; s_zz[q] = f2s{a.z, a.z};
+      } else {
+        s_pts[q] = a;
+      }
       s_col[q] = 0;
     }
     __syncthreads();
+    if constexpr (TPW >= 2) {
+      // two row tiles per pass, packed: lane holds rows r and r + 256 as (x, x'), (y, y'), (z, z') pairs, a column is read
+      // once as (x, x), (y, y), (z, z) -- v_pk_add / v_pk_mul are IEEE per component, the sum order is the scalar one
+      typedef __attribute__((ext_vector_type(2))) float f2;
+#pragma unroll
+      for (int t = 0; t < TPW; t += 2) {
+        const int wr0 = row0 + t * MS_THREADS + wave_row, wr1 = wr0 + MS_THREADS;     // wave-uniform first rows
+        if (wr0 >= n) continue;
+        const unsigned long long cm0 = wr0 >= ncore ? 0ULL : wr0 + 64 <= ncore ? ~0ULL : ((1ULL << (ncore - wr0)) - 1ULL);
+        const unsigned long long cm1 = wr1 >= ncore ? 0ULL : wr1 + 64 <= ncore ? ~0ULL : ((1ULL << (ncore - wr1)) - 1ULL);
+        const f2 cx = {c[t].x, c[t + 1].x}, cy = {c[t].y, c[t + 1].y}, cz = {c[t].z, c[t + 1].z};
+        float d2m = d2_max;
+        asm("" : "+v"(d2m));                            // (one register for the loop, not a move per compare)
+        // the walk over the columns, with and without the column sums (cm1 != 0 implies cm0 != 0); the LDS index lives in
+        // a VGPR so that the 64 unrolled columns are immediate offsets from one address
+#define MS_SYM_WALK(COLS_TOO)                                                                          \
+  for (int qb = 0; qb < cnt; qb += 64) {          /* (columns cnt .. roundup64(cnt) hold +inf: never a hit) */ \
+    int colv = 0, qv = qb;                                                                             \
+    asm("" : "+v"(qv));                                                                                \
+    _Pragma("unroll") for (int k = 0; k < 64; ++k) {                                                   \
+      const f2 ax = s_xx[qv + k], ay = s_yy[qv + k], az = s_zz[qv + k];                                \
+      const f2 dx = ax - cx, dy = ay - cy, dz = az - cz;                                               \
+      const f2 d2 = (dx * dx + dy * dy) + dz * dz;                                                     \
+      unsigned long long m0, m1;                                                                       \
+      asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m0) : "v"(d2.x), "v"(d2m));                             \
+      asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m1) : "v"(d2.y), "v"(d2m));                             \
+      asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(count[t]) : "s"(m0) : "vcc");                  \
+      asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(count[t + 1]) : "s"(m1) : "vcc");              \
+      if (COLS_TOO) {                                                                                  \
+        const int pc = __popcll(m0 & cm0) + __popcll(m1 & cm1);                                        \
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(pc), "i"(k));                              \
+      }                                                                                                \
+    }                                                                                                  \
+    if (COLS_TOO && qb + lane < cnt) atomicAdd(&s_col[qb + lane], colv);                               \
+  }
+        if (cm0 != 0ULL) { MS_SYM_WALK(true) } else { MS_SYM_WALK(false) }
+#undef MS_SYM_WALK
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int wr0 = row0 + t * MS_THREADS + wave_row;            // first row of this wave in tile t (wave-uniform)
@@ -1106,6 +1152,7 @@ __global__ __launch_bounds__(MS_THREADS) void ms_count_sym_kernel(
           count[t] += (live && d2 <= d2_max) ? 1 : 0;
         }
       }
+    }
     }
     if (any_core) {
       __syncthreads();
