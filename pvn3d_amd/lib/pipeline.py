@@ -36,13 +36,19 @@ def _handle_tensors(h):
         out.extend(t for t in geom[1] if t is not None)
     for (nb, _ev_) in h["fp"]:
         out.extend(nb)
+    for k in ("xyz_bound", "feat_bound"):              # the fp16 x 2 chains' input bounds travel with the handle
+        if h.get(k) is not None:
+            out.append(h[k])
     return out
 
 
 def _with_event(h, ev):
     """The same handle with every hand-over event replaced by `ev`."""
-    return {"sa": [(geom, ev) for (geom, _e) in h["sa"]], "fp": [(nb, ev) for (nb, _e) in h["fp"]],
-            "shape": h["shape"], "device": h["device"]}
+    out = {"sa": [(geom, ev) for (geom, _e) in h["sa"]], "fp": [(nb, ev) for (nb, _e) in h["fp"]],
+           "shape": h["shape"], "device": h["device"]}
+    if h.get("xyz_bound") is not None:
+        out.update(xyz_bound=h["xyz_bound"], feat_bound=h.get("feat_bound"), bounds_event=ev)
+    return out
 
 
 class GraphedPipeline(object):
@@ -93,6 +99,8 @@ class GraphedPipeline(object):
             #     on this stream, the geometry stream's events have been waited for)
             for (_g, ev) in list(nxt["sa"]) + list(nxt["fp"]):
                 cap.wait_event(ev)
+            if nxt.get("bounds_event") is not None:
+                cap.wait_event(nxt["bounds_event"])
             for dst, src in zip(self._persist, _handle_tensors(nxt)):
                 dst.copy_(src)
             if depth == 3:
@@ -116,6 +124,8 @@ class GraphedPipeline(object):
             cur = torch.cuda.current_stream(pc.device)
             for (_g, ev) in list(h["sa"]) + list(h["fp"]):
                 cur.wait_event(ev)
+            if h.get("bounds_event") is not None:
+                cur.wait_event(h["bounds_event"])
             for dst, src in zip(self._persist, _handle_tensors(h)):
                 dst.copy_(src)
         self._handle_valid = True

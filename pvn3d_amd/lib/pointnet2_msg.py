@@ -15,6 +15,9 @@ from .pointnet2_utils.pointnet2_modules import PointnetSAModuleMSG, PointnetFPMo
 # while the MFMA kernels of the previous level occupy the matrix cores; the feature path waits
 # on one event per level.  False keeps everything on the caller's stream.
 GEOMETRY_STREAM = os.environ.get("PVN3D_GEOMETRY_STREAM", "1") != "0"
+# The fp16 x 2 chains' input bounds (abs-max of the cloud and of its features) with the geometry handle, on the geometry
+# stream; "0" computes them at the head of the feature path as rounds 5 did (A/B)
+BOUNDS_AHEAD = os.environ.get("PVN3D_BOUNDS_AHEAD", "1") != "0"
 _geo_streams = {}
 
 
@@ -158,7 +161,34 @@ class Pointnet2MSG(nn.Module):
         # function has returned and dropped its reference: keep the allocator from recycling it early
         xyz.record_stream(_geo_stream(xyz.device))
         sa_geo, fp_geo = self._geometry_ahead(xyz, presampled=presampled)
-        return {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device}
+        h = {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device}
+        h.update(self._input_bounds(pointcloud, xyz))
+        return h
+
+    def _input_bounds(self, pointcloud, xyz):
+        """The device-side abs-max bounds of the cloud's coordinates and input features that the fp16 x 2 chains scale
+        their operands by -- input-only work like the geometry, so it runs on the geometry stream too (round 6: the two
+        reductions were 39 us at the head of the feature path, the step's critical stream).  They are enqueued behind the
+        levels' geometry, so the feature path waits for `bounds_event`, not for a level's hand-over event."""
+        from .pointnet2_utils import _ext, _fused_mlp
+        if _fused_mlp.MLP_ARITH != "fp16x2" or not BOUNDS_AHEAD:
+            return {}
+        cur = torch.cuda.current_stream(xyz.device)
+        geo = _geo_stream(xyz.device)
+        pointcloud.record_stream(geo)
+        with torch.cuda.stream(geo):
+            xb = _ext.table_absmax(xyz, xyz.size(0) * xyz.size(1), 3, 3)
+            fb = None
+            c = pointcloud.size(-1) - 3
+            if c > 0:
+                feats = pointcloud[..., 3:].transpose(1, 2)        # the view the feature path reads in place
+                fb = _ext.table_absmax(feats, xyz.size(0) * xyz.size(1), c, pointcloud.size(-1))
+            ev = torch.cuda.Event()
+            ev.record(geo)
+        for t in (xb, fb):
+            if t is not None:
+                t.record_stream(cur)
+        return {"xyz_bound": xb, "feat_bound": fb, "bounds_event": ev}
 
     def _geometry_ahead(self, xyz, presampled=None):
         """Run every level's xyz-only work on the geometry stream; returns per-level results and
@@ -245,7 +275,14 @@ class Pointnet2MSG(nn.Module):
         xyz_bound = None
         from .pointnet2_utils import _ext, _fused_mlp
         if _fused_mlp.MLP_ARITH == "fp16x2":
-            xyz_bound = _ext.table_absmax(xyz, xyz.size(0) * xyz.size(1), 3, 3)
+            if geometry is not None and geometry.get("xyz_bound") is not None:
+                # reduced on the geometry stream with the handle (input-only work)
+                cur.wait_event(geometry["bounds_event"])
+                xyz_bound = geometry["xyz_bound"]
+                if features is not None and geometry.get("feat_bound") is not None:
+                    features._pvn3d_bound = geometry["feat_bound"]
+            else:
+                xyz_bound = _ext.table_absmax(xyz, xyz.size(0) * xyz.size(1), 3, 3)
         for sa, (geom, ev) in zip(self.SA_modules, sa_geo):
             cur.wait_event(ev)
             if xyz_bound is not None:
