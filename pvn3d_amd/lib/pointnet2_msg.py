@@ -161,7 +161,7 @@ class Pointnet2MSG(nn.Module):
         # function has returned and dropped its reference: keep the allocator from recycling it early
         xyz.record_stream(_geo_stream(xyz.device))
         sa_geo, fp_geo = self._geometry_ahead(xyz, presampled=presampled)
-        h = {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device}
+        h = {"sa": sa_geo, "fp": fp_geo, "shape": tuple(xyz.shape), "device": xyz.device, "xyz": xyz}
         h.update(self._input_bounds(pointcloud, xyz))
         return h
 
@@ -236,9 +236,18 @@ class Pointnet2MSG(nn.Module):
         THIS cloud, enqueued earlier on the geometry stream -- by an evaluator for the next batch, or by a training loop
         for the next step's batch while the current step's backward runs (train_step.py's ``prefetch``).  The indices
         are what an inline run would compute (no parameters are involved), so training results do not change."""
-        xyz, features = self._break_up_pc(pointcloud)
-        if features is not None and not self.training and _pm.FUSED_INFERENCE and not torch.is_grad_enabled():
-            features = pointcloud[..., 3:].transpose(1, 2)   # same values, point-major in place
+        in_place = (pointcloud.size(-1) > 3 and not self.training and _pm.FUSED_INFERENCE and not torch.is_grad_enabled())
+        if in_place:
+            # the fused levels read the features in place (point-major view: same values) -- the channel-major copy of
+            # _break_up_pc would be 19 MB written and dropped per 64-frame forward; the contiguous xyz of a geometry
+            # handle made for THIS cloud is reused instead of copied again
+            xyz = geometry["xyz"] if geometry is not None and geometry.get("xyz") is not None \
+                else pointcloud[..., 0:3].contiguous()
+            features = pointcloud[..., 3:].transpose(1, 2)
+            if xyz.is_cuda:
+                xyz.record_stream(torch.cuda.current_stream(xyz.device))      # (a handle's xyz may come from another stream)
+        else:
+            xyz, features = self._break_up_pc(pointcloud)
         ahead = (GEOMETRY_STREAM and _pm.FUSED_INFERENCE and not self.training and xyz.is_cuda
                  and not torch.is_grad_enabled())
         l_xyz, l_features = [xyz], [features]
