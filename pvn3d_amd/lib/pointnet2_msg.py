@@ -267,6 +267,11 @@ class Pointnet2MSG(nn.Module):
             for i in range(-1, -(len(self.FP_modules) + 1), -1):
                 l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
             return l_features[0]
+        from .pointnet2_utils import _ext as _ext_z
+        with _ext_z.zero_arena(xyz.device):            # the levels' abs-max words and bounds: one fill instead of a dozen
+            return self._forward_ahead(pointcloud, xyz, features, geometry, l_xyz, l_features)
+
+    def _forward_ahead(self, pointcloud, xyz, features, geometry, l_xyz, l_features):
         cur = torch.cuda.current_stream(xyz.device)
         if geometry is not None:
             if geometry["shape"] != tuple(xyz.shape) or geometry["device"] != xyz.device:

@@ -11,6 +11,9 @@ All compute is in libpvn3d_hip.so (include/pvn3d_hip.h); this file only validate
 and passes raw pointers.  Extra (non-reference) entry points used by the fused callers are
 grouped at the bottom.
 """
+import contextlib
+import threading
+
 import torch
 
 from ..._lib import lib, check, on_device
@@ -445,6 +448,33 @@ def invalidate_table_caches(t):
                 pass
 
 
+# Device-side scalars that a kernel accumulates into (abs-max words, bounds) have to start at zero: a dozen one-word
+# torch.zeros per 64-frame forward, each a fill kernel of its own on the feature path's stream.  Inside `zero_arena` they
+# are 16-byte slices of ONE zeroed buffer (one fill).  Thread-local: the evaluator's worker threads run their own calls.
+_ZERO_ARENA = threading.local()
+
+
+@contextlib.contextmanager
+def zero_arena(device, floats=512):
+    prev = getattr(_ZERO_ARENA, "state", None)
+    _ZERO_ARENA.state = [torch.zeros(floats, dtype=torch.float32, device=device), 0]
+    try:
+        yield
+    finally:
+        _ZERO_ARENA.state = prev
+
+
+def zeros_f32(n, device):
+    """n zeroed float32 words on `device` (a 16-byte-aligned slice of the current zero_arena, or a tensor of their own)."""
+    st = getattr(_ZERO_ARENA, "state", None)
+    if st is not None and st[0].device == torch.device(device):
+        off, need = st[1], (int(n) + 3) // 4 * 4
+        if off + need <= st[0].numel():
+            st[1] = off + need
+            return st[0][off:off + int(n)]
+    return torch.zeros(int(n), dtype=torch.float32, device=device)
+
+
 def table_absmax(base, rows, c, ld):
     """Device float32[1] holding max|x| over the point-major table (rows, c) at `base` (row stride ld): the input bound
     the fp16 x 2 kernels scale by (include/pvn3d_hip.h).  One reduction per table: the result is cached on the tensor
@@ -456,7 +486,7 @@ def table_absmax(base, rows, c, ld):
     cache = getattr(base, "_pvn3d_absmax", None)
     if cache is not None and cache[0] == key:
         return cache[1]
-    out = torch.zeros(1, dtype=torch.float32, device=base.device)
+    out = zeros_f32(1, base.device)
     with on_device(base.device):
         check(lib.pvn3d_absmax(int(rows), int(c), base.data_ptr(), int(ld), out.data_ptr(), _stream(base)), "absmax")
     try:
@@ -611,7 +641,7 @@ def sa_precontract(features, packs, nsamples):
     amax = None
     if h2:
         xs, fa = table_h16(feat, B * n, C, ld, S)
-        amax = torch.zeros(1, dtype=torch.float32, device=dev)
+        amax = zeros_f32(1, dev)
         with on_device(dev):
             check(lib.pvn3d_split_gemm2(B * n, n_out, S, xs.data_ptr(), fa.data_ptr(), ws.data_ptr(), 1.0, rm.data_ptr(), None, 0,
                                         None, 0, 0, 0, None, None, y.data_ptr(), n_out, amax.data_ptr(), None, 0, None, st),
@@ -664,7 +694,7 @@ def _fp_layerwise_split(B, n, m, C2, C1, kf, ld_k, uf, ld_u, idx, weight, packed
         xu, ua = table_h16(uf, P, C1, ld_u, w["s_b"])
         z = torch.empty((Pk, n1p), dtype=torch.float32, device=dev)
         h = torch.empty((P * w["s_h"] * 64,), dtype=torch.uint8, device=dev)
-        bnd = torch.zeros(2, dtype=torch.float32, device=dev)            # [0] bound of H, [1] abs-max of the output
+        bnd = zeros_f32(2, dev)            # [0] bound of H, [1] abs-max of the output
         with on_device(dev):
             # |H| <= ||Wb||_inf max|skip| + ||Wa||_inf max|known| + max|b1|  (interpolation weights are >= 0 and sum to 1)
             check(lib.pvn3d_bound_affine(bnd.data_ptr(), ua.data_ptr(), w["nb"], ka.data_ptr(), w["na"], w["b1max"], st),
@@ -755,7 +785,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
             z = torch.empty((B, m, n_out), dtype=torch.float32, device=dev)
             if h2:
                 xs, ka = table_h16(kf, B * m, C2, ld_k, S)
-                amax = torch.zeros(1, dtype=torch.float32, device=dev)
+                amax = zeros_f32(1, dev)
                 with on_device(dev):
                     check(lib.pvn3d_split_gemm2(B * m, n_out, S, xs.data_ptr(), ka.data_ptr(), wp.data_ptr(), 1.0, rm.data_ptr(),
                                                 None, 0, None, 0, 0, 0, None, None, z.data_ptr(), n_out, amax.data_ptr(), None,
@@ -774,7 +804,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
             and lib.pvn3d_mlp_split2_ok(0, C2, C1, 0, packed.n_layers, packed.dims_c, _mlp_flags())):
         w2, meta, b2, rinv = packed.split2()
         # a point-major output feeds another fused level: leave its abs-max for that level's operand scale
-        amax = torch.zeros(1, dtype=torch.float32, device=known_feats.device) if point_major_out else None
+        amax = zeros_f32(1, known_feats.device) if point_major_out else None
         ka = table_absmax(kf, B * m, C2, ld_k)
         ua = table_absmax(uf, B * n, C1, ld_u) if uf is not None else None
         # (the pre-contracted form has an entry point of its own: the shapes its kernel takes add the interpolated rows

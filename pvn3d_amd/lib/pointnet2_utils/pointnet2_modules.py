@@ -203,7 +203,7 @@ class _PointnetSAModuleBase(nn.Module):
                 pre = _ext.sa_precontract(features, packs, [g.nsample for g in self.groupers])
         # fp16 x 2 chains leave the abs-max of what they write for the level that consumes this table (no extra pass);
         # it only counts if EVERY scale of the level went through such a chain
-        amax = torch.zeros(1, dtype=torch.float32, device=xyz.device) if _fused_mlp.MLP_ARITH == "fp16x2" else None
+        amax = _ext.zeros_f32(1, xyz.device) if _fused_mlp.MLP_ARITH == "fp16x2" else None
         amax_writers = 0
         for si, (grouper, mlp, packed, idx, off) in enumerate(zip(self.groupers, self.mlps, packs, idxs, offs)):
             if idx is None:
