@@ -469,3 +469,32 @@ def test_equilibrated_chain_is_exact_and_survives_trained_like_batchnorm_statist
                 assert float(e_old.max()) > 8 * float(e_new.max()), (float(e_old.max()), float(e_new.max()))
         else:
             assert not safe and p16 > 1e-4 and float(e_old.max()) > 1e-3 and float(e_32.max()) < 2e-6
+
+def test_zero_arena_hands_out_aligned_disjoint_zero_slices_and_falls_back():
+    """_ext.zero_arena / zeros_f32 (round 6): the one-word accumulators of a fused forward (abs-max words, bounds) are
+    16-byte-aligned slices of ONE zeroed buffer inside the context, tensors of their own outside it or when the arena is
+    used up or lives on another device; contexts nest and restore; the arena is thread-local."""
+    import threading
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+    cpu = torch.device("cpu")
+    a = _ext.zeros_f32(1, cpu)
+    assert a.shape == (1,) and float(a) == 0.0 and a._base is None                 # no arena: its own tensor
+    with _ext.zero_arena(cpu, floats=16):
+        s = [_ext.zeros_f32(n, cpu) for n in (1, 2, 1, 4)]
+        assert all(t._base is s[0]._base and t._base is not None for t in s)       # slices of one buffer
+        offs = [(t.data_ptr() - s[0]._base.data_ptr()) for t in s]
+        assert offs == [0, 16, 32, 48] and all(float(t.abs().sum()) == 0.0 for t in s)
+        s[1][:] = 7.0
+        assert float(s[0]) == 0.0 and float(s[2]) == 0.0                           # disjoint
+        over = _ext.zeros_f32(8, cpu)                                              # 16 floats are used up: falls back
+        assert over._base is None and over.numel() == 8
+        with _ext.zero_arena(cpu, floats=8):                                       # nested: a fresh arena ...
+            inner = _ext.zeros_f32(1, cpu)
+            assert inner._base is not s[0]._base and float(inner) == 0.0
+        again = _ext.zeros_f32(1, cpu)                                             # ... and the outer one is back (still full)
+        assert again._base is None
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(_ext.zeros_f32(1, cpu)._base is None))
+        th.start(); th.join()
+        assert seen == [True]                                                      # another thread has no arena
+    assert _ext.zeros_f32(1, cpu)._base is None
