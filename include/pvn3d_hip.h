@@ -283,6 +283,13 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
  *                 and stays on pvn3d_sa_mlp_maxpool).  The library has no process-wide switch (no global mutable state). */
 #define PVN3D_MLP_NO_NARROW 1
 int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int flags);
+/* The kernel family the fp16 x 2 entry points would run the chain on: 0 none, 1 the 4 + 4-wave kernel, 2 a narrow-chain
+ * kernel (weights resident in LDS; instantiated for the backbone's widths: SA chains 6 / 96 features -> (16, 16, 32),
+ * (32, 32, 64), (64, 64, 128), (64, 96, 128) at nsample 16 / 32; the pre-contracted FP chain 128 + 6 -> 128 -> 128 with a
+ * channel-major output).  A diagnostic for hosts that build other networks (round 6: the review's "a backbone with one
+ * different width silently loses 1.8 ms"). */
+int pvn3d_mlp_split2_kernel(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host,
+                            int out_point_major, int flags);
 /* The FP chain in its pre-contracted form: the caller promises that the first c2 columns of layer 0's weights are the
  * identity (known_pm holds the first conv's interpolated half, already applied per KNOWN point: what
  * _ext.fp_interp_mlp does for FP level 0), i.e. layer 0 = relu(interp(known) + Wb.skip + b0).  Arguments and results as

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pvn3d_sa_mlp_maxpool_split": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_fp_interp_mlp_split": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p]),
     "pvn3d_mlp_split2_ok": (_i, [_i, _i, _i, _i, _i, _p, _i]),
+    "pvn3d_mlp_split2_kernel": (_i, [_i, _i, _i, _i, _i, _p, _i, _i]),
     "pvn3d_sa_mlp_maxpool_split2": (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "pvn3d_fp_interp_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     "pvn3d_fp_interp_add_mlp_split2": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p]),

@@ -1928,6 +1928,19 @@ extern "C" int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int
   return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 1, flags & PVN3D_MLP_NO_NARROW);
 }
 
+// Which kernel family pvn3d_*_split2 would run the chain on: 0 none (pvn3d_mlp_split2_ok == 0), 1 the 4 + 4-wave kernel,
+// 2 a narrow-chain kernel (the chain's weights resident in LDS: 2-4 x faster on chains it takes).  The narrow kernels
+// are instantiated for the backbone's widths only; a host that builds a different network can see here that a chain
+// every layer of which is <= 128 wide does not get one (lib/pointnet2_utils/_ext.py warns once per shape).
+extern "C" int pvn3d_mlp_split2_kernel(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host,
+                                       int out_point_major, int flags) {
+  if (!dims_host || n_layers < 1 || n_layers > S3_MAX_LAYERS) return 0;
+  const int no_narrow = flags & PVN3D_MLP_NO_NARROW;
+  if (is_sa && nw_signature(c_a, nsample, n_layers, dims_host, no_narrow) > 0) return 2;
+  if (!is_sa && nwfp_ok(c_a, c_b, n_layers, dims_host, out_point_major, no_narrow)) return 2;
+  return s3_ok(is_sa, c_a, c_b, nsample, n_layers, dims_host, 1, no_narrow) ? 1 : 0;
+}
+
 // fp16 x 2: per-layer (sw, ||W||_inf, max|b|) triples + the device-side input bounds -> S3Args; false when malformed
 static bool s3_fill_scales(S3Args* a, int n_layers, const float* layer_meta, const float* bound_a, const float* bound_b,
                            float mul_b) {

@@ -402,6 +402,31 @@ def group_xyz_features_pair(xyz, new_xyz, features, idx0, idx1):
     return out0, out1
 
 
+_NARROW_MISS_SEEN = set()
+
+
+def _note_narrow_miss(is_sa, c_a, c_b, nsample, packed, out_point_major=0):
+    """Once per chain shape: a chain whose layers are all <= 128 wide (what the narrow-chain kernels are for) but whose
+    widths are not among the instantiated ones runs on the 4 + 4-wave kernel -- 2-4 x slower for such chains.  The
+    library answers which family it would pick (pvn3d_mlp_split2_kernel); this is the message a host with a different
+    backbone gets instead of a silent slowdown."""
+    dims = tuple(int(d) for d in packed.dims)
+    if not NARROW_KERNELS or max(dims[1:]) > 128 or (is_sa and nsample not in (16, 32)):
+        return
+    key = (bool(is_sa), int(c_a), int(c_b), int(nsample), dims, int(out_point_major))
+    if key in _NARROW_MISS_SEEN:
+        return
+    _NARROW_MISS_SEEN.add(key)
+    fam = lib.pvn3d_mlp_split2_kernel(int(is_sa), int(c_a), int(c_b), int(nsample), packed.n_layers, packed.dims_c,
+                                      int(out_point_major), _mlp_flags())
+    if fam == 1:
+        import warnings
+        warnings.warn("pvn3d_amd: the %s chain %s (%s) has no narrow-chain kernel instance and runs on the 4 + 4-wave "
+                      "kernel; the narrow kernels (csrc/sa_mlp_split.hip: nw_signature / nwfp_ok) are instantiated for the "
+                      "PVN3D backbone's widths" % ("set-abstraction" if is_sa else "feature-propagation", list(dims),
+                                                   "nsample %d" % nsample if is_sa else "skip %d" % c_b), stacklevel=3)
+
+
 def _point_major(t):
     """(B, C, n) tensor -> (base tensor, ld) of a point-major (B, n, ld) table holding it.
     Zero-copy when `t` already is a transposed view of a point-major buffer (what the fused
@@ -563,6 +588,7 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
             and lib.pvn3d_mlp_split2_ok(1, C, 0, nsample, packed.n_layers, packed.dims_c, _mlp_flags())
             and packed.fp16x2_safe()):
         w2, meta, b2, rinv = packed.split2()
+        _note_narrow_miss(1, C, 0, nsample, packed)
         fa, xa = table_absmax(feat, B * N, C, ld_feat), table_absmax(xyz, B * N, 3, 3)
         with on_device(xyz.device):
             check(lib.pvn3d_sa_mlp_maxpool_split2(B, N, m, C, nsample, xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(),

@@ -498,3 +498,41 @@ def test_zero_arena_hands_out_aligned_disjoint_zero_slices_and_falls_back():
         th.start(); th.join()
         assert seen == [True]                                                      # another thread has no arena
     assert _ext.zeros_f32(1, cpu)._base is None
+
+
+def test_kernel_family_query_names_the_narrow_kernels_instances_and_the_host_warns_once_on_a_miss():
+    """pvn3d_mlp_split2_kernel (host-only arithmetic, no GPU): the PVN3D backbone's narrow chains get a narrow-chain
+    kernel (2), its wide chains the 4 + 4-wave kernel (1); a chain that is narrow enough but has other widths gets 1 --
+    and _ext._note_narrow_miss turns that into ONE warning per shape (round-5 review: a different backbone must not lose
+    its narrow kernels silently); PVN3D_MLP_NO_NARROW takes the narrow instances away."""
+    import ctypes
+    import warnings
+    from pvn3d_amd._lib import lib
+    from pvn3d_amd.lib.pointnet2_utils import _ext
+
+    def fam(is_sa, c_a, c_b, ns, dims, pm=0, flags=0):
+        arr = (ctypes.c_int * len(dims))(*dims)
+        return lib.pvn3d_mlp_split2_kernel(is_sa, c_a, c_b, ns, len(dims) - 1, arr, pm, flags)
+
+    assert fam(1, 6, 0, 16, [9, 16, 16, 32]) == 2 and fam(1, 6, 0, 32, [9, 32, 32, 64]) == 2          # SA level 0
+    assert fam(1, 96, 0, 16, [99, 64, 64, 128]) == 2 and fam(1, 96, 0, 32, [99, 64, 96, 128]) == 2     # SA level 1
+    assert fam(0, 128, 6, 0, [134, 128, 128]) == 2                                                    # FP level 0, pre-contracted
+    assert fam(0, 128, 6, 0, [134, 128, 128], pm=1) == 1                                              # ... point-major out: 4 + 4
+    assert fam(1, 128, 0, 32, [131, 196, 256]) in (0, 1)                                              # a wide chain: never 2
+    assert fam(1, 96, 0, 32, [99, 64, 80, 128]) == 1                                                  # narrow enough, other widths
+    assert fam(1, 96, 0, 32, [99, 64, 96, 128], flags=1) == 1                                         # PVN3D_MLP_NO_NARROW
+    assert fam(1, 96, 0, 24, [99, 64, 96, 128]) == 0                                                  # nsample 24: no fp16 x 2 kernel at all (fp32 path)
+
+    class P(object):                                   # what _note_narrow_miss reads of a PackedMLP
+        def __init__(self, dims):
+            self.dims, self.n_layers = list(dims), len(dims) - 1
+            self.dims_c = (ctypes.c_int * len(dims))(*dims)
+
+    _ext._NARROW_MISS_SEEN.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _ext._note_narrow_miss(1, 96, 0, 32, P([99, 64, 96, 128]))         # has an instance: silent
+        _ext._note_narrow_miss(1, 96, 0, 32, P([99, 64, 80, 128]))         # a miss: one warning ...
+        _ext._note_narrow_miss(1, 96, 0, 32, P([99, 64, 80, 128]))         # ... once
+        _ext._note_narrow_miss(1, 256, 0, 32, P([259, 128, 196, 256]))     # a wide chain: not the narrow kernels' business
+    assert len(w) == 1 and "no narrow-chain kernel instance" in str(w[0].message)
