@@ -52,10 +52,16 @@ def _with_event(h, ev):
 
 
 class GraphedPipeline(object):
-    def __init__(self, net, pc, post=None, obj_id=1, async_limit=8, warmup=2, depth=3):
-        assert not net.training and pc.is_cuda and depth in (2, 3)
+    def __init__(self, net, pc, post=None, obj_id=1, async_limit=8, warmup=2, depth=3, kind="lm", n_cls=22):
+        """kind: "lm" -- `post` are F LineMOD frames of object `obj_id` (cal_batch_poses_lm); "ycb" -- ONE YCB frame with
+        `n_cls` classes (cal_batch_poses with the centre-cluster filter: like GraphedFramePoses, a single frame instantiates
+        every class slot, which is a fixed launch sequence)."""
+        assert not net.training and pc.is_cuda and depth in (2, 3) and kind in ("lm", "ycb")
+        if kind == "ycb" and post is not None and post[0].size(0) != 1:
+            raise ValueError("GraphedPipeline(kind='ycb') captures ONE frame per call (got %d)" % post[0].size(0))
         dev = pc.device
         self.net, self.obj_id, self.async_limit, self.depth = net, obj_id, async_limit, depth
+        self.kind, self.n_cls = kind, n_cls
         self.pc_cur, self.pc_next, self.pc_next2 = pc.clone(), pc.clone(), pc.clone()
         self.post = [t.clone() for t in post] if post is not None else None
         self.fallbacks = 0
@@ -115,6 +121,8 @@ class GraphedPipeline(object):
 
     def _vote(self, limit, poll_every=8):
         p, m, c, k = self.post
+        if self.kind == "ycb":
+            return _ev.cal_batch_poses(p, m, c, k, True, self.n_cls, True, poll_every=poll_every, async_limit=limit)
         return _ev.cal_batch_poses_lm(p, m, c, k, True, 2, False, self.obj_id, poll_every=poll_every, async_limit=limit)
 
     def prime(self, pc):

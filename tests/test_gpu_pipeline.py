@@ -87,3 +87,43 @@ def test_graphed_pipeline_falls_back_to_the_polled_vote_stage_when_fits_do_not_f
         f, r = pipe(bs[i]["pc"], pc_next=bs[1 - i]["pc"], post=_post(bs[i]))
         assert torch.equal(f, want[i][0]) and torch.equal(r["poses"], want[i][1])
     assert pipe.fallbacks == 3
+
+
+def test_graphed_pipeline_ycb_single_frames_equal_the_eager_calls(dev):
+    """kind="ycb": a stream of single YCB frames (21 classes, centre-cluster filter on: cal_frame_poses,
+    pvn3d_eval_utils.py:90-197) -- the feature path and the multi-class vote stage of a frame in one replay; class ids
+    present, poses and keypoints are the eager calls' bits; more than one frame per call is refused."""
+    from pvn3d_amd import synth
+    from pvn3d_amd.lib.pointnet2_msg import Pointnet2MSG
+    from pvn3d_amd.lib.pipeline import GraphedPipeline
+    from pvn3d_amd.lib.utils import pvn3d_eval_utils as ev
+    torch.manual_seed(3)
+    net = Pointnet2MSG(input_channels=6).to(dev).eval()
+    fr = [synth.synth_frame_ycb(frame=8600 + i) for i in range(3)]
+    bs = []
+    for f in fr:
+        t = lambda k, dt: torch.from_numpy(np.asarray(f[k]).astype(dt))[None].to(dev).contiguous()
+        b = dict(pcld=t("pcld", np.float32), mask=t("mask", np.int32), ctr_of=t("ctr_of", np.float32),
+                 pred_kp_of=t("pred_kp_of", np.float32))
+        g = torch.Generator(device="cpu").manual_seed(int(f["cls_ids"][0]))
+        feats = torch.randn(1, 12288, 6, generator=g).to(dev)
+        b["pc"] = torch.cat([b["pcld"], feats], 2).contiguous()
+        bs.append(b)
+    want = []
+    for b in bs:
+        with torch.no_grad():
+            f = net(b["pc"]).clone()
+        r = ev.cal_batch_poses(*_post(b), True, 22, True, poll_every=4)
+        want.append((f, r["poses"].clone(), r["present"].clone()))
+    pipe = GraphedPipeline(net, bs[0]["pc"], post=_post(bs[0]), kind="ycb", n_cls=22)
+    order = [0, 1, 2, 1, 0]
+    for k, i in enumerate(order):
+        nxt = bs[order[k + 1]]["pc"] if k + 1 < len(order) else None
+        nxt2 = bs[order[k + 2]]["pc"] if k + 2 < len(order) else None
+        f, r = pipe(bs[i]["pc"], pc_next=nxt, pc_next2=nxt2, post=_post(bs[i]))
+        assert torch.equal(f, want[i][0]), (k, i)
+        assert torch.equal(r["present"], want[i][2]) and torch.equal(r["poses"], want[i][1]), (k, i)
+    assert int(want[0][2].sum()) == 5                       # five of the 21 classes are in the frame
+    two = tuple(torch.cat([x, x], 0) for x in _post(bs[0]))
+    with pytest.raises(ValueError):
+        GraphedPipeline(net, bs[0]["pc"], post=two, kind="ycb")
