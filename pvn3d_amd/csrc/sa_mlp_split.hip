@@ -87,6 +87,7 @@ struct S3Args {
   int n_frames;
   int rs, ps;                                   // P: bytes per column, bytes per piece plane
   int ring_off;                                 // byte offset of the chunk ring in dynamic LDS (0 = overlaid on P)
+  int ident_a;                                  // PVN3D_MLP_IDENTITY_A: layer 0's table-A slabs are an identity block (pre-contracted chains): their low weight pieces are zero, the wl.xh product is not issued
   int bias_off, bias_all;
   float* out; int point_major, ld_out, coff;
   // fp16 x 2 only: per-layer weight scale (power of two), ||W_l||_inf and max|b_l| of the true (folded) weights, and the
@@ -427,7 +428,8 @@ struct WSrc {
 // v_mfma_f32_32x32x16 are the same, so the registers are simply swapped in the instruction): the accumulator then holds
 // lane = output channel, registers = the tile's 32 columns.
 template <int AR, int NTC, int NT, int NR, bool TR = false>
-__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][s3_np(AR)], const uint4 (&b)[2][s3_np(AR)]) {
+__device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[NR][s3_np(AR)], const uint4 (&b)[2][s3_np(AR)],
+                                        bool a_lo_zero = false) {
   if (AR == 1 && TR) {
 #define S3_MM(PA, PB)                                                                                                  \
   _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
@@ -440,7 +442,11 @@ __device__ __forceinline__ void mm_slab(f32x16 (&acc)[NT][2], const uint4 (&a)[N
   _Pragma("unroll") for (int t = 0; t < NTC; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)                        \
       acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t][PA]),                          \
                                                          __builtin_bit_cast(f16x8, b[c][PB]), acc[t][c], 0, 0, 0)
-    S3_MM(0, 1); S3_MM(1, 0); S3_MM(0, 0);
+    // (a_lo_zero, wave-uniform: the weight slab's low piece is all zeros -- the identity block of a pre-contracted chain --
+    // so its product with the activations' high piece adds exact zeros and is not issued: a third of the block's MFMAs)
+    S3_MM(0, 1);
+    if (!a_lo_zero) S3_MM(1, 0);
+    S3_MM(0, 0);
 #undef S3_MM
   } else {
 #define S3_MM(PA, PB)                                                                                                  \
@@ -600,7 +606,7 @@ struct S3Consumer {
     a_load<NTC, NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
     b_ld<32>(bB, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0)], bA);                                                   \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0)], bA, idz_ && (C) < a.nA);                               \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     a_load<NTC, NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
     if ((C) + 1 < n_chunks) {                                                                          \
@@ -612,9 +618,10 @@ struct S3Consumer {
       b_ld<0>(bA, bn_);                                                                                \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0) + 1], bB);                                               \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0) + 1], bB, idz_ && (C) < a.nA);                           \
     lds_signal_add(&ctl->fin[slot_], lane);                                                            \
   } while (0)
+    const bool idz_ = AR == 1 && a.ident_a != 0;
     int c = 0;
     for (; c + 2 <= n_full; c += 2) {
       S3_CHUNK_STEP(c, 0);
@@ -1973,7 +1980,7 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
   if (arith == 1 && !s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, mul_b)) return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
-  a.out_row_mul = out_row_mul;
+  a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
   a.is_sa = 1;
   a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
   a.idx = idx;
@@ -2016,7 +2023,8 @@ static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const flo
                        const float* unknown_pm, int ld_unknown, const int* idx, const float* weight, int n_layers,
                        const int* dims_host, const void* const* w_split, const float* const* bias_padded,
                        const float* layer_meta, const float* bound_a, const float* bound_b, float* out,
-                       int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul, void* stream) {
+                       int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul, int flags,
+                       void* stream) {
   if (b <= 0 || n <= 0) return 0;
   if (!known_pm || !idx || !weight || !out || !dims_host || !w_split || !bias_padded || (c1 > 0 && !unknown_pm))
     return (int)hipErrorInvalidValue;
@@ -2029,7 +2037,7 @@ static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const flo
   if (arith == 1 && (!s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, 1.f) || (c1 > 0 && !bound_b)))
     return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
-  a.out_row_mul = out_row_mul;
+  a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
   a.is_sa = 0;
   a.idx = idx; a.weight = weight;
   a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
@@ -2047,7 +2055,7 @@ extern "C" int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, co
                                          const float* const* bias_padded, float* out, int out_point_major, int ld_out,
                                          void* stream) {
   return s3_fp_entry(0, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
-                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, nullptr, nullptr, stream);
+                     w_split, bias_padded, nullptr, nullptr, nullptr, out, out_point_major, ld_out, nullptr, nullptr, 0, stream);
 }
 extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, const float* known_pm, int ld_known,
                                           const float* unknown_pm, int ld_unknown, const int* idx, const float* weight,
@@ -2056,11 +2064,11 @@ extern "C" int pvn3d_fp_interp_mlp_split2(int b, int n, int m, int c2, int c1, c
                                           const float* known_absmax, const float* unknown_absmax, float* out,
                                           int out_point_major, int ld_out, float* out_absmax, const float* out_row_mul,
                                           int flags, void* stream) {
-  (void)flags;             // (no narrow-chain kernel behind this entry point)
+  // (no narrow-chain kernel behind this entry point: of the flags only PVN3D_MLP_IDENTITY_A matters)
   // interpolation weights are non-negative and sum to 1: |interp(known)| <= max|known|
   return s3_fp_entry(1, b, n, m, c2, c1, known_pm, ld_known, unknown_pm, ld_unknown, idx, weight, n_layers, dims_host,
                      w_split2, bias_padded, layer_meta, known_absmax, unknown_absmax, out, out_point_major, ld_out, out_absmax,
-                     out_row_mul, stream);
+                     out_row_mul, flags, stream);
 }
 
 // The pre-contracted form (DESIGN 4.7b''): the caller promises that the first c2 columns of layer 0's weights are the
@@ -2083,7 +2091,7 @@ extern "C" int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c
         !s3_fill_scales(&a, n_layers, layer_meta, known_absmax, unknown_absmax, 1.f))
       return (int)hipErrorInvalidValue;
     a.out_absmax = (unsigned*)out_absmax;
-    a.out_row_mul = out_row_mul;
+    a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
     a.is_sa = 0;
     a.idx = idx; a.weight = weight;
     a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known;

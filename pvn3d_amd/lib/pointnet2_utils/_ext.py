@@ -453,8 +453,14 @@ SPLIT2_NARROW = True
 NARROW_KERNELS = True
 
 
-def _mlp_flags():
-    return 0 if NARROW_KERNELS else 1          # PVN3D_MLP_NO_NARROW
+IDENTITY_SKIP = True      # pass PVN3D_MLP_IDENTITY_A for pre-contracted chains (False: A/B -- the results are the same bits)
+
+
+def _mlp_flags(packed=None):
+    f = 0 if NARROW_KERNELS else 1             # PVN3D_MLP_NO_NARROW
+    if IDENTITY_SKIP and packed is not None and getattr(packed, "identity_a", False):
+        f |= 2                                 # PVN3D_MLP_IDENTITY_A
+    return f
 
 
 def invalidate_table_caches(t):
@@ -595,7 +601,7 @@ def sa_mlp_maxpool(xyz, new_xyz, features, idx, use_xyz, packed, out_pm=None, ou
                                                   ld_feat, idx.data_ptr(), packed.n_layers, packed.dims_c, w2, b2,
                                                   meta, fa.data_ptr(), xa.data_ptr(), out_pm.data_ptr(), ld_out, out_coff,
                                                   out_absmax.data_ptr() if out_absmax is not None else None,
-                                                  rinv.data_ptr(), _mlp_flags(), _stream(xyz)), "sa_mlp_maxpool_split2")
+                                                  rinv.data_ptr(), _mlp_flags(packed), _stream(xyz)), "sa_mlp_maxpool_split2")
         if out_absmax is not None:
             out_absmax._pvn3d_written = True
         return out_pm[:, :, out_coff:out_coff + M].transpose(1, 2)
@@ -843,7 +849,7 @@ def fp_interp_mlp(known_feats, unknow_feats, idx, weight, packed, point_major_ou
                                                  ka.data_ptr(), ua.data_ptr() if ua is not None else None, out.data_ptr(),
                                                  1 if point_major_out else 0, ld_out,
                                                  amax.data_ptr() if amax is not None else None, rinv.data_ptr(),
-                                                 _mlp_flags(), _stream(known_feats)),
+                                                 _mlp_flags(packed), _stream(known_feats)),
                   "fp_interp_mlp_split2")
         if point_major_out:
             return seed_absmax(out[:, :, :M].transpose(1, 2), B * n, M, ld_out, amax)

@@ -83,6 +83,7 @@ class PackedMLP(object):
         folded = [w0] + list(Ws[1:])
         pre = PackedMLP([w0.shape[1]] + self.dims[1:], [_pack_weight(W) for W in folded], b_list, folded=folded,
                         equil=(rinv,) if equil else None)
+        pre.identity_a = True          # layer 0 = [I | Wr]: the low fp16 pieces of its table-A slabs are zero (PVN3D_MLP_IDENTITY_A)
         self._pre = ((c_feat, bool(equil)), pre, W0[:, :c_feat].contiguous())
         return pre, self._pre[2]
 
