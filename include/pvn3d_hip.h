@@ -284,9 +284,10 @@ int pvn3d_fp_interp_mlp_split(int b, int n, int m, int c2, int c1, const float* 
 #define PVN3D_MLP_NO_NARROW 1
 /* The caller's promise that layer 0's weight slabs over table A (SA: the gathered feature table, FP: the interpolated known
  * table) are an identity block, i.e. that their low fp16 pieces are zero -- what a pre-contracted chain is ([I | Wr]:
- * lib/pointnet2_utils/_fused_mlp.py::precontracted): the 4 + 4-wave kernel then does not issue the (weight low piece x
- * activation high piece) product for those slabs (exact zeros; a third of the identity block's MFMAs).  Results are the
- * same bits with and without the flag when the promise holds. */
+ * lib/pointnet2_utils/_fused_mlp.py::precontracted), scaled by the layer's power-of-two weight scale: the 4 + 4-wave kernel
+ * then multiplies a row tile only with the chunk of the table that carries its unit block, with constant weight fragments
+ * and without the zero low piece (FP level 1: 64 instead of 768 MFMAs per column block).  Results are the same bits with
+ * and without the flag when the promise holds. */
 #define PVN3D_MLP_IDENTITY_A 2
 int pvn3d_mlp_split2_ok(int is_sa, int c_a, int c_b, int nsample, int n_layers, const int* dims_host, int flags);
 /* The kernel family the fp16 x 2 entry points would run the chain on: 0 none, 1 the 4 + 4-wave kernel, 2 a narrow-chain

@@ -574,20 +574,75 @@ struct S3Consumer {
     }
     const WSrc<NTC> w = wsrc<NTC>(0, slabs, lane);
     init_acc<NTC>(acc, 0, 0, half);
+    // PVN3D_MLP_IDENTITY_A (pre-contracted chains): the a.nA chunks of the gathered table meet an identity block.  Row tile
+    // mt has non-zero weights in chunk mt only, and there they are the (scaled) unit matrix: those chunks are worked off
+    // first, by the one wave whose tile they concern, with constant weight fragments and without the zero low piece -- eight
+    // MFMAs per chunk and workgroup instead of 12 per slab and row tile (FP level 1: 64 instead of 768 per column block).
+    // The chunks that follow (skip features / xyz) run the pipelined loop below from chunk c0 on.
+    const bool idz_ = AR == 1 && a.ident_a != 0;
+    const int c0 = idz_ ? a.nA : 0;
     uint4 ringA[4][NTC][NP];
-    a_load<NTC, NTC>(ringA[0], w, 0);
-    a_load<NTC, NTC>(ringA[1], w, 1);
-    a_load<NTC, NTC>(ringA[2], w, 2);
+    a_load<NTC, NTC>(ringA[0], w, 2 * c0);
+    a_load<NTC, NTC>(ringA[1], w, 2 * c0 + 1);
+    a_load<NTC, NTC>(ringA[2], w, 2 * c0 + 2);
     // this lane's fragment addresses in ring slot 0; slot k is + k * CHUNK
     const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
     const int n_chunks = n_full + (tail ? 1 : 0);
+    if constexpr (AR == 1) {
+      if (idz_) {
+        // unit-matrix fragments of a 32-row tile's two slabs: lane (row m, k half h) holds k = 16 j + 8 h + i, i < 8, of
+        // slab j: the weight scale (a power of two, exact in fp16) where k == m
+        const int m = lane & 31;
+        const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a.sw[0]);
+        uint4 idA[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = m - 16 * j - 8 * half;
+          const unsigned v = (i >= 0 && i < 8) ? one << (16 * (i & 1)) : 0u;
+          idA[j] = make_uint4((i >> 1) == 0 ? v : 0u, (i >> 1) == 1 ? v : 0u, (i >> 1) == 2 ? v : 0u, (i >> 1) == 3 ? v : 0u);
+        }
+        for (int C = 0; C < c0; ++C) {
+          const unsigned cn = chunk_no + C;
+          const int slot = cn & (S3_RING - 1);
+          lds_wait_ge(&ctl->rdy[slot], cn + 1);
+          const int d = C - wave;                      // this wave's tile index t (tile wave + 4 t) that chunk C concerns
+          if (d >= 0 && (d & (S3_NWC - 1)) == 0 && (d >> 2) < NTC) {
+            BSrc bs;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+              for (int p2 = 0; p2 < NP; ++p2) bs.p[c2][p2] = bs0.p[c2][p2] + slot * CHUNK;
+            uint4 b0[2][NP], b1[2][NP];
+            b_ld<0>(b0, bs);
+            b_ld<32>(b1, bs);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+              if (t == (d >> 2)) {
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                  // (the dense loop's order per accumulator: slab 2 C -- hi x lo, hi x hi --, then slab 2 C + 1)
+                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
+                                                                      __builtin_bit_cast(f16x8, b0[c2][1]), acc[t][c2], 0, 0, 0);
+                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
+                                                                      __builtin_bit_cast(f16x8, b0[c2][0]), acc[t][c2], 0, 0, 0);
+                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
+                                                                      __builtin_bit_cast(f16x8, b1[c2][1]), acc[t][c2], 0, 0, 0);
+                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
+                                                                      __builtin_bit_cast(f16x8, b1[c2][0]), acc[t][c2], 0, 0, 0);
+                }
+              }
+          }
+          lds_signal_add(&ctl->fin[slot], lane);
+        }
+      }
+    }
     // Software pipeline over the chunks: the fragments of a chunk's first slab are requested during the previous
     // chunk (after its first slab's MFMAs have been issued, so the ready poll and the LDS round trip run under MFMAs
     // that are already in the pipe); a chunk step therefore starts with b0 in registers.
     uint4 bA[2][NP], bB[2][NP];           // first-slab fragments of the current / next chunk, second-slab fragments
     {
-      const int slot = chunk_no & (S3_RING - 1);
-      lds_wait_ge(&ctl->rdy[slot], chunk_no + 1);
+      const int slot = (chunk_no + c0) & (S3_RING - 1);
+      lds_wait_ge(&ctl->rdy[slot], chunk_no + c0 + 1);
       BSrc bs;
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2)
@@ -606,7 +661,7 @@ struct S3Consumer {
     a_load<NTC, NTC>(ringA[((U0) + 3) & 3], w, 2 * (C) + 3);                                                \
     b_ld<32>(bB, bs_);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0)], bA, idz_ && (C) < a.nA);                               \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0)], bA);                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     a_load<NTC, NTC>(ringA[((U0) + 4) & 3], w, 2 * (C) + 4);                                                \
     if ((C) + 1 < n_chunks) {                                                                          \
@@ -618,11 +673,10 @@ struct S3Consumer {
       b_ld<0>(bA, bn_);                                                                                \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
-    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0) + 1], bB, idz_ && (C) < a.nA);                           \
+    mm_slab<AR, NTC, NMAX>(acc, ringA[(U0) + 1], bB);                                               \
     lds_signal_add(&ctl->fin[slot_], lane);                                                            \
   } while (0)
-    const bool idz_ = AR == 1 && a.ident_a != 0;
-    int c = 0;
+    int c = c0;
     for (; c + 2 <= n_full; c += 2) {
       S3_CHUNK_STEP(c, 0);
       S3_CHUNK_STEP(c + 1, 2);
