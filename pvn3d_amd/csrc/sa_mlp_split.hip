@@ -1034,6 +1034,8 @@ struct S3Consumer {
         }
       }
     } else {
+      // (16-byte stores need the row's channel offset and stride to be multiples of four floats and an aligned base)
+      const bool pm_vec = a.point_major && ((a.ld_out | a.coff) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
       for (int t = 0; t < NLAST; ++t) {
         const int mt = wave + S3_NWC * t;
@@ -1044,6 +1046,28 @@ struct S3Consumer {
             const int g0 = col0 + col, g1 = col0 + 32 + col;
             const float4 om4 = *reinterpret_cast<const float4*>(s_om + row);     // accumulator -> output, per row
             const float omk[4] = {om4.x, om4.y, om4.z, om4.w};
+            if (pm_vec && row + 3 < M) {
+              // point-major rows, four consecutive channels of a point: one 16-byte store per column tile (written value
+              // by value the compiler cannot prove the alignment and emits four 4-byte stores per lane and row group --
+              // 64 scattered dword stores per lane and block: 19 k of FP level 1's 73 k cycles per block)
+              float v0[4], v1[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v0[k] = fmaxf(acc[t][0][4 * g + k], 0.f) * omk[k];
+                v1[k] = fmaxf(acc[t][1][4 * g + k], 0.f) * omk[k];
+              }
+              if (g0 < a.cols_total) {
+                amax = fmaxf(amax, fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])));
+                *reinterpret_cast<float4*>(out + ((size_t)bi * a.cols_total + g0) * a.ld_out + a.coff + row) =
+                    make_float4(v0[0], v0[1], v0[2], v0[3]);
+              }
+              if (g1 < a.cols_total) {
+                amax = fmaxf(amax, fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3])));
+                *reinterpret_cast<float4*>(out + ((size_t)bi * a.cols_total + g1) * a.ld_out + a.coff + row) =
+                    make_float4(v1[0], v1[1], v1[2], v1[3]);
+              }
+              continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               if (row + k < M) {
