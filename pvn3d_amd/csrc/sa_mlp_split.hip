@@ -146,9 +146,9 @@ __device__ __forceinline__ void lds_wait_ge(const unsigned* p, unsigned v) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void lds_signal_add(unsigned* p, int lane) {
+__device__ __forceinline__ void lds_signal_add(unsigned* p, int lane, unsigned n = 1u) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // this wave's LDS traffic has completed
-  if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (lane == 0) __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // barrier of the MFMA waves only
 __device__ __forceinline__ void cbar(S3Ctl* ctl, unsigned& phase, int lane) {
@@ -492,6 +492,11 @@ struct S3Consumer {
   unsigned phase;          // barrier arrivals expected so far
   unsigned chunk_no;       // chunks of this workgroup consumed so far (all blocks)
   int blk_no;              // column blocks done (probe only)
+  // layer 0's xyz slab of a pre-contracted set-abstraction chain: the only weights of that layer that are not the unit
+  // matrix, the same for every column block -- loaded once per workgroup (with the identity chunks worked off in a few
+  // hundred cycles, their L2 round trip at the head of every block was 2.4 k of SA level 2's 23.8 k cycles per block)
+  uint4 w0t[2][s3_np(AR)];
+  int w0t_ok;
 
   template <int NTC>
   __device__ __forceinline__ WSrc<NTC> wsrc(int l, int slabs, int lane, int tile_base = 0) const {
@@ -563,7 +568,8 @@ struct S3Consumer {
       // once the chunk is there (waiting for it keeps the wave from running ahead of the waves that do read, whose
       // counts the loaders rely on before they refill a slot)
       const int n_ch = n_full + (tail ? 1 : 0);
-      for (int c = 0; c < n_ch; ++c) {
+      // (an identity chunk is read, and counted as finished for all four MFMA waves, by the wave whose row tile it concerns)
+      for (int c = (AR == 1 && a.ident_a != 0) ? a.nA : 0; c < n_ch; ++c) {
         const unsigned cn = chunk_no + c;
         const int slot = cn & (S3_RING - 1);
         lds_wait_ge(&ctl->rdy[slot], cn + 1);
@@ -581,10 +587,15 @@ struct S3Consumer {
     // The chunks that follow (skip features / xyz) run the pipelined loop below from chunk c0 on.
     const bool idz_ = AR == 1 && a.ident_a != 0;
     const int c0 = idz_ ? a.nA : 0;
+    const bool tail_only = idz_ && c0 == n_full;       // nothing but the xyz slab behind the identity chunks
     uint4 ringA[4][NTC][NP];
-    a_load<NTC, NTC>(ringA[0], w, 2 * c0);
-    a_load<NTC, NTC>(ringA[1], w, 2 * c0 + 1);
-    a_load<NTC, NTC>(ringA[2], w, 2 * c0 + 2);
+    if (tail_only) {
+      if (tail && !w0t_ok) { a_load<NTC, 2>(w0t, w, 2 * c0); w0t_ok = 1; }
+    } else {
+      a_load<NTC, NTC>(ringA[0], w, 2 * c0);
+      a_load<NTC, NTC>(ringA[1], w, 2 * c0 + 1);
+      a_load<NTC, NTC>(ringA[2], w, 2 * c0 + 2);
+    }
     // this lane's fragment addresses in ring slot 0; slot k is + k * CHUNK
     const BSrc bs0 = bsrc(ring + col * S3_CS + half * 16, S3_CPS, 32 * S3_CS);
     const int n_chunks = n_full + (tail ? 1 : 0);
@@ -601,12 +612,18 @@ struct S3Consumer {
           const unsigned v = (i >= 0 && i < 8) ? one << (16 * (i & 1)) : 0u;
           idA[j] = make_uint4((i >> 1) == 0 ? v : 0u, (i >> 1) == 1 ? v : 0u, (i >> 1) == 2 ? v : 0u, (i >> 1) == 3 ? v : 0u);
         }
-        for (int C = 0; C < c0; ++C) {
-          const unsigned cn = chunk_no + C;
-          const int slot = cn & (S3_RING - 1);
-          lds_wait_ge(&ctl->rdy[slot], cn + 1);
-          const int d = C - wave;                      // this wave's tile index t (tile wave + 4 t) that chunk C concerns
-          if (d >= 0 && (d & (S3_NWC - 1)) == 0 && (d >> 2) < NTC) {
+        S3_STAMP((wave == 0 && blk_no == 40 ? 32 : 1 << 20));                             // (probe builds: phase I of block 40 starts)
+        // chunk C is read by ONE wave -- the one whose row tile wave + 4 t equals C -- which also reports it finished for all
+        // four MFMA waves (the loaders wait for four reports per use of a slot): the other waves neither wait for it nor
+        // touch its control words (a poll and a fenced LDS atomic per chunk and wave were 550 cycles each: 1.6 k of SA
+        // level 2's 4.0 k cycles of layer 0, twice that at SA level 3)
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+          const int C = wave + S3_NWC * t;
+          if (C < c0) {
+            const unsigned cn = chunk_no + C;
+            const int slot = cn & (S3_RING - 1);
+            lds_wait_ge(&ctl->rdy[slot], cn + 1);
             BSrc bs;
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
@@ -616,24 +633,22 @@ struct S3Consumer {
             b_ld<0>(b0, bs);
             b_ld<32>(b1, bs);
 #pragma unroll
-            for (int t = 0; t < NTC; ++t)
-              if (t == (d >> 2)) {
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                  // (the dense loop's order per accumulator: slab 2 C -- hi x lo, hi x hi --, then slab 2 C + 1)
-                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
-                                                                      __builtin_bit_cast(f16x8, b0[c2][1]), acc[t][c2], 0, 0, 0);
-                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
-                                                                      __builtin_bit_cast(f16x8, b0[c2][0]), acc[t][c2], 0, 0, 0);
-                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
-                                                                      __builtin_bit_cast(f16x8, b1[c2][1]), acc[t][c2], 0, 0, 0);
-                  acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
-                                                                      __builtin_bit_cast(f16x8, b1[c2][0]), acc[t][c2], 0, 0, 0);
-                }
-              }
+            for (int c2 = 0; c2 < 2; ++c2) {
+              // (the dense loop's order per accumulator: slab 2 C -- hi x lo, hi x hi --, then slab 2 C + 1)
+              acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
+                                                                  __builtin_bit_cast(f16x8, b0[c2][1]), acc[t][c2], 0, 0, 0);
+              acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[0]),
+                                                                  __builtin_bit_cast(f16x8, b0[c2][0]), acc[t][c2], 0, 0, 0);
+              acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
+                                                                  __builtin_bit_cast(f16x8, b1[c2][1]), acc[t][c2], 0, 0, 0);
+              acc[t][c2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, idA[1]),
+                                                                  __builtin_bit_cast(f16x8, b1[c2][0]), acc[t][c2], 0, 0, 0);
+            }
+            lds_signal_add(&ctl->fin[slot], lane, (unsigned)S3_NWC);
+            S3_STAMP((wave == 0 && blk_no == 40 && t < 6 ? 33 + t : 1 << 20));             // (probe builds: own chunk t done)
           }
-          lds_signal_add(&ctl->fin[slot], lane);
         }
+        S3_STAMP((wave == 0 ? blk_no * 8 : 1 << 20) + 6);          // (probe builds: identity chunks done)
       }
     }
     // Software pipeline over the chunks: the fragments of a chunk's first slab are requested during the previous
@@ -688,11 +703,13 @@ struct S3Consumer {
       // the tail chunk's single slab: its fragments are already in bA
       const unsigned cn = chunk_no + n_full;
       const int slot = cn & (S3_RING - 1);
-      if (odd) mm_slab<AR, NTC, NMAX>(acc, ringA[2], bA);
+      if (tail_only) mm_slab<AR, NTC, NMAX, 2>(acc, w0t, bA);
+      else if (odd) mm_slab<AR, NTC, NMAX>(acc, ringA[2], bA);
       else mm_slab<AR, NTC, NMAX>(acc, ringA[0], bA);
       lds_signal_add(&ctl->fin[slot], lane);
     }
     chunk_no += n_full + (tail ? 1 : 0);
+    S3_STAMP((wave == 0 && blk_no == 40 ? 39 : 1 << 20));                                 // (probe builds: layer 0 of block 40 done)
   }
 
   // layers >= 1: the input is P.  Three row tiles per wave (NTC = 3: 96 accumulator registers) run a two-slot weight
@@ -2058,7 +2075,7 @@ static int s3_sa_entry(int arith, int b, int n, int m, int c, int nsample, const
   if (!s3_fill(&a, n_layers, dims_host, w_split, bias_padded)) return (int)hipErrorInvalidValue;
   if (arith == 1 && !s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, mul_b)) return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
-  a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
+  a.out_row_mul = out_row_mul; a.ident_a = ((flags & PVN3D_MLP_IDENTITY_A) && c == dims_host[1] && c % S3_KC == 0) ? 1 : 0;   // (a unit block needs a square, chunk-aligned table part)
   a.is_sa = 1;
   a.xyz = xyz; a.new_xyz = new_xyz; a.n = n; a.m = m; a.ns = nsample;
   a.idx = idx;
@@ -2115,7 +2132,7 @@ static int s3_fp_entry(int arith, int b, int n, int m, int c2, int c1, const flo
   if (arith == 1 && (!s3_fill_scales(&a, n_layers, layer_meta, bound_a, bound_b, 1.f) || (c1 > 0 && !bound_b)))
     return (int)hipErrorInvalidValue;
   a.out_absmax = (unsigned*)out_absmax;
-  a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
+  a.out_row_mul = out_row_mul; a.ident_a = ((flags & PVN3D_MLP_IDENTITY_A) && c2 == dims_host[1] && c2 % S3_KC == 0) ? 1 : 0;
   a.is_sa = 0;
   a.idx = idx; a.weight = weight;
   a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known; a.nA = c2 / S3_KC;
@@ -2169,7 +2186,7 @@ extern "C" int pvn3d_fp_interp_add_mlp_split2(int b, int n, int m, int c2, int c
         !s3_fill_scales(&a, n_layers, layer_meta, known_absmax, unknown_absmax, 1.f))
       return (int)hipErrorInvalidValue;
     a.out_absmax = (unsigned*)out_absmax;
-    a.out_row_mul = out_row_mul; a.ident_a = (flags & PVN3D_MLP_IDENTITY_A) ? 1 : 0;
+    a.out_row_mul = out_row_mul; a.ident_a = ((flags & PVN3D_MLP_IDENTITY_A) && c2 == dims_host[1] && c2 % S3_KC == 0) ? 1 : 0;
     a.is_sa = 0;
     a.idx = idx; a.weight = weight;
     a.tabA = known_pm; a.rowsA = m; a.ldA = ld_known;

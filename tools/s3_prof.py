@@ -48,12 +48,15 @@ f = lib.pvn3d_debug_s3_prof_read          # exported by the -DPVN3D_S3_TUNING bu
 f.argtypes = [ctypes.c_void_p]
 assert f(buf) == 0
 t = np.array(buf[:], dtype=np.int64)
-names = ["start", "layer0 done", "bar", "store0+bar", "layer1 done", "bar+store1+bar", "layer2 done", "epilogue done"]
+names = ["start", "layer0 done", "bar", "store0+bar", "layer1 done", "bar+store1+bar", "(layer 0: identity chunks done)", "epilogue done"]
 t0 = t[0]
 for blk in range(4):
     row = t[blk * 8:blk * 8 + 8] - t0
     print("block %d:" % blk, "  ".join("%s %d" % (n, v) for n, v in zip(names, row)))
     print("        deltas:", np.diff(row))
+row = t[32:40] - t[32]
+print("layer 0 of block 40, MFMA wave 0, cycles since phase I started: identity chunk k done %s, layer 0 done %d" % (
+    [int(v) for v in row[1:7]], int(row[7])))
 rt = t[128:256]
 dc, dr = float(t[3 * 8 + 7] - t[0]), float(rt[3 * 8 + 7] - rt[0])
 print("four blocks: %.0f cycles in %.2f us on the real-time counter -> shader clock %.2f GHz" % (dc, dr / 100.0, dc / max(dr, 1.0) / 10.0))
